@@ -1,0 +1,287 @@
+"""CPU restatement of the TargetDiff denoising hot path (TEST INFRASTRUCTURE -- the parity checker).
+
+This file is NOT the product and is never imported from ``targetdiff_amd/``.  It restates, in plain
+torch-on-CPU (fp32 by default, fp64 on request), what the reference computes on the path
+
+    scripts/sample_diffusion.py:31  sample_diffusion_ligand
+      -> models/molopt_score_model.py:633  ScorePosNet3D.sample_diffusion
+      -> models/molopt_score_model.py:313  ScorePosNet3D.forward
+      -> models/uni_transformer.py:301     UniTransformerO2TwoUpdateGeneral.forward
+
+for the live configuration (configs/training.yml:9-42).  It works on a dense neighbour table
+``nbr[N, k]`` (row i = the in-edges of node i) instead of the reference's ``edge_index`` lists, so it
+shares no code structure with either the reference or the HIP kernels.  It is pinned against golden
+vectors produced by the *real* reference model files (``oracle/make_golden.py`` ->
+``tests/golden/*.npz``; checked in ``tests/test_oracle_golden.py``).
+
+Third-party semantics (kNN tie rule, scatter ops) are parity-unpinned upstream; see ``oracle/shims.py``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .shims import knn_neighbours
+from .weights import DEFAULT_MODEL_CONFIG
+
+
+# ----------------------------------------------------------------------------------------- schedules
+def diffusion_schedules(cfg=None):
+    """float64 numpy restatement of models/molopt_score_model.py:47-97 and :221-267; returns fp32 tensors."""
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    T = cfg['num_diffusion_timesteps']
+
+    def cosine_alphas(steps_T, s):                       # :81-97
+        steps = steps_T + 1
+        xx = np.linspace(0, steps, steps)
+        ac = np.cos(((xx / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+        ac = ac / ac[0]
+        al = np.clip(ac[1:] / ac[:-1], a_min=0.001, a_max=1.)
+        return np.sqrt(al)
+
+    if cfg['beta_schedule'] == 'cosine':                  # :221-224
+        alphas = cosine_alphas(T, cfg['pos_beta_s']) ** 2
+        betas = 1. - alphas
+    elif cfg['beta_schedule'] == 'sigmoid':               # :72-74
+        b = np.linspace(-6, 6, T)
+        betas = 1 / (np.exp(-b) + 1) * (cfg['beta_end'] - cfg['beta_start']) + cfg['beta_start']
+        alphas = 1. - betas
+    elif cfg['beta_schedule'] == 'linear':
+        betas = np.linspace(cfg['beta_start'], cfg['beta_end'], T, dtype=np.float64)
+        alphas = 1. - betas
+    else:
+        raise NotImplementedError(cfg['beta_schedule'])
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1., ac[:-1])
+    post_var = betas * (1. - ac_prev) / (1. - ac)         # :248
+    out = {
+        'betas': betas,
+        'alphas_cumprod': ac,
+        'posterior_mean_c0_coef': betas * np.sqrt(ac_prev) / (1. - ac),            # :249
+        'posterior_mean_ct_coef': (1. - ac_prev) * np.sqrt(alphas) / (1. - ac),    # :250-251
+    }
+    # :253-254 -- NB the reference takes the log of the *fp32-rounded* posterior_var tensor.
+    pv32 = post_var.astype(np.float32)
+    out['posterior_logvar'] = np.log(np.append(pv32[1], pv32[1:]))
+    alphas_v = cosine_alphas(T, cfg['v_beta_s'])          # :257-262
+    log_a = np.log(alphas_v)
+    log_ca = np.cumsum(log_a)
+    l1m = lambda a: np.log(1 - np.exp(a) + 1e-40)         # :169-170
+    out['log_alphas_v'] = log_a
+    out['log_one_minus_alphas_v'] = l1m(log_a)
+    out['log_alphas_cumprod_v'] = log_ca
+    out['log_one_minus_alphas_cumprod_v'] = l1m(log_ca)
+    return {k: torch.from_numpy(np.asarray(v)).float() for k, v in out.items()}
+
+
+# ----------------------------------------------------------------------------------------- building blocks
+def _mlp(sd, prefix, x, dtype):
+    """models/common.py:60-80: Linear -> LayerNorm(eps 1e-5) -> ReLU -> Linear."""
+    w0, b0 = sd[f'{prefix}.net.0.weight'].to(dtype), sd[f'{prefix}.net.0.bias'].to(dtype)
+    g, b = sd[f'{prefix}.net.1.weight'].to(dtype), sd[f'{prefix}.net.1.bias'].to(dtype)
+    w3, b3 = sd[f'{prefix}.net.3.weight'].to(dtype), sd[f'{prefix}.net.3.bias'].to(dtype)
+    y = F.linear(x, w0, b0)
+    y = F.layer_norm(y, (y.shape[-1],), g, b, 1e-5)
+    return F.linear(torch.relu(y), w3, b3)
+
+
+def gaussian_smearing(dist, offset):
+    """models/common.py:24-26 with coeff = -0.5/(offset[1]-offset[0])**2 (:18)."""
+    coeff = -0.5 / float(offset[1] - offset[0]) ** 2
+    return torch.exp(coeff * (dist.unsqueeze(-1) - offset) ** 2)
+
+
+def edge_types(nbr, mask_ligand):
+    """models/uni_transformer.py:288-299.  type: 0 l<-l, 1 (src lig, dst prot), 2 (src prot, dst lig), 3 p<-p."""
+    src_l = mask_ligand[nbr.clamp(min=0)]
+    dst_l = mask_ligand.unsqueeze(1).expand_as(nbr)
+    t = torch.full(nbr.shape, 3, dtype=torch.long)
+    t[src_l & dst_l] = 0
+    t[src_l & ~dst_l] = 1
+    t[~src_l & dst_l] = 2
+    return t
+
+
+def _kv_input(h, nbr, etype, gfeat, sl):
+    """[edge_type one-hot(4) | r_feat(80, type-major) | h_i | h_j]  (models/uni_transformer.py:45-51,
+    models/common.py:83-90) for the node slice ``sl``; returns [n, k, 340]."""
+    n, k = nbr[sl].shape
+    oh = F.one_hot(etype[sl], 4).to(h.dtype)                                   # [n,k,4]
+    r_feat = (oh.unsqueeze(-1) * gfeat.unsqueeze(-2)).reshape(n, k, -1)       # [n,k,80]
+    hi = h[sl].unsqueeze(1).expand(n, k, h.shape[-1])
+    hj = h[nbr[sl].clamp(min=0)]
+    return torch.cat([oh, r_feat, hi, hj], dim=-1)
+
+
+def _segment_softmax(logits, valid):
+    """scatter_softmax over the in-edges of each node (models/uni_transformer.py:73,135)."""
+    logits = logits.masked_fill(~valid.unsqueeze(-1), float('-inf'))
+    m = logits.max(dim=1, keepdim=True).values
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    e = torch.exp(logits - m)
+    e = e * valid.unsqueeze(-1).to(e.dtype)
+    s = e.sum(dim=1, keepdim=True)
+    return e / torch.where(s > 0, s, torch.ones_like(s))
+
+
+def refine_forward(sd, cfg, h, x, mask_ligand, batch, fix_x=False, dtype=torch.float32, chunk=4096,
+                   prefix='refine_net', collect=None):
+    """UniTransformerO2TwoUpdateGeneral.forward (models/uni_transformer.py:301-328), num_blocks == 1.
+
+    ``collect``: optional dict filled with intermediates (nbr, e_w, per-layer h/x) for stage-wise parity.
+    """
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    assert cfg['num_blocks'] == 1 and cfg['cutoff_mode'] == 'knn' and cfg['ew_net_type'] == 'global'
+    k, heads, H = cfg['knn'], cfg['n_heads'], cfg['hidden_dim']
+    dh = H // heads
+    h = h.to(dtype)
+    x = x.to(dtype)
+    N = h.shape[0]
+    nbr = knn_neighbours(x.float(), k, batch)                       # :307 -> :280 (fp32 compare by contract)
+    valid = nbr >= 0
+    etype = edge_types(nbr, mask_ligand)                            # :311
+    nb = nbr.clamp(min=0)
+    offset = sd[f'{prefix}.distance_expansion.offset'].to(dtype)
+    dist0 = (x.unsqueeze(1) - x[nb]).norm(dim=-1)                   # :313
+    e_w = torch.sigmoid(_mlp(sd, f'{prefix}.edge_pred_layer', gaussian_smearing(dist0, offset), dtype))  # :314-316
+    e_w = e_w.squeeze(-1)
+    if collect is not None:
+        collect.update(nbr=nbr.clone(), e_w=e_w.clone(), etype=etype.clone(), h_layers=[], x_layers=[])
+    scale = 1.0 / math.sqrt(dh)
+    for l in range(cfg['num_layers']):
+        p = f'{prefix}.base_block.{l}'
+        off_l = sd[f'{p}.distance_expansion.offset'].to(dtype)
+        rel = x.unsqueeze(1) - x[nb]                                # :188  x[dst]-x[src]
+        dist = rel.norm(dim=-1)                                     # :189
+        gfeat = gaussian_smearing(dist, off_l)                      # :194
+        # ---- x2h (BaseX2HAttLayer.forward :42-84) ------------------------------------------------
+        h_new = torch.empty_like(h)
+        for s in range(0, N, chunk):
+            sl = slice(s, min(N, s + chunk))
+            kv = _kv_input(h, nbr, etype, gfeat[sl], sl)
+            kk = _mlp(sd, f'{p}.x2h_layers.0.hk_func', kv, dtype).view(-1, k, heads, dh)      # :54
+            vv = _mlp(sd, f'{p}.x2h_layers.0.hv_func', kv, dtype) * e_w[sl].unsqueeze(-1)     # :56-65
+            vv = vv.view(-1, k, heads, dh)
+            q = _mlp(sd, f'{p}.x2h_layers.0.hq_func', h[sl], dtype).view(-1, 1, heads, dh)    # :70
+            alpha = _segment_softmax((q * kk * scale).sum(-1), valid[sl])                      # :73
+            out = (alpha.unsqueeze(-1) * vv).sum(dim=1).reshape(-1, H)                         # :77-79
+            h_new[sl] = out + h[sl]                                                             # :83
+        # ---- h2x (BaseH2XAttLayer.forward :108-140), uses the updated h (sync_twoup False :198) ----
+        dx = torch.zeros_like(x)
+        if not fix_x:
+            lig_idx = torch.nonzero(mask_ligand).squeeze(1)         # output is masked for protein rows (:206)
+            for s in range(0, lig_idx.numel(), chunk):
+                ids = lig_idx[s:s + chunk]
+                kv = _kv_input(h_new, nbr, etype, gfeat[ids], ids)
+                kk = _mlp(sd, f'{p}.h2x_layers.0.xk_func', kv, dtype).view(-1, k, heads, dh)   # :120
+                vv = _mlp(sd, f'{p}.h2x_layers.0.xv_func', kv, dtype) * e_w[ids].unsqueeze(-1)  # :121-130
+                q = _mlp(sd, f'{p}.h2x_layers.0.xq_func', h_new[ids], dtype).view(-1, 1, heads, dh)  # :133
+                alpha = _segment_softmax((q * kk * scale).sum(-1), valid[ids])                 # :135
+                m = (alpha * vv).unsqueeze(-1) * rel[ids].unsqueeze(2)                          # :132,138
+                dx[ids] = m.sum(dim=1).mean(dim=1)                                              # :139-140
+            x = x + dx * mask_ligand.unsqueeze(-1).to(dtype)                                    # :205-206
+        h = h_new
+        if collect is not None:
+            collect['h_layers'].append(h.clone())
+            collect['x_layers'].append(x.clone())
+    return {'x': x, 'h': h}
+
+
+def compose_context(h_p, h_l, pos_p, pos_l, batch_p, batch_l):
+    """models/common.py:120-137 (stable sort by graph id => per graph [protein..., ligand...])."""
+    batch_ctx = torch.cat([batch_p, batch_l])
+    idx = torch.sort(batch_ctx, stable=True).indices
+    mask = torch.cat([torch.zeros(len(batch_p), dtype=torch.bool), torch.ones(len(batch_l), dtype=torch.bool)])[idx]
+    return torch.cat([h_p, h_l])[idx], torch.cat([pos_p, pos_l])[idx], batch_ctx[idx], mask
+
+
+def model_forward(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand,
+                  fix_x=False, dtype=torch.float32, collect=None):
+    """ScorePosNet3D.forward (models/molopt_score_model.py:313-368), time_emb_dim == 0, node_indicator."""
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    C = sd['ligand_atom_emb.weight'].shape[1]
+    lv = F.one_hot(ligand_v, C).to(dtype)                                                       # :317
+    h_p = F.linear(protein_v.to(dtype), sd['protein_atom_emb.weight'].to(dtype), sd['protein_atom_emb.bias'].to(dtype))
+    h_l = F.linear(lv, sd['ligand_atom_emb.weight'].to(dtype), sd['ligand_atom_emb.bias'].to(dtype))  # :333-334
+    if cfg['node_indicator']:                                                                   # :336-338
+        h_p = torch.cat([h_p, torch.zeros(len(h_p), 1, dtype=dtype)], -1)
+        h_l = torch.cat([h_l, torch.ones(len(h_l), 1, dtype=dtype)], -1)
+    h, pos, batch_all, mask = compose_context(h_p, h_l, protein_pos.to(dtype), ligand_pos.to(dtype),
+                                              batch_protein, batch_ligand)                      # :340
+    out = refine_forward(sd, cfg, h, pos, mask, batch_all, fix_x=fix_x, dtype=dtype, collect=collect)  # :349
+    fh = out['h'][mask]
+    y = F.linear(fh, sd['v_inference.0.weight'].to(dtype), sd['v_inference.0.bias'].to(dtype))
+    y = F.softplus(y) - math.log(2.0)                                                           # common.py:156-162
+    v = F.linear(y, sd['v_inference.2.weight'].to(dtype), sd['v_inference.2.bias'].to(dtype))   # :352
+    return {'pred_ligand_pos': out['x'][mask], 'pred_ligand_v': v, 'final_h': out['h'], 'final_ligand_h': fh}
+
+
+# ----------------------------------------------------------------------------------------- posterior
+def _log_add_exp(a, b):
+    m = torch.max(a, b)                                                                          # :173-175
+    return m + torch.log(torch.exp(a - m) + torch.exp(b - m))
+
+
+def posterior_step(sched, t, ligand_pos, ligand_v, pred_pos, pred_v, batch_ligand, noise, uniform,
+                   num_classes):
+    """One reverse step (models/molopt_score_model.py:673-685): Gaussian posterior mean + injected noise,
+    categorical posterior in log space + Gumbel-max with injected uniforms.  ``t``: int64 [B]."""
+    tb = t[batch_ligand]
+    c0 = sched['posterior_mean_c0_coef'][tb].unsqueeze(-1)                                       # :424-428, :706-708
+    ct = sched['posterior_mean_ct_coef'][tb].unsqueeze(-1)
+    mean = c0 * pred_pos + ct * ligand_pos
+    logvar = sched['posterior_logvar'][tb].unsqueeze(-1)
+    nz = (1 - (t == 0).float())[batch_ligand].unsqueeze(-1)                                      # :676
+    pos_next = mean + nz * (0.5 * logvar).exp() * noise                                          # :677
+    log_v0 = F.log_softmax(pred_v, dim=-1)                                                       # :682
+    log_vt = torch.log(F.one_hot(ligand_v, num_classes).float().clamp(min=1e-30))                # :124-130
+    tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)[batch_ligand]                       # :403-405
+    lnK = np.log(num_classes)
+    log_q_tm1 = _log_add_exp(log_v0 + sched['log_alphas_cumprod_v'][tm1].unsqueeze(-1),
+                             sched['log_one_minus_alphas_cumprod_v'][tm1].unsqueeze(-1) - lnK)   # :383-392
+    log_q_one = _log_add_exp(log_vt + sched['log_alphas_v'][tb].unsqueeze(-1),
+                             sched['log_one_minus_alphas_v'][tb].unsqueeze(-1) - lnK)            # :371-381
+    un = log_q_tm1 + log_q_one
+    log_post = un - torch.logsumexp(un, dim=-1, keepdim=True)                                    # :407-408
+    gumbel = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)                                     # :160-166
+    v_next = (gumbel + log_post).argmax(dim=-1)
+    return pos_next, v_next, log_v0, log_post
+
+
+def center_positions(protein_pos, ligand_pos, batch_protein, batch_ligand):
+    """center_pos(mode='protein') (models/molopt_score_model.py:110-120): per-graph protein centroid."""
+    B = int(batch_protein.max()) + 1
+    s = torch.zeros(B, 3, dtype=protein_pos.dtype).index_add_(0, batch_protein, protein_pos)
+    c = torch.bincount(batch_protein, minlength=B).clamp(min=1).to(protein_pos.dtype).unsqueeze(-1)
+    off = s / c
+    return protein_pos - off[batch_protein], ligand_pos - off[batch_ligand], off
+
+
+def sample_diffusion(sd, cfg, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
+                     batch_ligand, num_steps=None, noises=None, uniforms=None, record=False):
+    """ScorePosNet3D.sample_diffusion (models/molopt_score_model.py:633-703), center_pos_mode='protein',
+    with the per-step Gaussian / uniform draws injected (``noises[s]`` [N_l,3], ``uniforms[s]`` [N_l,K])."""
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    sched = diffusion_schedules(cfg)
+    T = cfg['num_diffusion_timesteps']
+    num_steps = T if num_steps is None else num_steps
+    K = sd['ligand_atom_emb.weight'].shape[1]
+    B = int(batch_protein.max()) + 1
+    ppos, lpos, off = center_positions(protein_pos, init_ligand_pos, batch_protein, batch_ligand)   # :642
+    lv = init_ligand_v
+    traj = {'pos_traj': [], 'v_traj': [], 'v0_traj': [], 'vt_traj': []}
+    for s, i in enumerate(reversed(range(T - num_steps, T))):                                       # :649
+        t = torch.full((B,), i, dtype=torch.long)
+        preds = model_forward(sd, cfg, ppos, protein_v, batch_protein, lpos, lv, batch_ligand)
+        lpos, lv, log_v0, log_post = posterior_step(sched, t, lpos, lv, preds['pred_ligand_pos'],
+                                                    preds['pred_ligand_v'], batch_ligand,
+                                                    noises[s], uniforms[s], K)
+        if record:
+            traj['pos_traj'].append((lpos + off[batch_ligand]).clone())
+            traj['v_traj'].append(lv.clone())
+            traj['v0_traj'].append(log_v0.clone())
+            traj['vt_traj'].append(log_post.clone())
+    return dict(pos=lpos + off[batch_ligand], v=lv, **traj)

@@ -1,0 +1,191 @@
+"""Pure-torch stand-ins for the third-party ops on the reference hot path (TEST INFRASTRUCTURE).
+
+The reference pins pytorch-scatter 2.1.0, pytorch-cluster 1.6.0 and pyg 2.2.0
+(/root/reference/environment.yaml:185,196,199); none of them is installed here and their sources are
+not under /root/reference, so the arithmetic below restates their *published* semantics
+(SURVEY.md Appendix B).  Call sites pinned on:
+
+* ``knn_graph``       models/uni_transformer.py:280, models/egnn.py:99, models/common.py:199
+* ``scatter_softmax`` models/uni_transformer.py:73,135
+* ``scatter_sum``     models/uni_transformer.py:78,139, models/egnn.py:53,61
+* ``scatter_mean``    models/molopt_score_model.py:115, scripts/sample_diffusion.py:61
+
+The kNN tie/rounding rule is unpinned upstream (CUDA kernel vs CPU KD-tree disagree on ties); the rule
+adopted for this project -- and followed bit-for-bit by the HIP kernel -- is:
+
+    d2(i, j) = (dx*dx + dy*dy) + dz*dz     in fp32, no FMA contraction, dx = x_j - x_i
+    neighbours of i = the k smallest (d2, j) pairs, j != i, j in the same graph, ascending.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import torch
+
+
+# --------------------------------------------------------------------------- torch_scatter
+def _broadcast_index(index: torch.Tensor, src: torch.Tensor, dim: int) -> torch.Tensor:
+    if dim < 0:
+        dim = src.dim() + dim
+    if index.dim() == 1:
+        for _ in range(dim):
+            index = index.unsqueeze(0)
+    while index.dim() < src.dim():
+        index = index.unsqueeze(-1)
+    return index.expand(src.size())
+
+
+def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+    index = _broadcast_index(index, src, dim)
+    if out is None:
+        size = list(src.size())
+        if dim_size is not None:
+            size[dim] = dim_size
+        elif index.numel() == 0:
+            size[dim] = 0
+        else:
+            size[dim] = int(index.max()) + 1
+        out = torch.zeros(size, dtype=src.dtype, device=src.device)
+    return out.scatter_add_(dim, index, src)
+
+
+def scatter_add(src, index, dim=-1, out=None, dim_size=None):
+    return scatter_sum(src, index, dim, out, dim_size)
+
+
+def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
+    out = scatter_sum(src, index, dim, out, dim_size)
+    dim_size = out.size(dim)
+    index_dim = dim
+    if index_dim < 0:
+        index_dim = index_dim + src.dim()
+    if index.dim() <= index_dim:
+        index_dim = index.dim() - 1
+    ones = torch.ones(index.size(), dtype=src.dtype, device=src.device)
+    count = scatter_sum(ones, index, index_dim, None, dim_size)
+    count[count < 1] = 1
+    count = _broadcast_index(count, out, dim) if count.dim() == 1 else count
+    if out.is_floating_point():
+        out.true_divide_(count)
+    else:
+        out.div_(count, rounding_mode='floor')
+    return out
+
+
+def scatter_max(src, index, dim=-1, dim_size=None):
+    index_b = _broadcast_index(index, src, dim)
+    size = list(src.size())
+    size[dim] = dim_size if dim_size is not None else int(index.max()) + 1
+    out = torch.full(size, float('-inf'), dtype=src.dtype, device=src.device)
+    out = out.scatter_reduce(dim, index_b, src, reduce='amax', include_self=True)
+    return out
+
+
+def scatter_softmax(src, index, dim=-1, dim_size=None):
+    if not torch.is_floating_point(src):
+        raise ValueError('scatter_softmax needs floating point input')
+    index_b = _broadcast_index(index, src, dim)
+    max_per = scatter_max(src, index, dim, dim_size)
+    rec = (src - max_per.gather(dim, index_b)).exp_()
+    sum_per = scatter_sum(rec, index_b, dim, dim_size=dim_size)
+    return rec.div(sum_per.gather(dim, index_b))
+
+
+def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum'):
+    if reduce in ('sum', 'add'):
+        return scatter_sum(src, index, dim, out, dim_size)
+    if reduce == 'mean':
+        return scatter_mean(src, index, dim, out, dim_size)
+    raise NotImplementedError(reduce)
+
+
+# --------------------------------------------------------------------------- torch_geometric.nn
+def knn_neighbours(x: torch.Tensor, k: int, batch: torch.Tensor | None = None) -> torch.Tensor:
+    """Dense neighbour table [N, k] (int64, -1 padded) under the project's kNN rule (module docstring)."""
+    N = x.size(0)
+    if batch is None:
+        batch = torch.zeros(N, dtype=torch.long, device=x.device)
+    assert bool((batch[1:] >= batch[:-1]).all()), 'batch must be sorted'
+    out = torch.full((N, k), -1, dtype=torch.long, device=x.device)
+    if N == 0:
+        return out
+    counts = torch.bincount(batch)
+    start = 0
+    for n in counts.tolist():
+        if n == 0:
+            continue
+        xs = x[start:start + n].to(torch.float32)
+        dx = xs[None, :, 0] - xs[:, None, 0]
+        dy = xs[None, :, 1] - xs[:, None, 1]
+        dz = xs[None, :, 2] - xs[:, None, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz            # separate mul/add kernels: no FMA contraction
+        d2.fill_diagonal_(float('inf'))
+        kk = min(k, n - 1)
+        if kk > 0:
+            # stable sort => ties resolved towards the lower index
+            order = torch.sort(d2, dim=1, stable=True).indices[:, :kk]
+            out[start:start + n, :kk] = order + start
+        start += n
+    return out
+
+
+def knn_graph(x, k, batch=None, loop=False, flow='source_to_target', cosine=False, num_workers=1):
+    """edge_index [2, E]: row 0 = source (neighbour), row 1 = target (query); grouped by target ascending,
+    ascending distance inside a group (torch_geometric.nn.knn_graph, flow='source_to_target')."""
+    assert not loop and not cosine and flow == 'source_to_target'
+    nbr = knn_neighbours(x, k, batch)
+    dst = torch.arange(x.size(0), device=x.device).view(-1, 1).expand_as(nbr)
+    keep = nbr >= 0
+    return torch.stack([nbr[keep], dst[keep]], dim=0)
+
+
+def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow='source_to_target', num_workers=1):
+    raise NotImplementedError('radius_graph is dead code in the reference (models/uni_transformer.py:278 '
+                              'reads self.r which is never assigned)')
+
+
+# --------------------------------------------------------------------------- easydict
+class EasyDict(dict):
+    """Attribute dict used by the reference config loader (utils/misc.py:23-25)."""
+
+    def __init__(self, d=None, **kwargs):
+        super().__init__()
+        d = dict(d or {})
+        d.update(kwargs)
+        for key, val in d.items():
+            self[key] = val
+
+    def __setitem__(self, key, val):
+        if isinstance(val, dict) and not isinstance(val, EasyDict):
+            val = EasyDict(val)
+        super().__setitem__(key, val)
+
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError as exc:
+            raise AttributeError(key) from exc
+
+    __setattr__ = __setitem__
+
+
+def install() -> None:
+    """Register the shims under the third-party module names the reference imports."""
+    if 'torch_scatter' not in sys.modules:
+        m = types.ModuleType('torch_scatter')
+        for name in ('scatter_sum', 'scatter_add', 'scatter_mean', 'scatter_softmax', 'scatter_max', 'scatter'):
+            setattr(m, name, globals()[name])
+        sys.modules['torch_scatter'] = m
+    if 'torch_geometric' not in sys.modules:
+        tg = types.ModuleType('torch_geometric')
+        tgnn = types.ModuleType('torch_geometric.nn')
+        tgnn.knn_graph = knn_graph
+        tgnn.radius_graph = radius_graph
+        tg.nn = tgnn
+        sys.modules['torch_geometric'] = tg
+        sys.modules['torch_geometric.nn'] = tgnn
+    if 'easydict' not in sys.modules:
+        ed = types.ModuleType('easydict')
+        ed.EasyDict = EasyDict
+        sys.modules['easydict'] = ed

@@ -1,0 +1,118 @@
+"""Deterministic weights for parity tests and benchmarks (TEST INFRASTRUCTURE).
+
+No pretrained checkpoint ships with the reference (pretrained_models/.gitignore), so parity is against
+seeded random weights.  To be independent of module-construction order, every tensor is drawn from its
+own generator seeded by (seed, crc32(key)); the same ``state_dict`` loads into the real reference model
+(``make_golden.py``), into the restatement and into ``targetdiff_amd.ScorePosNet3D``.
+
+Key names and shapes restate SURVEY.md Appendix C (reference: models/molopt_score_model.py:236-311,
+models/uni_transformer.py:26-40,102-106,230-274, models/common.py:60-80); ``make_golden.py`` asserts they
+match the real reference ``state_dict`` exactly.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import torch
+
+# configs/training.yml:9-42 (model section), the live configuration of the sampler.
+DEFAULT_MODEL_CONFIG = dict(
+    model_mean_type='C0', beta_schedule='sigmoid', beta_start=1.e-7, beta_end=2.e-3,
+    v_beta_schedule='cosine', v_beta_s=0.01, num_diffusion_timesteps=1000, loss_v_weight=100.,
+    sample_time_method='symmetric', time_emb_dim=0, time_emb_mode='simple', center_pos_mode='protein',
+    node_indicator=True, model_type='uni_o2', num_blocks=1, num_layers=9, hidden_dim=128, n_heads=16,
+    edge_feat_dim=4, num_r_gaussian=20, knn=32, num_node_types=8, act_fn='relu', norm=True,
+    cutoff_mode='knn', ew_net_type='global', num_x2h=1, num_h2x=1, r_max=10., x2h_out_fc=False,
+    sync_twoup=False,
+)
+
+PROTEIN_FEATURE_DIM = 27   # utils/transforms.py:115-124 (6 elements + 20 amino acids + backbone flag)
+LIGAND_FEATURE_DIM = 13    # utils/transforms.py:48-62 ('add_aromatic' map)
+
+
+def _mlp_spec(prefix, in_dim, hidden, out_dim):
+    return [
+        (f'{prefix}.net.0.weight', (hidden, in_dim), 'linear', in_dim),
+        (f'{prefix}.net.0.bias', (hidden,), 'bias', in_dim),
+        (f'{prefix}.net.1.weight', (hidden,), 'ln_w', 0),
+        (f'{prefix}.net.1.bias', (hidden,), 'ln_b', 0),
+        (f'{prefix}.net.3.weight', (out_dim, hidden), 'linear', hidden),
+        (f'{prefix}.net.3.bias', (out_dim,), 'bias', hidden),
+    ]
+
+
+def _att_layer_spec(prefix, cfg, num_x2h, num_h2x):
+    H, heads = cfg['hidden_dim'], cfg['n_heads']
+    kv_in = 2 * H + cfg['edge_feat_dim'] + 4 * cfg['num_r_gaussian']
+    spec = [(f'{prefix}.distance_expansion.offset', (cfg['num_r_gaussian'],), 'offset', 0)]
+    for i in range(num_x2h):
+        p = f'{prefix}.x2h_layers.{i}'
+        spec += _mlp_spec(f'{p}.hk_func', kv_in, H, H)
+        spec += _mlp_spec(f'{p}.hv_func', kv_in, H, H)
+        spec += _mlp_spec(f'{p}.hq_func', H, H, H)
+    for i in range(num_h2x):
+        p = f'{prefix}.h2x_layers.{i}'
+        spec += _mlp_spec(f'{p}.xk_func', kv_in, H, H)
+        spec += _mlp_spec(f'{p}.xv_func', kv_in, H, heads)
+        spec += _mlp_spec(f'{p}.xq_func', H, H, H)
+    return spec
+
+
+def parameter_spec(cfg=None, protein_dim=PROTEIN_FEATURE_DIM, ligand_dim=LIGAND_FEATURE_DIM):
+    """[(key, shape, kind, fan_in)] for every learnable tensor / fixed offset of the default model."""
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    assert cfg['model_type'] == 'uni_o2' and cfg['time_emb_dim'] == 0 and cfg['ew_net_type'] == 'global'
+    assert not cfg['x2h_out_fc']
+    H = cfg['hidden_dim']
+    emb = H - 1 if cfg['node_indicator'] else H
+    spec = [
+        ('protein_atom_emb.weight', (emb, protein_dim), 'linear', protein_dim),
+        ('protein_atom_emb.bias', (emb,), 'bias', protein_dim),
+        ('ligand_atom_emb.weight', (emb, ligand_dim), 'linear', ligand_dim),
+        ('ligand_atom_emb.bias', (emb,), 'bias', ligand_dim),
+        ('refine_net.distance_expansion.offset', (cfg['num_r_gaussian'],), 'offset', 0),
+    ]
+    spec += _mlp_spec('refine_net.edge_pred_layer', cfg['num_r_gaussian'], H, 1)
+    # init_h_emb_layer: built with num_init_x2h=1, num_init_h2x=0 and never called
+    # (models/uni_transformer.py:245,255-261 vs :301-328); present in checkpoints.
+    spec += _att_layer_spec('refine_net.init_h_emb_layer', cfg, 1, 0)
+    for l in range(cfg['num_layers']):
+        spec += _att_layer_spec(f'refine_net.base_block.{l}', cfg, cfg['num_x2h'], cfg['num_h2x'])
+    spec += [
+        ('v_inference.0.weight', (H, H), 'linear', H),
+        ('v_inference.0.bias', (H,), 'bias', H),
+        ('v_inference.2.weight', (ligand_dim, H), 'linear', H),
+        ('v_inference.2.bias', (ligand_dim,), 'bias', H),
+    ]
+    return spec
+
+
+GAUSSIAN_OFFSETS = [0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10]
+"""models/common.py:15 (fixed_offset=True)."""
+
+
+def make_state_dict(seed: int = 2021, cfg=None, protein_dim=PROTEIN_FEATURE_DIM,
+                    ligand_dim=LIGAND_FEATURE_DIM, gain: float = 1.0) -> 'OrderedDict[str, torch.Tensor]':
+    """Learnable tensors only (load with strict=False: schedule constants/buffers come from the config).
+
+    Linear weights/biases ~ U(-b, b), b = gain/sqrt(fan_in) (nn.Linear's default range when gain=1);
+    LayerNorm weight = 1 + 0.2*N(0,1), bias = 0.1*N(0,1) so the affine terms are exercised.
+    """
+    sd = OrderedDict()
+    for key, shape, kind, fan_in in parameter_spec(cfg, protein_dim, ligand_dim):
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 63))
+        if kind == 'offset':
+            t = torch.tensor(GAUSSIAN_OFFSETS, dtype=torch.float32)
+            assert tuple(t.shape) == tuple(shape)
+        elif kind in ('linear', 'bias'):
+            b = gain / (fan_in ** 0.5)
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * b
+        elif kind == 'ln_w':
+            t = 1.0 + 0.2 * torch.randn(shape, generator=g, dtype=torch.float32)
+        elif kind == 'ln_b':
+            t = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+        else:
+            raise ValueError(kind)
+        sd[key] = t
+    return sd

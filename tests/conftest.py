@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='session')
+def state_dict():
+    from oracle import weights
+    return weights.make_state_dict(2021)
+
+
+@pytest.fixture(scope='session')
+def golden_small():
+    return load_golden('forward_small.npz')
+
+
+def small_inputs(g):
+    """torch tensors of the forward_small fixture inputs (already centred)."""
+    return dict(
+        protein_pos=torch.from_numpy(g['protein_pos']),
+        protein_v=torch.from_numpy(g['protein_feat'].astype(np.float32)),
+        batch_protein=torch.from_numpy(g['batch_protein']),
+        ligand_pos=torch.from_numpy(g['ligand_pos']),
+        ligand_v=torch.from_numpy(g['ligand_v']),
+        batch_ligand=torch.from_numpy(g['batch_ligand']),
+    )
+
+
+def pocket_1h36():
+    from targetdiff_amd import workloads
+    g = load_golden('pocket_1h36.npz')
+    return workloads.Pocket(g['pos'], g['feat'].astype(np.int64), '1h36_pocket10'), g['prior_sizes_seed2021']
