@@ -1,0 +1,136 @@
+/*
+ * targetdiff_hip.h -- C ABI of libtargetdiff_hip.so: the MI355X-native (gfx950) implementation of the
+ * TargetDiff denoising hot path.
+ *
+ * The reference (guanjq/targetdiff) is pure Python: it has no FFI / plugin interface, its seams are
+ * Python call signatures.  Each entry point below replaces one of those seams and
+ * cites it.  All pointers named d_* are DEVICE pointers (HIP), caller-owned; outputs are
+ * caller-allocated; `stream` is a hipStream_t passed as void*.  Every function returns TD_OK (0) or a
+ * negative TD_E* code; td_last_error() gives the message for the calling thread.  No exceptions cross
+ * the ABI, no hidden global state besides the per-thread error string; a td_model is immutable after
+ * creation and may be shared by streams/threads, a workspace must not be shared by concurrent calls.
+ *
+ * Packed-graph convention (what compose_context produces, models/common.py:120-137): the batch holds B
+ * graphs stored contiguously; inside a graph the protein atoms come first, then the ligand atoms.
+ * node_ptr[b]..node_ptr[b+1] is graph b's node range.
+ */
+#ifndef TARGETDIFF_HIP_H
+#define TARGETDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_OK 0
+#define TD_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define TD_ENOMEM (-2)      /* workspace too small or allocation failure */
+#define TD_EHIP (-3)        /* HIP runtime error (message in td_last_error) */
+
+#define TD_ABI_VERSION 1
+
+typedef struct td_model td_model;
+
+/* Model hyper-parameters (configs/training.yml:9-42, read from the checkpoint's config at
+ * scripts/sample_diffusion.py:158-162).  The HIP kernels are specialised for the live configuration
+ * (hidden 128, 16 heads, k = 32, 20 Gaussians, 4 edge types, uni_o2, knn graph, global edge gate);
+ * td_model_create returns TD_EINVAL for anything else. */
+typedef struct td_config {
+    int32_t hidden_dim;          /* 128 */
+    int32_t n_heads;             /* 16 */
+    int32_t knn;                 /* 32 */
+    int32_t num_layers;          /* 9 (any >= 1) */
+    int32_t num_r_gaussian;      /* 20 */
+    int32_t edge_feat_dim;       /* 4 */
+    int32_t protein_feat_dim;    /* 27 (<= 32) */
+    int32_t ligand_num_classes;  /* 13 (<= 16) */
+    int32_t num_timesteps;       /* 1000 */
+    int32_t reserved[7];
+} td_config;
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int td_abi_version(void);
+const char *td_last_error(void);
+
+/* ---- model (replaces: ScorePosNet3D.__init__ + load_state_dict, models/molopt_score_model.py:194-311,
+ *      scripts/sample_diffusion.py:158-163).  `host_weights` is the flat fp32 blob of the reference
+ *      state_dict tensors in the order documented in targetdiff_amd/capi.py::flatten_state_dict
+ *      (row-major [out, in] exactly as PyTorch stores them); the library re-packs them for its kernels
+ *      (node-side projection split of the 340-wide first Linear, MFMA fragment order) and uploads them.
+ *      `host_schedules` = 7 arrays of num_timesteps fp32 each, in this order: posterior_mean_c0_coef,
+ *      posterior_mean_ct_coef, posterior_logvar, log_alphas_v, log_one_minus_alphas_v,
+ *      log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (models/molopt_score_model.py:248-267). */
+int td_model_create(const td_config *cfg, const float *host_weights, size_t num_weights,
+                    const float *host_schedules, size_t num_schedule_floats, td_model **out);
+void td_model_destroy(td_model *m);
+size_t td_model_num_weights(const td_config *cfg);      /* expected length of the flat blob */
+
+/* ---- workspace ---------------------------------------------------------------------------------- */
+/* Bytes of scratch td_refine_forward / td_model_forward need for a batch of N nodes (N_l of them ligand)
+ * in B graphs. */
+size_t td_workspace_bytes(const td_model *m, int64_t N, int64_t B, int64_t N_l);
+
+/* ---- graph bookkeeping ---------------------------------------------------------------------------
+ * batch [N] int64, sorted ascending (torch_geometric `batch` vector) -> ptr [B+1] int32. */
+int td_graph_ptr(const int64_t *d_batch, int64_t N, int64_t B, int32_t *d_ptr, void *stream);
+
+/* ---- kNN graph (replaces: torch_geometric.nn.knn_graph(x, k, batch, flow='source_to_target') at
+ *      models/uni_transformer.py:280).  out_nbr [N, k] int32: row i = the k nearest same-graph nodes of
+ *      node i, ascending by (d2, index), d2 = (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction;
+ *      -1 padded when the graph has fewer than k+1 nodes.  `max_graph_nodes` is a performance hint
+ *      (0 = unknown). */
+int td_knn(const float *d_x /*[N,3]*/, const int32_t *d_node_ptr /*[B+1]*/, int64_t N, int64_t B, int32_t k,
+           int32_t max_graph_nodes, int32_t *d_out_nbr, void *stream);
+
+/* ---- backbone (replaces: refine_net(h, x, mask_ligand, batch, return_all=False, fix_x) ->
+ *      {'x','h'}, UniTransformerO2TwoUpdateGeneral.forward, models/uni_transformer.py:301-328).
+ *      d_h [N,128] f32, d_x [N,3] f32, d_mask_ligand [N] uint8, d_node_ptr [B+1] int32.
+ *      d_out_nbr ([N,k] int32) and d_out_ew ([N,k] f32, the global edge gate of :312-316) may be NULL. */
+int td_refine_forward(const td_model *m, const float *d_h, const float *d_x, const uint8_t *d_mask_ligand,
+                      const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t fix_x, int32_t max_graph_nodes,
+                      float *d_out_h, float *d_out_x, int32_t *d_out_nbr, float *d_out_ew,
+                      void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- one denoiser evaluation (replaces: ScorePosNet3D.forward, models/molopt_score_model.py:313-368,
+ *      time_emb_dim == 0).  Protein / ligand atoms are given un-composed, each sorted by graph:
+ *      d_protein_ptr / d_ligand_ptr are [B+1] int32 prefix offsets.  Outputs: pred_ligand_pos [N_l,3],
+ *      pred_ligand_v [N_l,C], final_ligand_h [N_l,128]; d_final_h [N,128] may be NULL. */
+int td_model_forward(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
+                     const int32_t *d_protein_ptr, int64_t N_p, const float *d_ligand_pos,
+                     const int64_t *d_ligand_v, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                     int32_t fix_x, int32_t max_graph_nodes, float *d_pred_ligand_pos, float *d_pred_ligand_v,
+                     float *d_final_ligand_h, float *d_final_h, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+
+/* ---- posterior update of one reverse-diffusion step (replaces the loop body
+ *      models/molopt_score_model.py:673-685: q_pos_posterior :424, extract :706, q_v_posterior :401,
+ *      q_v_pred :383, q_v_pred_one_timestep :371, log_add_exp :173, index_to_log_onehot :124,
+ *      log_sample_categorical :160).  d_t [B] int32 per-graph timestep; d_noise [N_l,3] ~ N(0,1) and
+ *      d_uniform [N_l,C] ~ U[0,1) are supplied by the caller (torch.randn_like / rand_like in the
+ *      reference).  d_log_v0 / d_log_post ([N_l,C]) may be NULL. */
+int td_posterior_step(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l,
+                      int64_t B, const float *d_ligand_pos, const int64_t *d_ligand_v,
+                      const float *d_pred_pos, const float *d_pred_v, const float *d_noise,
+                      const float *d_uniform, float *d_pos_next, int64_t *d_v_next, float *d_log_v0,
+                      float *d_log_post, void *stream);
+
+/* ---- centring (replaces: center_pos(mode='protein'), models/molopt_score_model.py:110-120).
+ *      offset [B,3] = per-graph protein centroid; positions are shifted in place by -offset (sign = -1)
+ *      or +offset (sign = +1, models/molopt_score_model.py:691,695).  d_protein_pos may be NULL to
+ *      shift only the ligand with an offset computed earlier (compute_offset = 0). */
+int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_ligand_pos,
+                  const int32_t *d_ligand_ptr, int64_t B, float *d_offset, int32_t compute_offset,
+                  int32_t sign, void *stream);
+
+/* ---- test hook (not a reference seam): node-side GEMMs of one attention stage of layer `layer`
+ *      (stage 0 = x2h: hk/hv/hq, stage 1 = h2x: xk/xv/xq).  d_P [N,512] = [k_i | k_j | v_i | v_j] node
+ *      projections of the 340-wide first Linear (h_i part incl. bias), d_q [N,128] = MLP_q(h). */
+int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N, float *d_P,
+                        float *d_q, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TARGETDIFF_HIP_H */

@@ -1,0 +1,74 @@
+"""Build libtargetdiff_hip.so (gfx950) in-tree with hipcc.  No torch dependency in the library.
+
+    python -m targetdiff_amd.build          # incremental
+    python -m targetdiff_amd.build --force
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(HERE, 'build')
+LIB = os.path.join(LIBDIR, 'libtargetdiff_hip.so')
+SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'edge.hip', 'misc.hip']
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function',
+         '-ffp-contract=off']   # fp contraction off: kNN distances and LayerNorm follow the stated association
+
+
+def hipcc() -> str:
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found (need ROCm >= 7.0)')
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(os.path.dirname(HERE), 'include', 'targetdiff_hip.h'))
+    objs, procs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [hipcc()] + FLAGS + ['-c', sp, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            failed = True
+            print(f'[build] {src} FAILED', file=sys.stderr)
+            if not verbose:
+                print(out, file=sys.stderr)
+    if failed:
+        raise RuntimeError('hipcc compilation failed')
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,251 @@
+"""ctypes binding of libtargetdiff_hip.so (C ABI: include/targetdiff_hip.h).
+
+This is the binding a maintainer of the reference would add: torch tensors own all
+device memory, the library only sees raw device pointers + sizes + the HIP stream of the current torch
+stream.  There is no CPU fallback anywhere in this package: if the library is missing or a tensor is
+not on a HIP device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtargetdiff_hip.so')
+
+TD_OK = 0
+HIDDEN = 128
+KNN = 32
+
+
+class TdConfig(ctypes.Structure):
+    _fields_ = [('hidden_dim', c_int32), ('n_heads', c_int32), ('knn', c_int32), ('num_layers', c_int32),
+                ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
+                ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('reserved', c_int32 * 7)]
+
+
+# every symbol include/targetdiff_hip.h declares: (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    'td_abi_version': (c_int32, []),
+    'td_last_error': (c_char_p, []),
+    'td_model_create': (c_int32, [POINTER(TdConfig), POINTER(c_float), c_size_t, POINTER(c_float), c_size_t,
+                                  POINTER(c_void_p)]),
+    'td_model_destroy': (None, [_P]),
+    'td_model_num_weights': (c_size_t, [POINTER(TdConfig)]),
+    'td_workspace_bytes': (c_size_t, [_P, c_int64, c_int64, c_int64]),
+    'td_graph_ptr': (c_int32, [_P, c_int64, c_int64, _P, _P]),
+    'td_knn': (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P]),
+    'td_refine_forward': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P,
+                                    c_size_t, _P]),
+    'td_model_forward': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P,
+                                   _P, _P, _P, c_size_t, _P]),
+    'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
+    'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f'{path} not found: build it with `python -m targetdiff_amd.build` '
+                           '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != TD_OK:
+        msg = load_library().td_last_error()
+        raise RuntimeError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def _ptr(t: torch.Tensor | None, dtype=None, what='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f'{what} must live on a HIP device (got {t.device}); targetdiff_amd has no CPU path')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'{what} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{what} must be contiguous')
+    return c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------- weight blob
+MLP_KEYS = ('net.0.weight', 'net.0.bias', 'net.1.weight', 'net.1.bias', 'net.3.weight', 'net.3.bias')
+
+
+def flat_key_order(num_layers: int):
+    """Order of the reference state_dict tensors inside the flat blob td_model_create consumes
+    (key names: SURVEY.md Appendix C; init_h_emb_layer and the schedule constants are not part of it)."""
+    keys = ['protein_atom_emb.weight', 'protein_atom_emb.bias', 'ligand_atom_emb.weight', 'ligand_atom_emb.bias',
+            'refine_net.distance_expansion.offset']
+    keys += [f'refine_net.edge_pred_layer.{k}' for k in MLP_KEYS]
+    for l in range(num_layers):
+        p = f'refine_net.base_block.{l}'
+        keys.append(f'{p}.distance_expansion.offset')
+        for f in ('x2h_layers.0.hk_func', 'x2h_layers.0.hv_func', 'x2h_layers.0.hq_func',
+                  'h2x_layers.0.xk_func', 'h2x_layers.0.xv_func', 'h2x_layers.0.xq_func'):
+            keys += [f'{p}.{f}.{k}' for k in MLP_KEYS]
+    keys += ['v_inference.0.weight', 'v_inference.0.bias', 'v_inference.2.weight', 'v_inference.2.bias']
+    return keys
+
+
+def flatten_state_dict(sd, num_layers: int) -> np.ndarray:
+    parts = [sd[k].detach().to('cpu', torch.float32).contiguous().reshape(-1).numpy() for k in flat_key_order(num_layers)]
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
+
+
+SCHEDULE_ORDER = ('posterior_mean_c0_coef', 'posterior_mean_ct_coef', 'posterior_logvar', 'log_alphas_v',
+                  'log_one_minus_alphas_v', 'log_alphas_cumprod_v', 'log_one_minus_alphas_cumprod_v')
+
+
+class NativeModel:
+    """Owns a td_model handle (packed weights on the current HIP device) and a growable workspace."""
+
+    def __init__(self, cfg: dict, state_dict, schedules: dict | None = None, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError('no HIP device visible: targetdiff_amd needs an MI355X (gfx950); there is no CPU path')
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.cfg = TdConfig(hidden_dim=cfg['hidden_dim'], n_heads=cfg['n_heads'], knn=cfg['knn'],
+                            num_layers=cfg['num_layers'], num_r_gaussian=cfg['num_r_gaussian'],
+                            edge_feat_dim=cfg['edge_feat_dim'], protein_feat_dim=cfg['protein_feat_dim'],
+                            ligand_num_classes=cfg['ligand_num_classes'], num_timesteps=cfg['num_timesteps'])
+        self.num_classes = int(cfg['ligand_num_classes'])
+        blob = flatten_state_dict(state_dict, cfg['num_layers'])
+        expect = self.lib.td_model_num_weights(ctypes.byref(self.cfg))
+        if blob.size != expect:
+            raise ValueError(f'weight blob has {blob.size} floats, library expects {expect}')
+        sched_ptr, sched_n = None, 0
+        if schedules is not None:
+            sch = np.ascontiguousarray(np.concatenate(
+                [np.asarray(schedules[k], dtype=np.float32).reshape(-1) for k in SCHEDULE_ORDER]))
+            sched_ptr, sched_n = sch.ctypes.data_as(POINTER(c_float)), sch.size
+        handle = c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.td_model_create(ctypes.byref(self.cfg), blob.ctypes.data_as(POINTER(c_float)), blob.size,
+                                            sched_ptr, sched_n, ctypes.byref(handle)), 'td_model_create')
+        self.handle = handle
+        self._ws = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and getattr(self, 'lib', None) is not None:
+            self.lib.td_model_destroy(h)
+
+    # ------------------------------------------------------------------------------------------
+    def workspace(self, N: int, B: int, Nl: int) -> torch.Tensor:
+        need = int(self.lib.td_workspace_bytes(self.handle, N, B, Nl))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def graph_ptr(self, batch: torch.Tensor, B: int) -> torch.Tensor:
+        ptr = torch.empty(B + 1, dtype=torch.int32, device=batch.device)
+        _check(self.lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream()),
+               'td_graph_ptr')
+        return ptr
+
+    def knn(self, x: torch.Tensor, node_ptr: torch.Tensor, k: int = KNN, max_graph_nodes: int = 0) -> torch.Tensor:
+        N = x.shape[0]
+        out = torch.empty(N, k, dtype=torch.int32, device=x.device)
+        _check(self.lib.td_knn(_ptr(x, torch.float32, 'x'), _ptr(node_ptr, torch.int32, 'node_ptr'), N,
+                               node_ptr.numel() - 1, k, max_graph_nodes, _ptr(out), _stream()), 'td_knn')
+        return out
+
+    def refine_forward(self, h, x, mask_ligand, node_ptr, fix_x=False, max_graph_nodes=0, want_graph=False):
+        N, B = h.shape[0], node_ptr.numel() - 1
+        out_h = torch.empty_like(h)
+        out_x = torch.empty_like(x)
+        nbr = torch.empty(N, KNN, dtype=torch.int32, device=h.device) if want_graph else None
+        ew = torch.empty(N, KNN, dtype=torch.float32, device=h.device) if want_graph else None
+        ws = self.workspace(N, B, 0)
+        mask_u8 = mask_ligand.to(torch.uint8).contiguous()
+        _check(self.lib.td_refine_forward(
+            self.handle, _ptr(h, torch.float32, 'h'), _ptr(x, torch.float32, 'x'), _ptr(mask_u8),
+            _ptr(node_ptr, torch.int32, 'node_ptr'), N, B, int(bool(fix_x)), max_graph_nodes, _ptr(out_h), _ptr(out_x),
+            _ptr(nbr), _ptr(ew), _ptr(ws), ws.numel(), _stream()), 'td_refine_forward')
+        return out_h, out_x, nbr, ew
+
+    def model_forward(self, protein_pos, protein_v, protein_ptr, ligand_pos, ligand_v, ligand_ptr, fix_x=False,
+                      max_graph_nodes=0, want_final_h=True, out=None):
+        Np, Nl, B = protein_pos.shape[0], ligand_pos.shape[0], protein_ptr.numel() - 1
+        N, C = Np + Nl, self.num_classes
+        dev = protein_pos.device
+        if out is None:
+            out = {}
+        pred_pos = out.get('pred_ligand_pos')
+        if pred_pos is None:
+            pred_pos = torch.empty(Nl, 3, dtype=torch.float32, device=dev)
+        pred_v = out.get('pred_ligand_v')
+        if pred_v is None:
+            pred_v = torch.empty(Nl, C, dtype=torch.float32, device=dev)
+        lig_h = out.get('final_ligand_h')
+        if lig_h is None:
+            lig_h = torch.empty(Nl, HIDDEN, dtype=torch.float32, device=dev)
+        final_h = torch.empty(N, HIDDEN, dtype=torch.float32, device=dev) if want_final_h else None
+        ws = self.workspace(N, B, Nl)
+        _check(self.lib.td_model_forward(
+            self.handle, _ptr(protein_pos, torch.float32, 'protein_pos'), _ptr(protein_v, torch.float32, 'protein_v'),
+            _ptr(protein_ptr, torch.int32, 'protein_ptr'), Np, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
+            _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
+            int(bool(fix_x)), max_graph_nodes, _ptr(pred_pos), _ptr(pred_v), _ptr(lig_h), _ptr(final_h), _ptr(ws),
+            ws.numel(), _stream()), 'td_model_forward')
+        return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': final_h, 'final_ligand_h': lig_h}
+
+    def posterior_step(self, t, ligand_ptr, ligand_pos, ligand_v, pred_pos, pred_v, noise, uniform,
+                       pos_next=None, v_next=None, log_v0=None, log_post=None):
+        Nl, B = ligand_pos.shape[0], ligand_ptr.numel() - 1
+        if pos_next is None:
+            pos_next = torch.empty_like(ligand_pos)
+        if v_next is None:
+            v_next = torch.empty_like(ligand_v)
+        _check(self.lib.td_posterior_step(
+            self.handle, _ptr(t, torch.int32, 't'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
+            _ptr(ligand_pos, torch.float32, 'ligand_pos'), _ptr(ligand_v, torch.int64, 'ligand_v'),
+            _ptr(pred_pos, torch.float32, 'pred_pos'), _ptr(pred_v, torch.float32, 'pred_v'),
+            _ptr(noise, torch.float32, 'noise'), _ptr(uniform, torch.float32, 'uniform'), _ptr(pos_next),
+            _ptr(v_next, torch.int64, 'v_next'), _ptr(log_v0), _ptr(log_post), _stream()), 'td_posterior_step')
+        return pos_next, v_next
+
+    def center_pos(self, protein_pos, protein_ptr, ligand_pos, ligand_ptr, offset=None, sign=-1):
+        """In place.  offset=None: compute the protein centroids and subtract them (sign=-1)."""
+        B = protein_ptr.numel() - 1
+        compute = offset is None
+        if compute:
+            offset = torch.empty(B, 3, dtype=torch.float32, device=ligand_pos.device)
+        _check(self.lib.td_center_pos(_ptr(protein_pos) if protein_pos is not None else None,
+                                      _ptr(protein_ptr, torch.int32, 'protein_ptr'), _ptr(ligand_pos),
+                                      _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), B, _ptr(offset), int(compute), sign,
+                                      _stream()), 'td_center_pos')
+        return offset
+
+    def debug_node_stage(self, layer: int, stage: int, h: torch.Tensor):
+        """Test hook: node projections P [N,512] and query vectors q [N,128] of one attention stage."""
+        N = h.shape[0]
+        P = torch.empty(N, 4 * HIDDEN, dtype=torch.float32, device=h.device)
+        q = torch.empty(N, HIDDEN, dtype=torch.float32, device=h.device)
+        _check(self.lib.td_debug_node_stage(self.handle, layer, stage, _ptr(h, torch.float32, 'h'), N, _ptr(P), _ptr(q),
+                                            _stream()), 'td_debug_node_stage')
+        return P, q

@@ -1,0 +1,483 @@
+// C ABI of libtargetdiff_hip.so: weight re-packing, workspace carving and the per-step launch sequence.
+// See include/targetdiff_hip.h for the contract of every entry point and the reference seam it replaces.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "td_device.h"
+#include "td_internal.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void td_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *td_last_error(void) { return g_err; }
+extern "C" int td_abi_version(void) { return TD_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------ blob layout
+namespace {
+
+struct MlpSrc {          // one reference MLP (models/common.py:60-80) inside the flat blob
+    const float *w0, *b0, *g, *b, *w3, *b3;
+};
+
+struct Cursor {
+    const float *p;
+    size_t left;
+    bool ok = true;
+    const float *take(size_t n) {
+        if (n > left) { ok = false; return p; }
+        const float *r = p;
+        p += n; left -= n;
+        return r;
+    }
+    MlpSrc mlp(int in, int hid, int out) {
+        MlpSrc m;
+        m.w0 = take((size_t)hid * in); m.b0 = take(hid); m.g = take(hid); m.b = take(hid);
+        m.w3 = take((size_t)out * hid); m.b3 = take(out);
+        return m;
+    }
+};
+
+size_t mlp_floats(int in, int hid, int out) { return (size_t)hid * in + 3 * (size_t)hid + (size_t)out * hid + out; }
+
+int kv_in(const td_config &c) { return 2 * c.hidden_dim + c.edge_feat_dim + 4 * c.num_r_gaussian; }
+
+bool config_supported(const td_config &c) {
+    return c.hidden_dim == TD_H && c.n_heads == TD_HEADS && c.knn == TD_K && c.num_r_gaussian == TD_NG &&
+           c.edge_feat_dim == 4 && c.num_layers >= 1 && c.protein_feat_dim >= 1 && c.protein_feat_dim <= 32 &&
+           c.ligand_num_classes >= 1 && c.ligand_num_classes <= TD_MAXC && c.num_timesteps >= 1;
+}
+
+// Packed-buffer builder: collects tensors into one host vector; pointers are fixed up after the upload.
+struct Packer {
+    std::vector<float> data;
+    size_t alloc(size_t n) {
+        size_t off = (data.size() + 63) & ~size_t(63);          // 256-byte alignment
+        data.resize(off + n, 0.f);
+        return off;
+    }
+};
+
+// B fragments of a 128-deep GEMM with all 4 N tiles per lane: dst[(s*64 + lane)*4 + t] = W[32t + c][col0 + kmap(s, hi)]
+size_t pack_B128(Packer &pk, const float *W, int ld, int col0) {
+    size_t off = pk.alloc((size_t)TD_KSTEPS * 64 * 4);
+    float *d = pk.data.data() + off;
+    for (int s = 0; s < TD_KSTEPS; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 4; ++t)
+                d[((size_t)s * 64 + lane) * 4 + t] = W[(size_t)(32 * t + (lane & 31)) * ld + col0 + td_kmap(s, lane >> 5)];
+    return off;
+}
+
+size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
+    size_t off = pk.alloc(padded ? padded : n);
+    if (v) memcpy(pk.data.data() + off, v, n * sizeof(float));
+    return off;
+}
+
+struct EdgeOff { size_t R, gamma, beta, W2, b2; };
+
+EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim) {
+    EdgeOff o;
+    // first layer radial / type table: [cls][wave][slot][kstep][lane]
+    o.R = pk.alloc((size_t)2 * 4 * 2 * TD_SLOT_STEPS * 64);
+    float *d = pk.data.data() + o.R;
+    for (int cls = 0; cls < 2; ++cls)
+        for (int w = 0; w < 4; ++w)
+            for (int sl = 0; sl < 2; ++sl) {
+                // edge type (models/uni_transformer.py:292-297): 0 l<-l, 1 src lig/dst prot, 2 src prot/dst lig, 3 p<-p
+                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+                for (int s = 0; s < TD_SLOT_STEPS; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int kk = td_kmap(s, lane >> 5), n = 32 * w + (lane & 31);
+                        float v = 0.f;
+                        if (kk < TD_NG) v = m.w0[(size_t)n * in_dim + 4 + TD_NG * type + kk];   // r_feat, type-major
+                        else if (kk == TD_NG) v = m.w0[(size_t)n * in_dim + type];              // one-hot edge type column
+                        d[((((size_t)cls * 4 + w) * 2 + sl) * TD_SLOT_STEPS + s) * 64 + lane] = v;
+                    }
+            }
+    o.gamma = pack_vec(pk, m.g, TD_H);
+    o.beta = pack_vec(pk, m.b, TD_H);
+    if (out_dim == TD_H) {
+        o.W2 = pk.alloc((size_t)4 * TD_KSTEPS * 64);
+        float *q = pk.data.data() + o.W2;
+        for (int w = 0; w < 4; ++w)
+            for (int s = 0; s < TD_KSTEPS; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    q[((size_t)w * TD_KSTEPS + s) * 64 + lane] =
+                        m.w3[(size_t)(32 * w + (lane & 31)) * TD_H + td_kmap(s, lane >> 5)];
+        o.b2 = pack_vec(pk, m.b3, TD_H);
+    } else {   // xv: [16][128] -> K-split over 4 waves, N padded 16 -> 32
+        o.W2 = pk.alloc((size_t)4 * 16 * 64);
+        float *q = pk.data.data() + o.W2;
+        for (int w = 0; w < 4; ++w)
+            for (int s = 0; s < 16; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int cc = lane & 31;
+                    q[((size_t)w * 16 + s) * 64 + lane] =
+                        cc < out_dim ? m.w3[(size_t)cc * TD_H + td_kmap(16 * w + s, lane >> 5)] : 0.f;
+                }
+        o.b2 = pack_vec(pk, m.b3, out_dim, TD_HEADS);
+    }
+    return o;
+}
+
+struct NodeOff { size_t projB, projBias, qGamma, qBeta, q3B, q3Bias; };
+
+NodeOff pack_node_stage(Packer &pk, const MlpSrc &k, const MlpSrc &v, const MlpSrc &q, int in_dim) {
+    NodeOff o;
+    const int hi_col = in_dim - 2 * TD_H, hj_col = in_dim - TD_H;       // [.. | h_i | h_j]
+    o.projB = pack_B128(pk, k.w0, in_dim, hi_col);
+    pack_B128(pk, k.w0, in_dim, hj_col);                                // consecutive 64-float-aligned blocks
+    pack_B128(pk, v.w0, in_dim, hi_col);
+    pack_B128(pk, v.w0, in_dim, hj_col);
+    pack_B128(pk, q.w0, TD_H, 0);
+    o.projBias = pk.alloc(5 * TD_H);
+    memcpy(pk.data.data() + o.projBias + 0 * TD_H, k.b0, TD_H * sizeof(float));
+    memcpy(pk.data.data() + o.projBias + 2 * TD_H, v.b0, TD_H * sizeof(float));
+    memcpy(pk.data.data() + o.projBias + 4 * TD_H, q.b0, TD_H * sizeof(float));
+    o.qGamma = pack_vec(pk, q.g, TD_H);
+    o.qBeta = pack_vec(pk, q.b, TD_H);
+    o.q3B = pack_B128(pk, q.w3, TD_H, 0);
+    o.q3Bias = pack_vec(pk, q.b3, TD_H);
+    return o;
+}
+
+float gaussian_coeff(const float *off) {                // models/common.py:18
+    const float d = off[1] - off[0];
+    return -0.5f / (d * d);
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" size_t td_model_num_weights(const td_config *cfg) {
+    if (!cfg) return 0;
+    const td_config &c = *cfg;
+    const int H = c.hidden_dim, E = H - 1, KV = kv_in(c);
+    size_t n = (size_t)E * c.protein_feat_dim + E + (size_t)E * c.ligand_num_classes + E;
+    n += c.num_r_gaussian + mlp_floats(c.num_r_gaussian, H, 1);
+    n += (size_t)c.num_layers * (c.num_r_gaussian + 2 * mlp_floats(KV, H, H) + 2 * mlp_floats(H, H, H) +
+                                 mlp_floats(KV, H, H) + mlp_floats(KV, H, c.n_heads));
+    n += (size_t)H * H + H + (size_t)c.ligand_num_classes * H + c.ligand_num_classes;
+    return n;
+}
+
+extern "C" int td_model_create(const td_config *cfg, const float *host_weights, size_t num_weights,
+                               const float *host_schedules, size_t num_schedule_floats, td_model **out) {
+    if (!cfg || !host_weights || !out) { td_set_error("td_model_create: null argument"); return TD_EINVAL; }
+    const td_config &c = *cfg;
+    if (!config_supported(c)) {
+        td_set_error("td_model_create: unsupported configuration (need hidden 128, 16 heads, knn 32, 20 gaussians, "
+                     "edge_feat_dim 4; got %d/%d/%d/%d/%d)", c.hidden_dim, c.n_heads, c.knn, c.num_r_gaussian,
+                     c.edge_feat_dim);
+        return TD_EINVAL;
+    }
+    if (num_weights != td_model_num_weights(cfg)) {
+        td_set_error("td_model_create: weight blob has %zu floats, expected %zu", num_weights, td_model_num_weights(cfg));
+        return TD_EINVAL;
+    }
+    if (host_schedules && num_schedule_floats != (size_t)7 * c.num_timesteps) {
+        td_set_error("td_model_create: schedule blob has %zu floats, expected %zu", num_schedule_floats,
+                     (size_t)7 * c.num_timesteps);
+        return TD_EINVAL;
+    }
+    const int H = TD_H, E = H - 1, F = c.protein_feat_dim, C = c.ligand_num_classes, KV = kv_in(c), L = c.num_layers;
+    Cursor cur{host_weights, num_weights};
+    const float *Wp = cur.take((size_t)E * F), *bp = cur.take(E);
+    const float *Wl = cur.take((size_t)E * C), *bl = cur.take(E);
+    const float *goff = cur.take(TD_NG);
+    MlpSrc gate = cur.mlp(TD_NG, H, 1);
+
+    Packer pk;
+    // ---- embeddings (+ node indicator column, models/molopt_score_model.py:336-338)
+    size_t oWpT = pk.alloc((size_t)F * H), obp = pk.alloc(H), oWlT = pk.alloc((size_t)C * H), obl = pk.alloc(H);
+    for (int cc = 0; cc < F; ++cc)
+        for (int n = 0; n < E; ++n) pk.data[oWpT + (size_t)cc * H + n] = Wp[(size_t)n * F + cc];
+    for (int cc = 0; cc < C; ++cc)
+        for (int n = 0; n < E; ++n) pk.data[oWlT + (size_t)cc * H + n] = Wl[(size_t)n * C + cc];
+    for (int n = 0; n < E; ++n) { pk.data[obp + n] = bp[n]; pk.data[obl + n] = bl[n]; }
+    pk.data[obp + E] = 0.f;
+    pk.data[obl + E] = 1.f;
+    // ---- gate
+    size_t oGR = pk.alloc((size_t)TD_SLOT_STEPS * 64 * 4);
+    for (int s = 0; s < TD_SLOT_STEPS; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 4; ++t) {
+                const int kk = td_kmap(s, lane >> 5), n = 32 * t + (lane & 31);
+                pk.data[oGR + ((size_t)s * 64 + lane) * 4 + t] = kk < TD_NG ? gate.w0[(size_t)n * TD_NG + kk] : 0.f;
+            }
+    size_t oGb0 = pack_vec(pk, gate.b0, H), oGg = pack_vec(pk, gate.g, H), oGb = pack_vec(pk, gate.b, H),
+           oGw3 = pack_vec(pk, gate.w3, H), oGoff = pack_vec(pk, goff, TD_NG);
+    const float gate_b3 = gate.b3[0], gate_coeff = gaussian_coeff(goff);
+    // ---- layers
+    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; };
+    std::vector<LayerOff> lo(L);
+    for (int l = 0; l < L; ++l) {
+        const float *off = cur.take(TD_NG);
+        MlpSrc hk = cur.mlp(KV, H, H), hv = cur.mlp(KV, H, H), hq = cur.mlp(H, H, H);
+        MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
+        if (!cur.ok) break;
+        lo[l].off = pack_vec(pk, off, TD_NG);
+        lo[l].coeff = gaussian_coeff(off);
+        lo[l].nx = pack_node_stage(pk, hk, hv, hq, KV);
+        lo[l].nh = pack_node_stage(pk, xk, xv, xq, KV);
+        lo[l].hk = pack_edge_mlp(pk, hk, KV, H);
+        lo[l].hv = pack_edge_mlp(pk, hv, KV, H);
+        lo[l].xk = pack_edge_mlp(pk, xk, KV, H);
+        lo[l].xv = pack_edge_mlp(pk, xv, KV, c.n_heads);
+    }
+    // ---- head
+    const float *V0 = cur.take((size_t)H * H), *vb0 = cur.take(H), *V2 = cur.take((size_t)C * H), *vb2 = cur.take(C);
+    if (!cur.ok || cur.left != 0) { td_set_error("td_model_create: weight blob layout mismatch"); return TD_EINVAL; }
+    size_t oW0T = pk.alloc((size_t)H * H), ohb0 = pack_vec(pk, vb0, H), oW2T = pk.alloc((size_t)H * TD_MAXC),
+           ohb2 = pack_vec(pk, vb2, C, TD_MAXC);
+    for (int k = 0; k < H; ++k) {
+        for (int n = 0; n < H; ++n) pk.data[oW0T + (size_t)k * H + n] = V0[(size_t)n * H + k];
+        for (int cc = 0; cc < C; ++cc) pk.data[oW2T + (size_t)k * TD_MAXC + cc] = V2[(size_t)cc * H + k];
+    }
+    // ---- schedules
+    const int T = c.num_timesteps;
+    size_t oS = pk.alloc((size_t)7 * T);
+    if (host_schedules) memcpy(pk.data.data() + oS, host_schedules, (size_t)7 * T * sizeof(float));
+
+    td_model *m = new (std::nothrow) td_model();
+    if (!m) { td_set_error("td_model_create: out of host memory"); return TD_ENOMEM; }
+    m->cfg = c;
+    m->blob_floats = pk.data.size();
+    m->layers = new (std::nothrow) TdLayer[L];
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->blob), m->blob_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->blob, pk.data.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess || !m->layers) {
+        td_set_error("td_model_create: device upload failed: %s", hipGetErrorString(e));
+        if (m->blob) (void)hipFree(m->blob);
+        delete[] m->layers;
+        delete m;
+        return e != hipSuccess ? TD_EHIP : TD_ENOMEM;
+    }
+    const float *D = m->blob;
+    m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
+    m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
+    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2}; };
+    auto node = [&](const NodeOff &o) {
+        return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias};
+    };
+    for (int l = 0; l < L; ++l) {
+        TdLayer &Ly = m->layers[l];
+        Ly.nodeX2h = node(lo[l].nx); Ly.nodeH2x = node(lo[l].nh);
+        Ly.hk = edge(lo[l].hk); Ly.hv = edge(lo[l].hv); Ly.xk = edge(lo[l].xk); Ly.xv = edge(lo[l].xv);
+        Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
+    }
+    m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
+    const float *S = D + oS;
+    m->sched = TdSchedules{S, S + T, S + 2 * T, S + 3 * T, S + 4 * T, S + 5 * T, S + 6 * T};
+    *out = m;
+    return TD_OK;
+}
+
+extern "C" void td_model_destroy(td_model *m) {
+    if (!m) return;
+    if (m->blob) (void)hipFree(m->blob);
+    delete[] m->layers;
+    delete m;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+namespace {
+struct Workspace {
+    float4 *x4a, *x4b;
+    int32_t *gid, *nbr, *lig_node, *node_ptr;
+    float *ew, *P, *q, *h;
+    size_t bytes;
+};
+
+Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t n) { char *p = base ? base + off : nullptr; off += align_up(n); return p; };
+    const size_t n = (size_t)(N > 0 ? N : 1), nl = (size_t)(Nl > 0 ? Nl : n);
+    w.x4a = reinterpret_cast<float4 *>(take(n * sizeof(float4)));
+    w.x4b = reinterpret_cast<float4 *>(take(n * sizeof(float4)));
+    w.gid = reinterpret_cast<int32_t *>(take(n * sizeof(int32_t)));
+    w.nbr = reinterpret_cast<int32_t *>(take(n * TD_K * sizeof(int32_t)));
+    w.lig_node = reinterpret_cast<int32_t *>(take((nl + 1) * sizeof(int32_t)));
+    w.node_ptr = reinterpret_cast<int32_t *>(take((size_t)(B + 1) * sizeof(int32_t)));
+    w.ew = reinterpret_cast<float *>(take(n * TD_K * sizeof(float)));
+    w.P = reinterpret_cast<float *>(take(n * 4 * TD_H * sizeof(float)));
+    w.q = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
+    w.h = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
+    w.bytes = off;
+    return w;
+}
+
+// kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
+// the buffer holding the final coordinates through *x_final.
+int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
+                 float4 **x_final, hipStream_t s) {
+    int rc;
+    if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
+    if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, w.ew, s)) != TD_OK) return rc;
+    float4 *xc = w.x4a, *xn = w.x4b;
+    if (!fix_x && Nl > 0) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < m->cfg.num_layers; ++l) {
+        const TdLayer &L = m->layers[l];
+        if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc;
+        if ((rc = td_launch_x2h(L, xc, w.nbr, w.ew, w.P, w.q, N, h, s)) != TD_OK) return rc;
+        if (!fix_x && Nl > 0) {
+            if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc;
+            if ((rc = td_launch_h2x(L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, s)) != TD_OK) return rc;
+            float4 *t = xc; xc = xn; xn = t;
+        }
+    }
+    *x_final = xc;
+    return TD_OK;
+}
+}  // namespace
+
+extern "C" size_t td_workspace_bytes(const td_model *m, int64_t N, int64_t B, int64_t N_l) {
+    (void)m;
+    return carve(nullptr, N, B, N_l).bytes;
+}
+
+// ------------------------------------------------------------------------------------------ entry points
+extern "C" int td_graph_ptr(const int64_t *d_batch, int64_t N, int64_t B, int32_t *d_ptr, void *stream) {
+    if (!d_ptr || (N > 0 && !d_batch) || N < 0 || B < 0) { td_set_error("td_graph_ptr: bad argument"); return TD_EINVAL; }
+    return td_launch_graph_ptr(d_batch, N, B, d_ptr, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_knn(const float *d_x, const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t k,
+                      int32_t max_graph_nodes, int32_t *d_out_nbr, void *stream) {
+    if (k != TD_K) { td_set_error("td_knn: only k = %d is built (got %d)", TD_K, k); return TD_EINVAL; }
+    if (N < 0 || B < 0 || (N > 0 && (!d_x || !d_node_ptr || !d_out_nbr))) { td_set_error("td_knn: bad argument"); return TD_EINVAL; }
+    if (N == 0) return TD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // scratch: float4 coordinates + graph ids (stream-ordered allocation keeps the call self-contained)
+    float4 *x4 = nullptr;
+    int32_t *gid = nullptr;
+    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&x4), (size_t)N * sizeof(float4), s));
+    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&gid), (size_t)N * sizeof(int32_t), s));
+    TD_CHECK_HIP(hipMemsetAsync(gid, 0, (size_t)N * sizeof(int32_t), s));
+    // the ligand flag (.w) is irrelevant for the search: pack with an all-zero mask (gid is zero-filled scratch)
+    int rc = td_launch_pack_x(d_x, reinterpret_cast<const uint8_t *>(gid), N, x4, s);
+    if (rc == TD_OK) rc = td_launch_node_gid(d_node_ptr, N, B, gid, s);
+    if (rc == TD_OK) rc = td_launch_knn(x4, d_node_ptr, gid, N, max_graph_nodes, d_out_nbr, s);
+    (void)hipFreeAsync(x4, s);
+    (void)hipFreeAsync(gid, s);
+    return rc;
+}
+
+extern "C" int td_refine_forward(const td_model *m, const float *d_h, const float *d_x, const uint8_t *d_mask_ligand,
+                                 const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t fix_x,
+                                 int32_t max_graph_nodes, float *d_out_h, float *d_out_x, int32_t *d_out_nbr,
+                                 float *d_out_ew, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!m || N < 0 || B < 0) { td_set_error("td_refine_forward: bad argument"); return TD_EINVAL; }
+    if (N == 0) return TD_OK;
+    if (!d_h || !d_x || !d_mask_ligand || !d_node_ptr || !d_out_h || !d_out_x || !d_workspace) {
+        td_set_error("td_refine_forward: null pointer");
+        return TD_EINVAL;
+    }
+    Workspace w = carve(static_cast<char *>(d_workspace), N, B, 0);
+    if (w.bytes > workspace_bytes) {
+        td_set_error("td_refine_forward: workspace has %zu bytes, need %zu", workspace_bytes, w.bytes);
+        return TD_ENOMEM;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    TD_CHECK_HIP(hipMemcpyAsync(w.node_ptr, d_node_ptr, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if ((rc = td_launch_node_gid(w.node_ptr, N, B, w.gid, s)) != TD_OK) return rc;
+    if ((rc = td_launch_pack_x(d_x, d_mask_ligand, N, w.x4a, s)) != TD_OK) return rc;
+    // ligand dst list for h2x; its length is needed for the launch shape -> one small D2H (this entry point
+    // mirrors the refine_net seam; the sampler path uses td_model_forward, which knows N_l on the host).
+    int32_t nl = 0;
+    if (!fix_x) {
+        if ((rc = td_launch_ligand_list(d_mask_ligand, N, w.lig_node, w.lig_node + N, s)) != TD_OK) return rc;
+        TD_CHECK_HIP(hipMemcpyAsync(&nl, w.lig_node + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        TD_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    if (d_out_h != d_h) TD_CHECK_HIP(hipMemcpyAsync(d_out_h, d_h, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    float4 *xf = nullptr;
+    if ((rc = run_backbone(m, w, d_out_h, N, nl, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
+    if ((rc = td_launch_unpack_x(xf, N, d_out_x, s)) != TD_OK) return rc;
+    if (d_out_nbr) TD_CHECK_HIP(hipMemcpyAsync(d_out_nbr, w.nbr, (size_t)N * TD_K * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (d_out_ew) TD_CHECK_HIP(hipMemcpyAsync(d_out_ew, w.ew, (size_t)N * TD_K * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return TD_OK;
+}
+
+extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
+                                const int32_t *d_protein_ptr, int64_t N_p, const float *d_ligand_pos,
+                                const int64_t *d_ligand_v, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                                int32_t fix_x, int32_t max_graph_nodes, float *d_pred_ligand_pos,
+                                float *d_pred_ligand_v, float *d_final_ligand_h, float *d_final_h, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    if (!m || N_p < 0 || N_l < 0 || B < 0) { td_set_error("td_model_forward: bad argument"); return TD_EINVAL; }
+    const int64_t N = N_p + N_l;
+    if (N == 0) return TD_OK;
+    if (!d_protein_ptr || !d_ligand_ptr || !d_workspace || (N_p > 0 && (!d_protein_pos || !d_protein_v)) ||
+        (N_l > 0 && (!d_ligand_pos || !d_ligand_v || !d_pred_ligand_pos || !d_pred_ligand_v))) {
+        td_set_error("td_model_forward: null pointer");
+        return TD_EINVAL;
+    }
+    Workspace w = carve(static_cast<char *>(d_workspace), N, B, N_l);
+    if (w.bytes > workspace_bytes) {
+        td_set_error("td_model_forward: workspace has %zu bytes, need %zu", workspace_bytes, w.bytes);
+        return TD_ENOMEM;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    float *h = d_final_h ? d_final_h : w.h;
+    if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
+                                d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, s)) != TD_OK)
+        return rc;
+    float4 *xf = nullptr;
+    if ((rc = run_backbone(m, w, h, N, N_l, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
+    return td_launch_head(m->head, h, xf, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos,
+                          d_pred_ligand_v, d_final_ligand_h, s);
+}
+
+extern "C" int td_posterior_step(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l,
+                                 int64_t B, const float *d_ligand_pos, const int64_t *d_ligand_v,
+                                 const float *d_pred_pos, const float *d_pred_v, const float *d_noise,
+                                 const float *d_uniform, float *d_pos_next, int64_t *d_v_next, float *d_log_v0,
+                                 float *d_log_post, void *stream) {
+    if (!m || N_l < 0 || B < 0) { td_set_error("td_posterior_step: bad argument"); return TD_EINVAL; }
+    if (N_l == 0) return TD_OK;
+    if (!d_t || !d_ligand_ptr || !d_ligand_pos || !d_ligand_v || !d_pred_pos || !d_pred_v || !d_noise || !d_uniform ||
+        !d_pos_next || !d_v_next) {
+        td_set_error("td_posterior_step: null pointer");
+        return TD_EINVAL;
+    }
+    return td_launch_posterior(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, N_l, B, m->cfg.ligand_num_classes,
+                               d_ligand_pos, d_ligand_v, d_pred_pos, d_pred_v, d_noise, d_uniform, d_pos_next,
+                               d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_ligand_pos,
+                             const int32_t *d_ligand_ptr, int64_t B, float *d_offset, int32_t compute_offset,
+                             int32_t sign, void *stream) {
+    if (B < 0 || !d_offset || !d_protein_ptr || !d_ligand_ptr || (compute_offset && !d_protein_pos)) {
+        td_set_error("td_center_pos: bad argument");
+        return TD_EINVAL;
+    }
+    return td_launch_center(d_protein_pos, d_protein_ptr, d_ligand_pos, d_ligand_ptr, B, d_offset, compute_offset,
+                            sign, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N,
+                                   float *d_P, float *d_q, void *stream) {
+    if (!m || layer < 0 || layer >= m->cfg.num_layers || (stage != 0 && stage != 1) || N < 0 || (N > 0 && (!d_h || !d_P || !d_q))) {
+        td_set_error("td_debug_node_stage: bad argument");
+        return TD_EINVAL;
+    }
+    const TdLayer &L = m->layers[layer];
+    return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, d_P, d_q, static_cast<hipStream_t>(stream));
+}

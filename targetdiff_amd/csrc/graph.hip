@@ -1,0 +1,271 @@
+// Graph bookkeeping, context composition and the batched k-nearest-neighbour search (gfx950).
+//
+// Replaces on the reference path:
+//   * compose_context                      models/common.py:120-137
+//   * atom embeddings + node indicator     models/molopt_score_model.py:333-338
+//   * knn_graph(x, k=32, batch)            models/uni_transformer.py:280 (torch_cluster 1.6.0, external)
+#include "td_device.h"
+#include "td_internal.h"
+
+// ------------------------------------------------------------------------------------------ graph_ptr
+__global__ void graph_ptr_kernel(const int64_t *__restrict__ batch, int64_t N, int64_t B, int32_t *__restrict__ ptr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (N == 0) {
+        if (i <= B) ptr[i] = 0;
+        return;
+    }
+    if (i >= N) return;
+    int64_t b = batch[i];
+    int64_t prev = (i == 0) ? -1 : batch[i - 1];
+    for (int64_t g = prev + 1; g <= b && g <= B; ++g) ptr[g] = (int32_t)i;
+    if (i == N - 1)
+        for (int64_t g = b + 1; g <= B; ++g) ptr[g] = (int32_t)N;
+}
+
+int td_launch_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, hipStream_t s) {
+    int64_t n = N > B + 1 ? N : B + 1;
+    graph_ptr_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(batch, N, B, ptr);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+__device__ __forceinline__ int td_find_graph(const int32_t *__restrict__ ptr, int B, int i) {
+    int lo = 0, hi = B;   // invariant: ptr[lo] <= i < ptr[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void node_gid_kernel(const int32_t *__restrict__ ptr, int64_t N, int B, int32_t *__restrict__ gid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) gid[i] = td_find_graph(ptr, B, (int)i);
+}
+
+int td_launch_node_gid(const int32_t *node_ptr, int64_t N, int64_t B, int32_t *gid, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    node_gid_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(node_ptr, N, (int)B, gid);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ x packing
+// Internal coordinate layout: float4 (x, y, z, is_ligand) -- one 16-byte gather per neighbour.
+__global__ void pack_x_kernel(const float *__restrict__ x3, const uint8_t *__restrict__ mask, int64_t N,
+                              float4 *__restrict__ x4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) x4[i] = make_float4(x3[3 * i], x3[3 * i + 1], x3[3 * i + 2], mask[i] ? 1.f : 0.f);
+}
+__global__ void unpack_x_kernel(const float4 *__restrict__ x4, int64_t N, float *__restrict__ x3) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        float4 v = x4[i];
+        x3[3 * i] = v.x; x3[3 * i + 1] = v.y; x3[3 * i + 2] = v.z;
+    }
+}
+int td_launch_pack_x(const float *x3, const uint8_t *mask, int64_t N, float4 *x4, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    pack_x_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(x3, mask, N, x4);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+int td_launch_unpack_x(const float4 *x4, int64_t N, float *x3, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    unpack_x_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(x4, N, x3);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+__global__ void ligand_list_kernel(const uint8_t *__restrict__ mask, int64_t N, int32_t *__restrict__ lig_node,
+                                   int32_t *__restrict__ count) {
+    // single-block ordered compaction (N <= a few million; once per refine call, not per layer)
+    __shared__ int s_base;
+    __shared__ int s_cnt[1024];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t start = 0; start < N; start += blockDim.x) {
+        int64_t i = start + threadIdx.x;
+        int f = (i < N && mask[i]) ? 1 : 0;
+        s_cnt[threadIdx.x] = f;
+        __syncthreads();
+        for (int off = 1; off < (int)blockDim.x; off <<= 1) {       // inclusive scan
+            int v = (threadIdx.x >= (unsigned)off) ? s_cnt[threadIdx.x - off] : 0;
+            __syncthreads();
+            s_cnt[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (f) lig_node[s_base + s_cnt[threadIdx.x] - 1] = (int32_t)i;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) s_base += s_cnt[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && count) *count = s_base;
+}
+int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s) {
+    ligand_list_kernel<<<dim3(1), dim3(1024), 0, s>>>(mask, N, lig_node, count);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ kNN
+// One wavefront per query node.  Lane l scores the candidates beg + l, beg + l + 64, ... of the query's
+// graph; key = (fp32 bits of d2) << 32 | global index, so the unsigned 64-bit order is exactly the
+// (d2, index) order of the project's kNN rule.  The 32 smallest keys are extracted by 32 rounds of
+// {per-lane minimum, 6-step butterfly wave minimum, winner retires its candidate}; round r's key ends up
+// in lane r, i.e. the row comes out sorted ascending.  Graphs larger than 64*CH nodes are scanned in
+// passes; the running best-32 (one per lane 0..31) joins the next pass as an extra candidate.
+constexpr unsigned long long TD_KEY_MAX = ~0ull;
+
+template <int CH>
+__global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
+                                                  const int32_t *__restrict__ gid, int64_t N,
+                                                  int32_t *__restrict__ nbr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int g = gid[i];
+    const int beg = ptr[g], end = ptr[g + 1];
+    const float4 xi = x4[i];
+    unsigned long long best = TD_KEY_MAX;    // lanes 0..31: current r-th smallest key
+    for (int base = beg; base < end; base += 64 * CH) {
+        unsigned long long key[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            int j = base + lane + 64 * u;
+            key[u] = TD_KEY_MAX;
+            if (j < end && j != (int)i) {
+                float4 xj = x4[j];
+                float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+                key[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+            }
+        }
+        unsigned long long carry = best;     // previous passes' winners compete again
+        unsigned long long out = TD_KEY_MAX;
+        for (int r = 0; r < TD_K; ++r) {
+            unsigned long long lmin = carry;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) lmin = key[u] < lmin ? key[u] : lmin;
+            unsigned long long wmin = lmin;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                unsigned long long o = __shfl_xor(wmin, off);
+                wmin = o < wmin ? o : wmin;
+            }
+            if (wmin != TD_KEY_MAX) {        // keys are unique (they embed the index): exactly one owner
+                if (carry == wmin) carry = TD_KEY_MAX;
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (key[u] == wmin) key[u] = TD_KEY_MAX;
+            }
+            if (lane == r) out = wmin;
+        }
+        best = out;
+    }
+    if (lane < TD_K) nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+}
+
+int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, int max_graph_nodes,
+                  int32_t *nbr, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    if (max_graph_nodes > 0 && max_graph_nodes <= 256)
+        knn_kernel<4><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
+    else if (max_graph_nodes > 0 && max_graph_nodes <= 384)
+        knn_kernel<6><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
+    else if (max_graph_nodes <= 704)         // also the "unknown" (0) default
+        knn_kernel<11><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
+    else
+        knn_kernel<17><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ compose
+// h0 = [Linear(protein_v) ; 0] / [Linear(one_hot(ligand_v)) ; 1], written straight into the packed
+// (graph-major, protein-then-ligand) node order that compose_context's stable sort produces.
+constexpr int TD_COMPOSE_ATOMS = 16;
+
+__global__ __launch_bounds__(128) void compose_protein_kernel(
+    const float *__restrict__ ppos, const float *__restrict__ pv, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ lptr, int64_t Np, int B, int F, const float *__restrict__ WpT,
+    const float *__restrict__ bp, float *__restrict__ h, float4 *__restrict__ x4, int32_t *__restrict__ gid) {
+    __shared__ float s_v[TD_COMPOSE_ATOMS][32];
+    const int n = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
+    for (int idx = n; idx < TD_COMPOSE_ATOMS * 32; idx += 128) {
+        int a = idx >> 5, c = idx & 31;
+        s_v[a][c] = (a0 + a < Np && c < F) ? pv[(a0 + a) * F + c] : 0.f;
+    }
+    __syncthreads();
+    float w[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) w[c] = (c < F) ? WpT[c * TD_H + n] : 0.f;
+    const float bias = bp[n];
+    for (int a = 0; a < TD_COMPOSE_ATOMS; ++a) {
+        int64_t at = a0 + a;
+        if (at >= Np) break;
+        int g = td_find_graph(pptr, B, (int)at);
+        int64_t p = at + lptr[g];
+        float acc = bias;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc = fmaf(w[c], s_v[a][c], acc);
+        h[p * TD_H + n] = acc;
+        if (n == 0) {
+            x4[p] = make_float4(ppos[3 * at], ppos[3 * at + 1], ppos[3 * at + 2], 0.f);
+            gid[p] = g;
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void compose_ligand_kernel(
+    const float *__restrict__ lpos, const int64_t *__restrict__ lv, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ lptr, int64_t Nl, int B, int C, const float *__restrict__ WlT,
+    const float *__restrict__ bl, float *__restrict__ h, float4 *__restrict__ x4, int32_t *__restrict__ gid,
+    int32_t *__restrict__ lig_node) {
+    const int n = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
+    const float bias = bl[n];
+    for (int a = 0; a < TD_COMPOSE_ATOMS; ++a) {
+        int64_t at = a0 + a;
+        if (at >= Nl) break;
+        int g = td_find_graph(lptr, B, (int)at);
+        int64_t p = (int64_t)pptr[g + 1] + at;
+        int v = (int)lv[at];
+        v = v < 0 ? 0 : (v >= C ? C - 1 : v);
+        h[p * TD_H + n] = WlT[v * TD_H + n] + bias;
+        if (n == 0) {
+            x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
+            gid[p] = g;
+            lig_node[at] = (int32_t)p;
+        }
+    }
+}
+
+__global__ void node_ptr_kernel(const int32_t *__restrict__ pptr, const int32_t *__restrict__ lptr, int B,
+                                int32_t *__restrict__ node_ptr) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= B) node_ptr[g] = pptr[g] + lptr[g];
+}
+
+int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
+                      const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
+                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, hipStream_t s) {
+    node_ptr_kernel<<<dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s>>>(pptr, lptr, (int)B, node_ptr);
+    TD_CHECK_HIP(hipGetLastError());
+    if (Np > 0) {
+        unsigned nb = (unsigned)((Np + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
+        compose_protein_kernel<<<dim3(nb), dim3(128), 0, s>>>(ppos, pv, pptr, lptr, Np, (int)B,
+                                                             m->cfg.protein_feat_dim, m->emb.WpT, m->emb.bp, h, x4,
+                                                             gid);
+        TD_CHECK_HIP(hipGetLastError());
+    }
+    if (Nl > 0) {
+        unsigned nb = (unsigned)((Nl + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
+        compose_ligand_kernel<<<dim3(nb), dim3(128), 0, s>>>(lpos, lv, pptr, lptr, Nl, (int)B,
+                                                            m->cfg.ligand_num_classes, m->emb.WlT, m->emb.bl, h, x4,
+                                                            gid, lig_node);
+        TD_CHECK_HIP(hipGetLastError());
+    }
+    return TD_OK;
+}

@@ -1,0 +1,221 @@
+// Small per-ligand-atom kernels of one reverse-diffusion step (gfx950):
+//   * head_kernel       v_inference = Linear -> ShiftedSoftplus -> Linear on ligand rows
+//                       (models/molopt_score_model.py:307-311,351-352; models/common.py:156-162)
+//   * posterior_kernel  Gaussian + categorical posterior and Gumbel-max draw
+//                       (models/molopt_score_model.py:673-685 and the helpers cited in targetdiff_hip.h)
+//   * center kernels    center_pos(mode='protein') (models/molopt_score_model.py:110-120)
+// The reference spends ~40 tiny launches and two host syncs per step here; each is one launch.
+#include "td_device.h"
+#include "td_internal.h"
+
+constexpr int HEAD_ATOMS = 8;
+
+__global__ __launch_bounds__(128) void head_kernel(TdHead hd, const float *__restrict__ h,
+                                                   const float4 *__restrict__ x4,
+                                                   const int32_t *__restrict__ lig_node, int64_t Nl, int C,
+                                                   float *__restrict__ pred_pos, float *__restrict__ pred_v,
+                                                   float *__restrict__ lig_h) {
+    __shared__ float s_h[HEAD_ATOMS][TD_H];
+    __shared__ float s_y[HEAD_ATOMS][TD_H];
+    const int n = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * HEAD_ATOMS;
+    for (int a = 0; a < HEAD_ATOMS; ++a) {
+        const int64_t at = a0 + a;
+        float v = 0.f;
+        if (at < Nl) {
+            const int64_t p = lig_node[at];
+            v = h[p * TD_H + n];
+            if (lig_h) lig_h[at * TD_H + n] = v;
+            if (n < 3) {
+                const float4 xp = x4[p];
+                pred_pos[at * 3 + n] = n == 0 ? xp.x : (n == 1 ? xp.y : xp.z);
+            }
+        }
+        s_h[a][n] = v;
+    }
+    __syncthreads();
+    float acc[HEAD_ATOMS];
+    const float b0 = hd.b0[n];
+#pragma unroll
+    for (int a = 0; a < HEAD_ATOMS; ++a) acc[a] = b0;
+    for (int k = 0; k < TD_H; ++k) {
+        const float wv = hd.W0T[k * TD_H + n];
+#pragma unroll
+        for (int a = 0; a < HEAD_ATOMS; ++a) acc[a] = fmaf(wv, s_h[a][k], acc[a]);
+    }
+#pragma unroll
+    for (int a = 0; a < HEAD_ATOMS; ++a) {
+        const float xv = acc[a];
+        const float sp = xv > 20.f ? xv : log1pf(expf(xv));          // F.softplus (beta 1, threshold 20)
+        s_y[a][n] = sp - 0.69314718055994531f;                      // ShiftedSoftplus: - log(2)
+    }
+    __syncthreads();
+    // second Linear: 128 -> C (C <= 16).  thread (a, cc) = (n / 16, n % 16)
+    const int a = n >> 4, cc = n & 15;
+    if (cc < C && a0 + a < Nl) {
+        float o = hd.b2[cc];
+        for (int k = 0; k < TD_H; ++k) o = fmaf(hd.W2T[k * TD_MAXC + cc], s_y[a][k], o);
+        pred_v[(a0 + a) * C + cc] = o;
+    }
+}
+
+int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
+                   int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s) {
+    if (Nl == 0) return TD_OK;
+    head_kernel<<<dim3((unsigned)((Nl + HEAD_ATOMS - 1) / HEAD_ATOMS)), dim3(128), 0, s>>>(
+        hd, h, x4, lig_node, Nl, classes, pred_pos, pred_v, lig_h);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ posterior
+__device__ __forceinline__ float td_log_add_exp(float a, float b) {      // molopt_score_model.py:173-175
+    const float m = fmaxf(a, b);
+    return m + logf(expf(a - m) + expf(b - m));
+}
+
+__device__ __forceinline__ int td_find_graph_l(const int32_t *__restrict__ ptr, int B, int i) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restrict__ tg,
+                                 const int32_t *__restrict__ lptr, int64_t Nl, int B, int C,
+                                 const float *__restrict__ pos, const int64_t *__restrict__ v,
+                                 const float *__restrict__ pred_pos, const float *__restrict__ pred_v,
+                                 const float *__restrict__ noise, const float *__restrict__ uni,
+                                 float *__restrict__ pos_next, int64_t *__restrict__ v_next,
+                                 float *__restrict__ log_v0_out, float *__restrict__ log_post_out) {
+    const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (at >= Nl) return;
+    const int g = td_find_graph_l(lptr, B, (int)at);
+    int t = tg[g];
+    t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+    // ---- positions: mean = c0[t] x0 + ct[t] x_t ; x_{t-1} = mean + [t != 0] exp(0.5 logvar[t]) eps  (:673-679)
+    const float c0 = sc.c0[t], ct = sc.ct[t];
+    const float sd = t == 0 ? 0.f : expf(0.5f * sc.logvar[t]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        pos_next[at * 3 + d] = (c0 * pred_pos[at * 3 + d] + ct * pos[at * 3 + d]) + sd * noise[at * 3 + d];
+    // ---- types (:682-685)
+    float lg[TD_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < TD_MAXC; ++cc) {
+        lg[cc] = cc < C ? pred_v[at * C + cc] : -INFINITY;
+        mx = fmaxf(mx, lg[cc]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < TD_MAXC; ++cc) se += cc < C ? expf(lg[cc] - mx) : 0.f;
+    const float lse = mx + logf(se);
+    const int tm1 = t - 1 < 0 ? 0 : t - 1;
+    const float lnK = logf((float)C);
+    const float l_ca = sc.log_ca[tm1], l_1mca = sc.log_1mca[tm1] - lnK;
+    const float l_a = sc.log_a[t], l_1ma = sc.log_1ma[t] - lnK;
+    const int vt = (int)v[at];
+    const float LOG_EPS = logf(1e-30f);                         // log(clamp(onehot, 1e-30)), :129
+    float un[TD_MAXC];
+    float umx = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < TD_MAXC; ++cc) {
+        if (cc < C) {
+            const float lv0 = lg[cc] - lse;                     // log_softmax
+            lg[cc] = lv0;
+            const float lvt = cc == vt ? 0.f : LOG_EPS;
+            un[cc] = td_log_add_exp(lv0 + l_ca, l_1mca) + td_log_add_exp(lvt + l_a, l_1ma);
+            umx = fmaxf(umx, un[cc]);
+        } else {
+            un[cc] = -INFINITY;
+        }
+    }
+    float us = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < TD_MAXC; ++cc) us += cc < C ? expf(un[cc] - umx) : 0.f;
+    const float ulse = umx + logf(us);
+    int best = 0;
+    float bestv = -INFINITY;
+#pragma unroll
+    for (int cc = 0; cc < TD_MAXC; ++cc) {
+        if (cc < C) {
+            const float lp = un[cc] - ulse;
+            if (log_v0_out) log_v0_out[at * C + cc] = lg[cc];
+            if (log_post_out) log_post_out[at * C + cc] = lp;
+            const float gum = -logf(-logf(uni[at * C + cc] + 1e-30f) + 1e-30f);     // :160-166
+            const float sc2 = gum + lp;
+            if (sc2 > bestv) { bestv = sc2; best = cc; }        // first maximum, like argmax
+        }
+    }
+    v_next[at] = best;
+}
+
+int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B,
+                        int classes, const float *pos, const int64_t *v, const float *pred_pos,
+                        const float *pred_v, const float *noise, const float *uni, float *pos_next,
+                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s) {
+    if (Nl == 0) return TD_OK;
+    posterior_kernel<<<dim3((unsigned)((Nl + 127) / 128)), dim3(128), 0, s>>>(
+        sc, T, t, lptr, Nl, (int)B, classes, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0,
+        log_post);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ centring
+__global__ __launch_bounds__(256) void center_kernel(float *__restrict__ ppos, const int32_t *__restrict__ pptr,
+                                                     float *__restrict__ lpos, const int32_t *__restrict__ lptr,
+                                                     float *__restrict__ offset, int compute, float sign) {
+    __shared__ float red[3][256];
+    __shared__ float s_off[3];
+    const int g = blockIdx.x;
+    if (compute) {
+        const int b = pptr[g], e = pptr[g + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int i = b + threadIdx.x; i < e; i += blockDim.x) {
+            sx += ppos[3 * i]; sy += ppos[3 * i + 1]; sz += ppos[3 * i + 2];
+        }
+        red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sy; red[2][threadIdx.x] = sz;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (threadIdx.x < (unsigned)off) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + off];
+                red[1][threadIdx.x] += red[1][threadIdx.x + off];
+                red[2][threadIdx.x] += red[2][threadIdx.x + off];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 3) {
+            const int cnt = e - b;                                // scatter_mean: sum / clamp(count, 1)
+            const float o = red[threadIdx.x][0] / (float)(cnt < 1 ? 1 : cnt);
+            s_off[threadIdx.x] = o;
+            offset[3 * g + threadIdx.x] = o;
+        }
+    } else if (threadIdx.x < 3) {
+        s_off[threadIdx.x] = offset[3 * g + threadIdx.x];
+    }
+    __syncthreads();
+    const float ox = sign * s_off[0], oy = sign * s_off[1], oz = sign * s_off[2];
+    if (ppos) {
+        for (int i = pptr[g] + threadIdx.x; i < pptr[g + 1]; i += blockDim.x) {
+            ppos[3 * i] += ox; ppos[3 * i + 1] += oy; ppos[3 * i + 2] += oz;
+        }
+    }
+    if (lpos) {
+        for (int i = lptr[g] + threadIdx.x; i < lptr[g + 1]; i += blockDim.x) {
+            lpos[3 * i] += ox; lpos[3 * i + 1] += oy; lpos[3 * i + 2] += oz;
+        }
+    }
+}
+
+int td_launch_center(float *ppos, const int32_t *pptr, float *lpos, const int32_t *lptr, int64_t B, float *offset,
+                     int compute, int sign, hipStream_t s) {
+    if (B == 0) return TD_OK;
+    center_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(ppos, pptr, lpos, lptr, offset, compute,
+                                                         sign < 0 ? -1.f : 1.f);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

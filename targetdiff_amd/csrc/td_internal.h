@@ -1,0 +1,124 @@
+// Internal declarations shared by the translation units of libtargetdiff_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/targetdiff_hip.h"
+
+// ---- compile-time shape of the live configuration (configs/training.yml:9-42) ----------------------
+constexpr int TD_H = 128;        // hidden_dim
+constexpr int TD_HEADS = 16;     // n_heads
+constexpr int TD_DH = 8;         // head dim
+constexpr int TD_K = 32;         // knn fan-in: one node's in-edges = one 32-row MFMA tile
+constexpr int TD_NG = 20;        // num_r_gaussian
+constexpr int TD_SLOTK = 24;     // K columns per source-class slot of the first-layer edge GEMM: 20 g + 1 + 3 pad
+constexpr int TD_SLOT_STEPS = TD_SLOTK / 2;   // 12 MFMA k-steps per slot
+constexpr int TD_KSTEPS = TD_H / 2;           // 64 k-steps (32x32x2) for a 128-deep contraction
+constexpr int TD_MAXC = 16;      // ligand classes padded
+
+void td_set_error(const char *fmt, ...);
+#define TD_CHECK_HIP(expr)                                                                       \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            td_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TD_EHIP;                                                                      \
+        }                                                                                        \
+    } while (0)
+
+// ---- packed weights (device pointers) ---------------------------------------------------------------
+// One edge MLP (hk/hv/xk/xv: Linear(340,128) -> LN -> ReLU -> Linear(128,out)), re-packed:
+//  * the 340-wide first Linear is split into node-side projections (proj_*), a per-(dst class, src class)
+//    radial/type table R and a bias;  * the second Linear is stored as per-wave MFMA B fragments.
+struct TdEdgeMlp {
+    const float *R;        // [2 dst class][4 wave][2 slot][12 kstep][64 lane]  first-layer radial+type B fragments
+    const float *gamma;    // [128] LayerNorm weight
+    const float *beta;     // [128] LayerNorm bias
+    const float *W2;       // out=128: [4 wave][64 kstep][64 lane];  out=16 (xv): [4 wave(K slice)][16 kstep][64 lane]
+    const float *b2;       // [128] or [16]
+};
+
+// Node-side weights of one stage (x2h or h2x): 4 projections (k_i,k_j,v_i,v_j) + the query MLP.
+struct TdNodeStage {
+    const float *projB;    // [5 mat][64 kstep][64 lane][4 ntile]   mats: k_i, k_j, v_i, v_j, q.net.0
+    const float *projBias; // [5][128]  (k_i: b0 of k MLP, k_j: 0, v_i: b0 of v MLP, v_j: 0, q: b0)
+    const float *qGamma, *qBeta;   // [128]
+    const float *q3B;      // [64 kstep][64 lane][4 ntile]  q.net.3
+    const float *q3Bias;   // [128]
+};
+
+struct TdLayer {
+    TdNodeStage nodeX2h, nodeH2x;
+    TdEdgeMlp hk, hv, xk, xv;
+    const float *offsets;  // [20] Gaussian centres of this layer (models/common.py:15)
+    float coeff;           // -0.5 / (offset[1]-offset[0])^2
+};
+
+struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_transformer.py:236-237,312-316)
+    const float *R;        // [12 kstep][64 lane][4 ntile]
+    const float *b0, *gamma, *beta, *w3;   // [128] each
+    float b3;
+    const float *offsets;  // [20]
+    float coeff;
+};
+
+struct TdEmbed {
+    const float *WpT;      // [protein_feat_dim][128]  (column 127 zero)
+    const float *bp;       // [128] (entry 127 = 0: node indicator of protein atoms)
+    const float *WlT;      // [classes][128]
+    const float *bl;       // [128] (entry 127 = 1: node indicator of ligand atoms)
+};
+
+struct TdHead {            // v_inference (models/molopt_score_model.py:307-311)
+    const float *W0T;      // [128 in][128 out]
+    const float *b0;       // [128]
+    const float *W2T;      // [128 in][16 out] (classes padded)
+    const float *b2;       // [16]
+};
+
+struct TdSchedules {       // [T] each
+    const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_ca, *log_1mca;
+};
+
+struct td_model {
+    td_config cfg;
+    float *blob;           // one device allocation holding every packed tensor
+    size_t blob_floats;
+    TdEmbed emb;
+    TdGate gate;
+    TdLayer *layers;       // host array [num_layers]
+    TdHead head;
+    TdSchedules sched;
+};
+
+// ---- kernel launchers (each defined next to its kernels) --------------------------------------------
+// graph.hip
+int td_launch_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr, hipStream_t s);
+int td_launch_node_gid(const int32_t *node_ptr, int64_t N, int64_t B, int32_t *gid, hipStream_t s);
+int td_launch_pack_x(const float *x3, const uint8_t *mask, int64_t N, float4 *x4, hipStream_t s);
+int td_launch_unpack_x(const float4 *x4, int64_t N, float *x3, hipStream_t s);
+int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, int max_graph_nodes,
+                  int32_t *nbr, hipStream_t s);
+int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
+                      const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
+                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, hipStream_t s);
+int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
+// node.hip
+int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, float *P, float *q, hipStream_t s);
+// edge.hip
+int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, float *ew, hipStream_t s);
+int td_launch_x2h(const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
+                  const float *q, int64_t N, float *h, hipStream_t s);
+int td_launch_h2x(const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr, const float *ew,
+                  const float *P, const float *q, const int32_t *lig_node, int64_t Nl, hipStream_t s);
+// misc.hip
+int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
+                   int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);
+int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B,
+                        int classes, const float *pos, const int64_t *v, const float *pred_pos,
+                        const float *pred_v, const float *noise, const float *uni, float *pos_next,
+                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
+int td_launch_center(float *ppos, const int32_t *pptr, float *lpos, const int32_t *lptr, int64_t B, float *offset,
+                     int compute, int sign, hipStream_t s);

@@ -1,0 +1,350 @@
+"""Host-side mirror of the reference's model interface for the denoising path.
+
+Same class names, constructor arguments, ``state_dict`` keys and call signatures as
+``models/molopt_score_model.py`` / ``models/uni_transformer.py`` so that
+``scripts/sample_diffusion.py`` and ``scripts/sample_for_pocket.py`` run unchanged
+ -- but the modules below only *hold* parameters.  All arithmetic of the path runs in
+libtargetdiff_hip.so (hand-written HIP for gfx950) through ``capi.NativeModel``; there is no PyTorch or
+CPU implementation of the layers in this package, and calling them without the library / a HIP device
+raises.
+
+Seams mirrored (reference file:line):
+  ScorePosNet3D.__init__            models/molopt_score_model.py:194-311
+  ScorePosNet3D.forward             models/molopt_score_model.py:313-368
+  ScorePosNet3D.sample_diffusion    models/molopt_score_model.py:633-703
+  get_refine_net                    models/molopt_score_model.py:13-45
+  UniTransformerO2TwoUpdateGeneral  models/uni_transformer.py:213-328  (forward :301-328)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import capi
+
+_FIXED_OFFSETS = (0, 1, 1.25, 1.5, 1.75, 2, 2.25, 2.5, 2.75, 3, 3.5, 4, 4.5, 5, 5.5, 6, 7, 8, 9, 10)
+
+
+def _cfg_get(config, key, default=None):
+    if isinstance(config, dict):
+        return config.get(key, default)
+    return getattr(config, key, default)
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class _Offsets(nn.Module):
+    """Holds the ``offset`` buffer of GaussianSmearing (models/common.py:7-19, fixed_offset=True)."""
+
+    def __init__(self, num_gaussians: int):
+        super().__init__()
+        if num_gaussians != len(_FIXED_OFFSETS):
+            raise NotImplementedError('the HIP kernels are built for the 20 fixed Gaussian centres')
+        self.register_buffer('offset', torch.tensor(_FIXED_OFFSETS, dtype=torch.float32))
+
+
+class _MLPParams(nn.Module):
+    """Parameters of the reference 2-layer MLP (models/common.py:60-80): keys net.0 / net.1 / net.3."""
+
+    def __init__(self, in_dim: int, out_dim: int, hidden_dim: int):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(in_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.ReLU(),
+                                 nn.Linear(hidden_dim, out_dim))
+
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter holder: the arithmetic runs in libtargetdiff_hip.so')
+
+
+class _X2HParams(nn.Module):
+    def __init__(self, hidden, heads, kv_in):
+        super().__init__()
+        self.hk_func = _MLPParams(kv_in, hidden, hidden)
+        self.hv_func = _MLPParams(kv_in, hidden, hidden)
+        self.hq_func = _MLPParams(hidden, hidden, hidden)
+
+
+class _H2XParams(nn.Module):
+    def __init__(self, hidden, heads, kv_in):
+        super().__init__()
+        self.xk_func = _MLPParams(kv_in, hidden, hidden)
+        self.xv_func = _MLPParams(kv_in, heads, hidden)
+        self.xq_func = _MLPParams(hidden, hidden, hidden)
+
+
+class _AttLayerParams(nn.Module):
+    def __init__(self, hidden, heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x):
+        super().__init__()
+        kv_in = 2 * hidden + edge_feat_dim + 4 * num_r_gaussian
+        self.distance_expansion = _Offsets(num_r_gaussian)
+        self.x2h_layers = nn.ModuleList([_X2HParams(hidden, heads, kv_in) for _ in range(num_x2h)])
+        self.h2x_layers = nn.ModuleList([_H2XParams(hidden, heads, kv_in) for _ in range(num_h2x)])
+
+
+class UniTransformerO2TwoUpdateGeneral(nn.Module):
+    """``refine_net``: kNN graph + edge gate + num_layers x (x2h, h2x) -- executed by td_refine_forward."""
+
+    def __init__(self, num_blocks, num_layers, hidden_dim, n_heads=1, k=32, num_r_gaussian=50, edge_feat_dim=0,
+                 num_node_types=8, act_fn='relu', norm=True, cutoff_mode='radius', ew_net_type='r',
+                 num_init_x2h=1, num_init_h2x=0, num_x2h=1, num_h2x=1, r_max=10., x2h_out_fc=True,
+                 sync_twoup=False):
+        super().__init__()
+        unsupported = []
+        if num_blocks != 1: unsupported.append(f'num_blocks={num_blocks}')
+        if cutoff_mode != 'knn': unsupported.append(f'cutoff_mode={cutoff_mode!r}')
+        if ew_net_type != 'global': unsupported.append(f'ew_net_type={ew_net_type!r}')
+        if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
+        if num_x2h != 1 or num_h2x != 1: unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x}')
+        if x2h_out_fc or sync_twoup: unsupported.append(f'x2h_out_fc={x2h_out_fc}/sync_twoup={sync_twoup}')
+        if (hidden_dim, n_heads, k, num_r_gaussian, edge_feat_dim) != (128, 16, 32, 20, 4):
+            unsupported.append(f'shape {(hidden_dim, n_heads, k, num_r_gaussian, edge_feat_dim)}')
+        if unsupported:
+            raise NotImplementedError('libtargetdiff_hip.so is built for the live configuration of '
+                                      'configs/training.yml:9-42; unsupported: ' + ', '.join(unsupported))
+        self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
+        self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
+        self.cutoff_mode, self.ew_net_type = cutoff_mode, ew_net_type
+        self.distance_expansion = _Offsets(num_r_gaussian)
+        self.edge_pred_layer = _MLPParams(num_r_gaussian, 1, hidden_dim)
+        # built by the reference with (num_init_x2h, num_init_h2x) and never called (uni_transformer.py:245 vs
+        # :301-328); kept so that checkpoints load with strict=True.
+        self.init_h_emb_layer = _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim,
+                                                num_init_x2h, num_init_h2x)
+        self.base_block = nn.ModuleList([
+            _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x)
+            for _ in range(num_layers)])
+        self._owner = None       # set by ScorePosNet3D: the module that owns the packed native weights
+
+    def forward(self, h, x, mask_ligand, batch, return_all=False, fix_x=False):
+        if return_all:
+            raise NotImplementedError('return_all=True (per-block outputs) is not built yet')
+        if self._owner is None:
+            raise RuntimeError('refine_net must be owned by a ScorePosNet3D (it packs the weights for the HIP library)')
+        native = self._owner()._native(h.device)
+        B = int(batch.max().item()) + 1 if batch.numel() else 0
+        node_ptr = native.graph_ptr(batch.contiguous(), B)
+        out_h, out_x, _, _ = native.refine_forward(h.contiguous().float(), x.contiguous().float(), mask_ligand,
+                                                   node_ptr, fix_x=fix_x)
+        return {'x': out_x, 'h': out_h}
+
+
+def get_refine_net(refine_net_type, config):
+    """models/molopt_score_model.py:13-45."""
+    if refine_net_type != 'uni_o2':
+        # 'egnn' cannot be reached through ScorePosNet3D in the reference either (TypeError at :349)
+        raise NotImplementedError(f'refine_net_type {refine_net_type!r}: only uni_o2 is built')
+    g = lambda k, d=None: _cfg_get(config, k, d)
+    return UniTransformerO2TwoUpdateGeneral(
+        num_blocks=g('num_blocks'), num_layers=g('num_layers'), hidden_dim=g('hidden_dim'), n_heads=g('n_heads'),
+        k=g('knn'), edge_feat_dim=g('edge_feat_dim'), num_r_gaussian=g('num_r_gaussian'),
+        num_node_types=g('num_node_types'), act_fn=g('act_fn'), norm=g('norm'), cutoff_mode=g('cutoff_mode'),
+        ew_net_type=g('ew_net_type'), num_x2h=g('num_x2h'), num_h2x=g('num_h2x'), r_max=g('r_max'),
+        x2h_out_fc=g('x2h_out_fc'), sync_twoup=g('sync_twoup'))
+
+
+# ------------------------------------------------------------------------------------------ schedules
+def _sigmoid_betas(beta_start, beta_end, T):
+    t = np.linspace(-6, 6, T)
+    return 1.0 / (1.0 + np.exp(-t)) * (beta_end - beta_start) + beta_start
+
+
+def _cosine_alphas(T, s):
+    steps = T + 1
+    grid = np.linspace(0, steps, steps)
+    cum = np.cos(((grid / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    cum = cum / cum[0]
+    return np.sqrt(np.clip(cum[1:] / cum[:-1], a_min=0.001, a_max=1.0))
+
+
+def _const(x):
+    return nn.Parameter(torch.from_numpy(np.asarray(x)).float(), requires_grad=False)
+
+
+class ShiftedSoftplus(nn.Module):
+    """Position 1 of ``v_inference`` (models/common.py:156-162); parameter-free, evaluated inside head_kernel."""
+
+    def forward(self, x):
+        raise RuntimeError('evaluated inside libtargetdiff_hip.so')
+
+
+class ScorePosNet3D(nn.Module):
+    """Drop-in for models/molopt_score_model.py::ScorePosNet3D on the sampling path.
+
+    Training-only members (get_diffusion_loss, likelihood_estimation, ...) are out of scope.
+    """
+
+    def __init__(self, config, protein_atom_feature_dim, ligand_atom_feature_dim):
+        super().__init__()
+        self.config = config
+        g = lambda k, d=None: _cfg_get(config, k, d)
+        self.model_mean_type = g('model_mean_type')
+        self.loss_v_weight = g('loss_v_weight')
+        self.sample_time_method = g('sample_time_method')
+        if self.model_mean_type != 'C0':
+            raise NotImplementedError("model_mean_type != 'C0' is not built (configs/training.yml:10)")
+        if g('time_emb_dim', 0) != 0:
+            raise NotImplementedError('time_emb_dim > 0 is not built (configs/training.yml:20)')
+        if not g('node_indicator', True):
+            raise NotImplementedError('node_indicator=False is not built')
+
+        # ---- variance schedules, float64 on the host exactly as the reference builds them (:221-267)
+        T = g('num_diffusion_timesteps')
+        sched = g('beta_schedule')
+        if sched == 'cosine':
+            alphas = _cosine_alphas(T, g('pos_beta_s')) ** 2
+            betas = 1.0 - alphas
+        elif sched == 'sigmoid':
+            betas = _sigmoid_betas(g('beta_start'), g('beta_end'), T)
+            alphas = 1.0 - betas
+        elif sched == 'linear':
+            betas = np.linspace(g('beta_start'), g('beta_end'), T, dtype=np.float64)
+            alphas = 1.0 - betas
+        else:
+            raise NotImplementedError(sched)
+        cum = np.cumprod(alphas, axis=0)
+        cum_prev = np.append(1.0, cum[:-1])
+        self.betas = _const(betas)
+        self.num_timesteps = self.betas.size(0)
+        self.alphas_cumprod = _const(cum)
+        self.alphas_cumprod_prev = _const(cum_prev)
+        self.sqrt_alphas_cumprod = _const(np.sqrt(cum))
+        self.sqrt_one_minus_alphas_cumprod = _const(np.sqrt(1.0 - cum))
+        self.sqrt_recip_alphas_cumprod = _const(np.sqrt(1.0 / cum))
+        self.sqrt_recipm1_alphas_cumprod = _const(np.sqrt(1.0 / cum - 1))
+        post_var = betas * (1.0 - cum_prev) / (1.0 - cum)
+        self.posterior_mean_c0_coef = _const(betas * np.sqrt(cum_prev) / (1.0 - cum))
+        self.posterior_mean_ct_coef = _const((1.0 - cum_prev) * np.sqrt(alphas) / (1.0 - cum))
+        self.posterior_var = _const(post_var)
+        pv32 = self.posterior_var.detach().numpy()        # the reference logs the fp32-rounded tensor (:254)
+        self.posterior_logvar = _const(np.log(np.append(pv32[1], pv32[1:])))
+        if g('v_beta_schedule') != 'cosine':
+            raise NotImplementedError(g('v_beta_schedule'))
+        log_a = np.log(_cosine_alphas(self.num_timesteps, g('v_beta_s')))
+        log_ca = np.cumsum(log_a)
+        one_minus = lambda a: np.log(1 - np.exp(a) + 1e-40)
+        self.log_alphas_v = _const(log_a)
+        self.log_one_minus_alphas_v = _const(one_minus(log_a))
+        self.log_alphas_cumprod_v = _const(log_ca)
+        self.log_one_minus_alphas_cumprod_v = _const(one_minus(log_ca))
+        self.register_buffer('Lt_history', torch.zeros(self.num_timesteps))
+        self.register_buffer('Lt_count', torch.zeros(self.num_timesteps))
+
+        # ---- learnable tensors (held here, packed for the HIP kernels on first use)
+        self.hidden_dim = g('hidden_dim')
+        self.num_classes = ligand_atom_feature_dim
+        self.protein_atom_feature_dim = protein_atom_feature_dim
+        emb_dim = self.hidden_dim - 1
+        self.protein_atom_emb = nn.Linear(protein_atom_feature_dim, emb_dim)
+        self.center_pos_mode = g('center_pos_mode')
+        self.time_emb_dim = 0
+        self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim, emb_dim)
+        self.refine_net_type = g('model_type')
+        self.refine_net = get_refine_net(self.refine_net_type, config)
+        import weakref
+        self.refine_net._owner = weakref.ref(self)
+        self.v_inference = nn.Sequential(nn.Linear(self.hidden_dim, self.hidden_dim), ShiftedSoftplus(),
+                                         nn.Linear(self.hidden_dim, ligand_atom_feature_dim))
+        self._native_model = None
+        self._native_key = None
+
+    # ------------------------------------------------------------------------------------------ native handle
+    def _param_fingerprint(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _native(self, device) -> capi.NativeModel:
+        """Packed weights inside libtargetdiff_hip.so; rebuilt when a parameter was modified / reloaded."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError(f'targetdiff_amd runs on HIP devices only (got {device}); there is no CPU path')
+        key = self._param_fingerprint(device)
+        if self._native_model is None or key != self._native_key:
+            rn = self.refine_net
+            cfg = dict(hidden_dim=rn.hidden_dim, n_heads=rn.n_heads, knn=rn.k, num_layers=rn.num_layers,
+                       num_r_gaussian=rn.num_r_gaussian, edge_feat_dim=rn.edge_feat_dim,
+                       protein_feat_dim=self.protein_atom_feature_dim, ligand_num_classes=self.num_classes,
+                       num_timesteps=self.num_timesteps)
+            sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER}
+            self._native_model = capi.NativeModel(cfg, self.state_dict(), sched, device=device)
+            self._native_key = key
+        return self._native_model
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
+                time_step=None, return_all=False, fix_x=False):
+        """One denoiser evaluation (models/molopt_score_model.py:313-368).  ``time_step`` is unused by the
+        network when time_emb_dim == 0, as in the reference."""
+        if return_all:
+            raise NotImplementedError('return_all=True is not built yet')
+        native = self._native(protein_pos.device)
+        B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
+        pptr = native.graph_ptr(batch_protein.contiguous(), B)
+        lptr = native.graph_ptr(batch_ligand.contiguous(), B)
+        return native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr,
+                                    init_ligand_pos.contiguous().float(), init_ligand_v.contiguous(), lptr,
+                                    fix_x=fix_x)
+
+    @torch.no_grad()
+    def fetch_embedding(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand):
+        """models/molopt_score_model.py:620-631."""
+        return self(protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand, fix_x=True)
+
+    # ------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
+                         num_steps=None, center_pos_mode=None, pos_only=False, max_graph_nodes=0,
+                         noise_source=None):
+        """Ancestral sampling loop (models/molopt_score_model.py:633-703).
+
+        Differences from the reference are confined to *where* things run, not what is computed: no
+        ``.item()`` / D2H sync inside the loop (graph offsets are built once), trajectories are
+        accumulated in device buffers and copied to the host once at the end (same returned lists of CPU
+        tensors, positions de-centred).  ``noise_source(step, name, like)`` may inject the Gaussian /
+        uniform draws (parity tests); by default torch.randn_like / rand_like are used in the reference's
+        order."""
+        if pos_only:
+            raise NotImplementedError('pos_only=True is not built yet')
+        if center_pos_mode not in ('protein', 'none', None):
+            raise NotImplementedError(center_pos_mode)
+        dev = protein_pos.device
+        native = self._native(dev)
+        T = self.num_timesteps
+        num_steps = T if num_steps is None else num_steps
+        B = int(batch_protein.max().item()) + 1
+        pptr = native.graph_ptr(batch_protein.contiguous(), B)
+        lptr = native.graph_ptr(batch_ligand.contiguous(), B)
+        ppos = protein_pos.detach().clone().contiguous().float()
+        lpos = init_ligand_pos.detach().clone().contiguous().float()
+        lv = init_ligand_v.detach().clone().contiguous()
+        pv = protein_v.contiguous().float()
+        Nl, C = lpos.shape[0], self.num_classes
+        offset = None
+        if center_pos_mode == 'protein':
+            offset = native.center_pos(ppos, pptr, lpos, lptr)                         # :642
+        steps = list(reversed(range(T - num_steps, T)))                                 # :649
+        S = len(steps)
+        pos_traj = torch.empty(S, Nl, 3, dtype=torch.float32, device=dev)
+        v_traj = torch.empty(S, Nl, dtype=torch.int64, device=dev)
+        v0_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
+        vt_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
+        t_all = torch.tensor(steps, dtype=torch.int32, device=dev).view(S, 1).expand(S, B).contiguous()
+        bufs = {}
+        for s in range(S):
+            preds = native.model_forward(ppos, pv, pptr, lpos, lv, lptr, max_graph_nodes=max_graph_nodes,
+                                         want_final_h=False, out=bufs)
+            bufs = preds
+            if noise_source is None:
+                noise = torch.randn_like(lpos)                                          # :677
+                uniform = torch.rand(Nl, C, dtype=torch.float32, device=dev)            # :161
+            else:
+                noise = noise_source(s, 'noise', lpos)
+                uniform = noise_source(s, 'uniform', v0_traj[s])
+            native.posterior_step(t_all[s], lptr, lpos, lv, preds['pred_ligand_pos'], preds['pred_ligand_v'],
+                                  noise, uniform, pos_next=pos_traj[s], v_next=v_traj[s], log_v0=v0_traj[s],
+                                  log_post=vt_traj[s])
+            lpos, lv = pos_traj[s], v_traj[s]
+        if offset is not None:
+            pos_traj += offset[batch_ligand].unsqueeze(0)                               # :691
+        final_pos = pos_traj[-1].clone() if S else (lpos + (offset[batch_ligand] if offset is not None else 0))
+        final_v = v_traj[-1].clone() if S else lv
+        pos_cpu, v_cpu, v0_cpu, vt_cpu = pos_traj.cpu(), v_traj.cpu(), v0_traj.cpu(), vt_traj.cpu()
+        return {'pos': final_pos, 'v': final_v, 'pos_traj': list(pos_cpu.unbind(0)), 'v_traj': list(v_cpu.unbind(0)),
+                'v0_traj': list(v0_cpu.unbind(0)), 'vt_traj': list(vt_cpu.unbind(0))}

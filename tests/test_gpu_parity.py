@@ -1,0 +1,374 @@
+"""Parity of the HIP path (through the C ABI) against the oracle restatement and against the golden
+vectors of the real reference.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances (fp32, stated once): neighbour indices and sampled atom types bit-exact; |dx| <= 2e-5 A on
+coordinates, |dh|, |dlogit| <= 2e-4 on features / type logits (the re-association noise floor of one
+reference forward is ~4e-7 A / 8e-7).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, small_inputs, pocket_1h36
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 2e-5
+TOL_H = 2e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    return torch.device('cuda:0')
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+@pytest.fixture(scope='module')
+def model(state_dict):
+    from oracle import weights
+    from targetdiff_amd.models import ScorePosNet3D
+    dev = _dev()
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    res = m.load_state_dict(state_dict, strict=False)
+    assert not res.unexpected_keys
+    return m.to(dev).eval()
+
+
+def _native_with_layers(state_dict, num_layers, dev):
+    from oracle import weights
+    from targetdiff_amd import capi
+    cfg = dict(hidden_dim=128, n_heads=16, knn=32, num_layers=num_layers, num_r_gaussian=20, edge_feat_dim=4,
+               protein_feat_dim=27, ligand_num_classes=13, num_timesteps=1000)
+    from oracle import restatement as R
+    sched = {k: v.numpy() for k, v in R.diffusion_schedules().items()}
+    with torch.cuda.device(dev):
+        return capi.NativeModel(cfg, state_dict, sched, device=dev)
+
+
+# ------------------------------------------------------------------------------------------ graph ops
+def test_graph_ptr(model):
+    dev = _dev()
+    nat = model._native(dev)
+    batch = torch.tensor([0, 0, 0, 2, 2, 3, 5, 5, 5, 5], device=dev)
+    ptr = nat.graph_ptr(batch, 7).cpu().tolist()
+    assert ptr == [0, 3, 3, 5, 6, 6, 10, 10]
+
+
+@pytest.mark.parametrize('sizes', [[147], [40, 33, 32, 5, 1, 2], [700], [1100, 90], [64, 65, 63, 128, 129]])
+def test_knn_bit_exact(model, sizes):
+    from oracle import shims
+    dev = _dev()
+    nat = model._native(dev)
+    g = torch.Generator().manual_seed(sum(sizes))
+    x = torch.randn(sum(sizes), 3, generator=g) * 6.0
+    x[3] = x[1]                                # exact duplicate: ties resolved towards the lower index
+    if sum(sizes) > 50:
+        x[17] = x[40]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    want = shims.knn_neighbours(x, 32, batch)
+    ptr = nat.graph_ptr(batch.to(dev), len(sizes))
+    for hint in (0, max(sizes)):
+        got = nat.knn(x.to(dev), ptr, 32, hint).cpu().long()
+        np.testing.assert_array_equal(got.numpy(), want.numpy())
+
+
+def test_knn_1h36_real_geometry(model):
+    from oracle import shims
+    from targetdiff_amd import workloads
+    dev = _dev()
+    nat = model._native(dev)
+    g = load_golden('forward_1h36x2.npz')
+    pocket, _ = pocket_1h36()
+    b = workloads.pack_samples(pocket, 2, g['sizes'])
+    # composed order: per graph [protein..., ligand...]
+    from oracle import restatement as R
+    ppos, _, _ = R.center_positions(b.protein_pos, torch.zeros(len(b.ligand_element_batch), 3),
+                                    b.protein_element_batch, b.ligand_element_batch)
+    _, pos, batch_all, _ = R.compose_context(torch.zeros(len(ppos), 1), torch.zeros(len(g['ligand_pos']), 1), ppos,
+                                             torch.from_numpy(g['ligand_pos']), b.protein_element_batch,
+                                             b.ligand_element_batch)
+    ptr = nat.graph_ptr(batch_all.to(dev), 2)
+    got = nat.knn(pos.to(dev).contiguous(), ptr, 32, 0).cpu().numpy()
+    np.testing.assert_array_equal(got, g['nbr'])          # == what the real reference ran on
+
+
+# ------------------------------------------------------------------------------------------ node GEMMs
+def test_node_stage_projections(model, state_dict):
+    dev = _dev()
+    nat = model._native(dev)
+    g = torch.Generator().manual_seed(3)
+    for N in (1, 37, 128, 300):
+        h = torch.randn(N, 128, generator=g)
+        for layer, stage in ((0, 0), (4, 1), (8, 0)):
+            P, q = nat.debug_node_stage(layer, stage, h.to(dev))
+            names = ('hk_func', 'hv_func', 'hq_func') if stage == 0 else ('xk_func', 'xv_func', 'xq_func')
+            pre = f'refine_net.base_block.{layer}.' + ('x2h_layers.0.' if stage == 0 else 'h2x_layers.0.')
+            hd = h.double()
+            want = []
+            for nm in names[:2]:
+                w0 = state_dict[pre + nm + '.net.0.weight'].double()
+                b0 = state_dict[pre + nm + '.net.0.bias'].double()
+                want.append(hd @ w0[:, 84:212].T + b0)
+                want.append(hd @ w0[:, 212:340].T)
+            want = torch.cat(want, dim=1)
+            assert _maxdiff(P, want) < 5e-5, (N, layer, stage)
+            from oracle import restatement as R
+            qw = R._mlp(state_dict, pre + names[2], hd, torch.float64)
+            assert _maxdiff(q, qw) < 5e-5, (N, layer, stage)
+
+
+# ------------------------------------------------------------------------------------------ backbone stages
+def _compose_small(state_dict, g):
+    from oracle import restatement as R
+    import torch.nn.functional as F
+    inp = small_inputs(g)
+    col = {}
+    out = R.model_forward(state_dict, None, inp['protein_pos'], inp['protein_v'], inp['batch_protein'],
+                          inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'], collect=col)
+    return inp, out, col
+
+
+def test_refine_first_layer_stagewise(state_dict, golden_small):
+    """num_layers = 1 model through td_refine_forward: neighbour table bit exact, gate, h and x after layer 0."""
+    from oracle import restatement as R
+    import torch.nn.functional as F
+    dev = _dev()
+    g = golden_small
+    inp = small_inputs(g)
+    nat1 = _native_with_layers(state_dict, 1, dev)
+    # the composed inputs of the backbone, from the restatement's own embedding + compose
+    C = 13
+    lv = F.one_hot(inp['ligand_v'], C).float()
+    h_p = F.linear(inp['protein_v'], state_dict['protein_atom_emb.weight'], state_dict['protein_atom_emb.bias'])
+    h_l = F.linear(lv, state_dict['ligand_atom_emb.weight'], state_dict['ligand_atom_emb.bias'])
+    h_p = torch.cat([h_p, torch.zeros(len(h_p), 1)], -1)
+    h_l = torch.cat([h_l, torch.ones(len(h_l), 1)], -1)
+    h, x, batch_all, mask = R.compose_context(h_p, h_l, inp['protein_pos'], inp['ligand_pos'], inp['batch_protein'],
+                                              inp['batch_ligand'])
+    B = int(batch_all.max()) + 1
+    ptr = nat1.graph_ptr(batch_all.to(dev), B)
+    out_h, out_x, nbr, ew = nat1.refine_forward(h.to(dev).contiguous(), x.to(dev).contiguous(), mask.to(dev), ptr,
+                                                want_graph=True)
+    np.testing.assert_array_equal(nbr.cpu().numpy(), g['nbr'])
+    valid = g['nbr'] >= 0
+    assert _maxdiff(ew.cpu().numpy()[valid], g['e_w'][valid]) < 1e-5
+    assert np.all(ew.cpu().numpy()[~valid] == 0)
+    dh = _maxdiff(out_h, g['h_layers'][0])
+    dx = _maxdiff(out_x, g['x_layers'][0])
+    print(f'layer0: |dh|={dh:.3e} |dx|={dx:.3e}')
+    assert dh < TOL_H and dx < TOL_X
+    # fix_x: coordinates untouched, same h
+    out_h2, out_x2, _, _ = nat1.refine_forward(h.to(dev).contiguous(), x.to(dev).contiguous(), mask.to(dev), ptr,
+                                               fix_x=True)
+    assert torch.equal(out_x2.cpu(), x)
+    assert _maxdiff(out_h2, g['h_layers'][0]) < TOL_H
+
+
+def test_refine_net_module_full_depth(model, state_dict, golden_small):
+    """refine_net(h, x, mask_ligand, batch) seam, all 9 layers, vs the real reference's per-layer outputs."""
+    from oracle import restatement as R
+    import torch.nn.functional as F
+    dev = _dev()
+    g = golden_small
+    inp = small_inputs(g)
+    lv = F.one_hot(inp['ligand_v'], 13).float()
+    h_p = F.linear(inp['protein_v'], state_dict['protein_atom_emb.weight'], state_dict['protein_atom_emb.bias'])
+    h_l = F.linear(lv, state_dict['ligand_atom_emb.weight'], state_dict['ligand_atom_emb.bias'])
+    h_p = torch.cat([h_p, torch.zeros(len(h_p), 1)], -1)
+    h_l = torch.cat([h_l, torch.ones(len(h_l), 1)], -1)
+    h, x, batch_all, mask = R.compose_context(h_p, h_l, inp['protein_pos'], inp['ligand_pos'], inp['batch_protein'],
+                                              inp['batch_ligand'])
+    out = model.refine_net(h.to(dev), x.to(dev), mask.to(dev), batch_all.to(dev))
+    dh = _maxdiff(out['h'], g['h_layers'][8])
+    dx = _maxdiff(out['x'], g['x_layers'][8])
+    print(f'layer8: |dh|={dh:.3e} |dx|={dx:.3e}')
+    assert dh < TOL_H and dx < TOL_X
+
+
+# ------------------------------------------------------------------------------------------ full forward
+def _forward(model, inp, dev, **kw):
+    return model(inp['protein_pos'].to(dev), inp['protein_v'].to(dev), inp['batch_protein'].to(dev),
+                 inp['ligand_pos'].to(dev), inp['ligand_v'].to(dev), inp['batch_ligand'].to(dev), **kw)
+
+
+def test_forward_small_vs_reference_golden(model, golden_small):
+    dev = _dev()
+    g = golden_small
+    out = _forward(model, small_inputs(g), dev)
+    d = {k: _maxdiff(out[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h', 'final_ligand_h')}
+    print(d)
+    assert d['pred_ligand_pos'] < TOL_X
+    assert d['pred_ligand_v'] < TOL_H and d['final_h'] < TOL_H and d['final_ligand_h'] < TOL_H
+
+
+def test_forward_small_fix_x(model, golden_small):
+    dev = _dev()
+    g = load_golden('forward_small_fixx.npz')
+    inp = small_inputs(golden_small)
+    out = _forward(model, inp, dev, fix_x=True)
+    assert torch.equal(out['pred_ligand_pos'].cpu(), inp['ligand_pos'])
+    assert _maxdiff(out['pred_ligand_v'], g['pred_ligand_v']) < TOL_H
+    assert _maxdiff(out['final_ligand_h'], g['final_ligand_h']) < TOL_H
+    emb = model.fetch_embedding(inp['protein_pos'].to(dev), inp['protein_v'].to(dev), inp['batch_protein'].to(dev),
+                                inp['ligand_pos'].to(dev), inp['ligand_v'].to(dev), inp['batch_ligand'].to(dev))
+    assert torch.equal(emb['final_ligand_h'], out['final_ligand_h'])
+
+
+def test_forward_1h36_vs_reference_golden(model):
+    from oracle import restatement as R
+    from targetdiff_amd import workloads
+    dev = _dev()
+    g = load_golden('forward_1h36x2.npz')
+    pocket, _ = pocket_1h36()
+    b = workloads.pack_samples(pocket, 2, g['sizes'])
+    ppos, _, _ = R.center_positions(b.protein_pos, torch.zeros(len(b.ligand_element_batch), 3),
+                                    b.protein_element_batch, b.ligand_element_batch)
+    out = model(ppos.to(dev), b.protein_atom_feature.float().to(dev), b.protein_element_batch.to(dev),
+                torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev),
+                b.ligand_element_batch.to(dev))
+    d = {k: _maxdiff(out[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h')}
+    d['final_h_sample'] = _maxdiff(out['final_h'][::16], g['final_h_sample'])
+    print(d)
+    assert d['pred_ligand_pos'] < TOL_X
+    assert max(d['pred_ligand_v'], d['final_ligand_h'], d['final_h_sample']) < TOL_H
+
+
+def test_forward_deterministic_and_batch_independent(model):
+    """Size-independent properties at a larger batch: bit-identical reruns (no atomics), and every replica
+    of the same (pocket, ligand) graph gets bit-identical outputs wherever it sits in the ragged pack."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    pocket = workloads.synthetic_pocket(1000, 300)
+    reps = 24
+    b = workloads.pack_samples(pocket, reps, [25] * reps).to(dev)
+    g = torch.Generator(device='cpu').manual_seed(1)
+    one = workloads.pack_samples(pocket, 1, [25])
+    pos1, v1 = workloads.init_ligand(one, generator=g)
+    lpos = pos1.repeat(reps, 1).to(dev)
+    lv = v1.repeat(reps).to(dev)
+    args = (b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv, b.ligand_element_batch)
+    o1 = model(*args)
+    o2 = model(*args)
+    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h'):
+        assert torch.equal(o1[k], o2[k]), k
+    pp = o1['pred_ligand_pos'].view(reps, 25, 3)
+    pv = o1['pred_ligand_v'].view(reps, 25, 13)
+    assert torch.equal(pp, pp[:1].expand_as(pp))
+    assert torch.equal(pv, pv[:1].expand_as(pv))
+
+
+def test_forward_rotation_equivariance(model):
+    """SE(3) property at a size the oracle would take minutes for: rotating + translating every input
+    coordinate rotates the predicted positions and leaves invariant features (almost) unchanged."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    pockets = [workloads.synthetic_pocket(1000 + p, 300) for p in range(4)]
+    b = workloads.pack_samples(pockets, 8, [25] * 32).to(dev)
+    g = torch.Generator().manual_seed(2)
+    lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets, 8, [25] * 32), generator=g)
+    lpos, lv = lpos.to(dev), lv.to(dev)
+    nat = model._native(dev)
+    pptr = nat.graph_ptr(b.protein_element_batch, 32)
+    lptr = nat.graph_ptr(b.ligand_element_batch, 32)
+    ppos = b.protein_pos.clone()
+    nat.center_pos(ppos, pptr, lpos, lptr)
+    A = torch.linalg.qr(torch.randn(3, 3, generator=g)).Q
+    if torch.det(A) < 0:
+        A[:, 0] = -A[:, 0]
+    A = A.to(dev)
+    pv = b.protein_atom_feature.float()
+    o1 = model(ppos, pv, b.protein_element_batch, lpos, lv, b.ligand_element_batch)
+    o2 = model(ppos @ A.T, pv, b.protein_element_batch, lpos @ A.T, lv, b.ligand_element_batch)
+    # per graph: a near-tie at the 32nd/33rd neighbour may legitimately flip under rotation (discrete kNN),
+    # so require the property on all but at most 2 of the 32 graphs.
+    dpos = ((o1['pred_ligand_pos'] @ A.T) - o2['pred_ligand_pos']).abs().view(32, 25, 3).amax(dim=(1, 2))
+    dv = (o1['pred_ligand_v'] - o2['pred_ligand_v']).abs().view(32, 25, 13).amax(dim=(1, 2))
+    print('rotation: max dpos per graph', dpos.max().item(), 'median', dpos.median().item())
+    assert int((dpos < 2e-4).sum()) >= 30 and int((dv < 2e-3).sum()) >= 30
+
+
+# ------------------------------------------------------------------------------------------ posterior / sampling
+def test_posterior_known_answers(model):
+    dev = _dev()
+    nat = model._native(dev)
+    g = load_golden('posterior_kat.npz')
+    bl = torch.from_numpy(g['batch_ligand']).to(dev)
+    lptr = nat.graph_ptr(bl, 3)
+    T = lambda k, dt=None: torch.from_numpy(g[k]).to(dev)
+    n = bl.numel()
+    log_v0 = torch.empty(n, 13, device=dev)
+    log_post = torch.empty(n, 13, device=dev)
+    pos_next, v_next = nat.posterior_step(torch.from_numpy(g['t']).int().to(dev), lptr, T('x_t'), T('v_t'), T('x0'),
+                                          T('v0_logits'), T('noise'), T('uniform'), log_v0=log_v0, log_post=log_post)
+    assert _maxdiff(pos_next, g['pos_next']) < 2e-6
+    assert _maxdiff(log_v0, g['log_v0']) < 1e-5
+    assert _maxdiff(log_post, g['log_post']) < 2e-5
+    np.testing.assert_array_equal(v_next.cpu().numpy(), g['v_next'])
+
+
+def test_center_pos(model):
+    from targetdiff_amd import workloads
+    from oracle import restatement as R
+    dev = _dev()
+    nat = model._native(dev)
+    pockets = [workloads.synthetic_pocket(7, 50), workloads.synthetic_pocket(8, 300)]
+    b = workloads.pack_samples(pockets, 2, [5, 6, 7, 8])
+    lpos = torch.randn(26, 3)
+    wp, wl, woff = R.center_positions(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch)
+    pptr = nat.graph_ptr(b.protein_element_batch.to(dev), 4)
+    lptr = nat.graph_ptr(b.ligand_element_batch.to(dev), 4)
+    pp, ll = b.protein_pos.clone().to(dev), lpos.clone().to(dev)
+    off = nat.center_pos(pp, pptr, ll, lptr)
+    assert _maxdiff(off, woff) < 1e-5 and _maxdiff(pp, wp) < 1e-5 and _maxdiff(ll, wl) < 1e-5
+
+
+def test_sample_diffusion_trajectory_vs_reference(model):
+    """6 reverse steps with the reference's own recorded randn/rand draws injected: every step's positions
+    within tolerance, every sampled atom type bit-exact."""
+    from oracle.make_golden import small_batch
+    dev = _dev()
+    g = load_golden('sample_small.npz')
+    b, lpos, lv = small_batch()
+    noises = torch.from_numpy(g['noises']).to(dev)
+    unis = torch.from_numpy(g['uniforms']).to(dev)
+
+    def src(step, name, like):
+        return (noises if name == 'noise' else unis)[step].contiguous()
+    r = model.sample_diffusion(b.protein_pos.to(dev), b.protein_atom_feature.float().to(dev),
+                               b.protein_element_batch.to(dev), lpos.to(dev), lv.to(dev),
+                               b.ligand_element_batch.to(dev), num_steps=6, center_pos_mode='protein',
+                               noise_source=src)
+    assert len(r['pos_traj']) == 6 and not r['pos_traj'][0].is_cuda
+    np.testing.assert_array_equal(torch.stack(r['v_traj']).numpy(), g['v_traj'])
+    d = dict(pos=_maxdiff(torch.stack(r['pos_traj']), g['pos_traj']), v0=_maxdiff(torch.stack(r['v0_traj']), g['v0_traj']),
+             vt=_maxdiff(torch.stack(r['vt_traj']), g['vt_traj']), final=_maxdiff(r['pos'], g['pos']))
+    print(d)
+    assert d['pos'] < 5e-5 and d['final'] < 5e-5 and d['v0'] < 5e-4 and d['vt'] < 5e-4
+    np.testing.assert_array_equal(r['v'].cpu().numpy(), g['v'])
+
+
+def test_sample_diffusion_ligand_driver(model):
+    from targetdiff_amd import sampling, workloads
+    dev = _dev()
+    pocket = workloads.synthetic_pocket(55, 120)
+    res = sampling.sample_diffusion_ligand(model, pocket, num_samples=5, batch_size=3, device=dev, num_steps=3,
+                                           ligand_num_atoms=[9, 10, 11, 12, 13])
+    pos, v, pos_traj, v_traj, v0_traj, vt_traj, times = res
+    assert [p.shape for p in pos] == [(n, 3) for n in (9, 10, 11, 12, 13)] and pos[0].dtype == np.float64
+    assert [t.shape for t in pos_traj] == [(3, n, 3) for n in (9, 10, 11, 12, 13)]
+    assert [t.shape for t in v0_traj] == [(3, n, 13) for n in (9, 10, 11, 12, 13)]
+    assert len(times) == 2 and all(np.isfinite(p).all() for p in pos)
+    assert all(((x >= 0) & (x < 13)).all() for x in v)
+
+
+def test_fails_loudly_without_device_tensors(model):
+    cpu = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError):
+        model(cpu, torch.zeros(4, 27), torch.zeros(4, dtype=torch.long), cpu, torch.zeros(4, dtype=torch.long),
+              torch.zeros(4, dtype=torch.long))
