@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- ligands/sec of the TargetDiff denoising hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|c5] [--no-cpu-baseline]
+
+A "step" is one reverse-diffusion step (denoiser forward + posterior update + on-device trajectory
+record) over one packed batch.  Default workload = BASELINE.json configs[1] (the configuration the
+metric is quoted on): the 1h36 pocket (572 protein atoms), 100 samples with ligand sizes from the
+reference prior (np seed 2021), packed in one ragged graph on one GPU.  Inputs are resident in HBM
+before the timed region.  metric value = n_gpus * samples_per_batch / (1000 steps * seconds_per_step):
+the rate at which finished ligands leave a 1000-step sampler.  With N > 1 (torch.distributed.run, one
+rank per GPU over RCCL) every rank samples its own pocket replica -- pockets shard with no data-path
+collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = edge_attn_kernel<x2h>; achieved = algorithmic FLOPs per launch
+               (2.441216 MFLOP per dst node) / mean launch time from HIP events recorded on
+               the launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, dense).
+  cpu_baseline the oracle restatement (torch CPU, same weights) timed on this host's cores over a bounded
+               sample of the same workload (the same pocket, fewer samples, a few steps).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from targetdiff_amd import capi, workloads  # noqa: E402
+from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
+X2H_FLOP_PER_NODE = 2 * (2 * 32 * 128 * 20 + 2 * 32 * 128 * 128 + 2 * 32 * 128)   # = 2,441,216
+METRIC = 'ligands/sec (1000-step sampling, 100 samples/pocket) at 1/2/4/8 MI355X'
+
+# configs/training.yml:9-42
+MODEL_CONFIG = dict(
+    model_mean_type='C0', beta_schedule='sigmoid', beta_start=1.e-7, beta_end=2.e-3, v_beta_schedule='cosine',
+    v_beta_s=0.01, num_diffusion_timesteps=1000, loss_v_weight=100., sample_time_method='symmetric', time_emb_dim=0,
+    time_emb_mode='simple', center_pos_mode='protein', node_indicator=True, model_type='uni_o2', num_blocks=1,
+    num_layers=9, hidden_dim=128, n_heads=16, edge_feat_dim=4, num_r_gaussian=20, knn=32, num_node_types=8,
+    act_fn='relu', norm=True, cutoff_mode='knn', ew_net_type='global', num_x2h=1, num_h2x=1, r_max=10.,
+    x2h_out_fc=False, sync_twoup=False)
+
+
+def load_1h36():
+    with np.load(os.path.join(ROOT, 'tests', 'golden', 'pocket_1h36.npz')) as z:
+        return workloads.Pocket(z['pos'], z['feat'].astype(np.int64), '1h36_pocket10'), z['prior_sizes_seed2021']
+
+
+def make_workload(name: str, rank: int):
+    """-> (pockets, samples_per_pocket, ligand sizes per graph, description)"""
+    if name == 'c2':
+        pocket, sizes = load_1h36()
+        return [pocket], 100, [int(s) for s in sizes], 'C2: 1h36 pocket10 (572 atoms) x 100 samples, prior sizes'
+    if name == 'c1':
+        pocket, sizes = load_1h36()
+        return [pocket], 4, [int(s) for s in sizes[:4]], 'C1: 1h36 pocket10 x 4 samples'
+    if name == 'c3':
+        pockets = [workloads.synthetic_pocket(1000 + p + 32 * rank, 300) for p in range(32)]
+        return pockets, 100, [25] * 3200, 'C3: 32 synthetic 300-atom pockets x 100 samples x 25 ligand atoms'
+    if name == 'c5':
+        pocket = workloads.synthetic_pocket(5000 + rank, 1000, 4.0, 21.0)
+        return [pocket], 256, [30] * 256, 'C5: synthetic 1000-atom pocket x 256 samples x 30 ligand atoms'
+    raise ValueError(name)
+
+
+def seeded_state_dict(model, seed=2021):
+    """Random-init weights of the reference architecture (no checkpoint ships with the reference)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if k.endswith('net.1.weight'):
+            sd[k] = 1.0 + 0.2 * torch.randn(p.shape, generator=g)
+        elif k.endswith('net.1.bias'):
+            sd[k] = 0.1 * torch.randn(p.shape, generator=g)
+        else:
+            fan_in = p.shape[-1] if p.dim() > 1 else p.shape[0]
+            sd[k] = (torch.rand(p.shape, generator=g) * 2 - 1) / (fan_in ** 0.5)
+    return sd
+
+
+def cpu_baseline(pocket, sizes, samples=4, steps=2):
+    """Oracle restatement on the host cores; bounded sample of the same workload."""
+    from oracle import restatement as R
+    from oracle import weights
+    sd = weights.make_state_dict(2021)
+    b = workloads.pack_samples(pocket, samples, sizes[:samples])
+    g = torch.Generator().manual_seed(0)
+    lpos, lv = workloads.init_ligand(b, generator=g)
+    nl = lpos.shape[0]
+    noises = torch.randn(steps + 1, nl, 3, generator=g)
+    unis = torch.rand(steps + 1, nl, 13, generator=g)
+    cores = torch.get_num_threads()
+    args = (sd, None, b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
+            b.ligand_element_batch)
+    R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)            # warm-up
+    t0 = time.time()
+    R.sample_diffusion(*args, num_steps=steps, noises=noises, uniforms=unis)
+    sec_per_step = (time.time() - t0) / steps
+    return {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/restatement.py (torch CPU fp32), same pocket, {samples} samples x {steps} steps '
+                      f'({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, extrapolated to 1000 steps'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c2', choices=['c1', 'c2', 'c3', 'c5'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-all', action='store_true', help='time every kernel class, print a breakdown to stderr')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (MI355X); there is no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI; rendezvous + timing max only
+
+    pockets, spp, sizes, desc = make_workload(args.workload, rank)
+    model = ScorePosNet3D(MODEL_CONFIG, workloads.PROTEIN_FEATURE_DIM, workloads.NUM_LIGAND_CLASSES)
+    model.load_state_dict(seeded_state_dict(model), strict=False)
+    model = model.to(dev).eval()
+
+    batch = workloads.pack_samples(pockets, spp, sizes).to(dev)
+    gen = torch.Generator(device='cpu').manual_seed(2021 + rank)
+    lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets, spp, sizes), generator=gen)
+    lpos, lv = lpos.to(dev), lv.to(dev)
+    n_nodes = int(batch.protein_pos.shape[0] + lpos.shape[0])
+    max_nodes = max(p.num_atoms for p in pockets) + max(sizes)
+    total = args.warmup + args.steps
+    if total > 1000:
+        raise SystemExit('warmup + steps must be <= 1000 (one sampling run)')
+    sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
+                                   lpos, lv, batch.ligand_element_batch, num_steps=total, center_pos_mode='protein',
+                                   max_graph_nodes=max_nodes)
+    for _ in range(args.warmup):
+        sampler.step()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h',)
+    fence()
+    capi.profile_begin(classes)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sampler.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = capi.profile_end()
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    sec_per_step = elapsed / args.steps
+    graphs = len(pockets) * spp
+    value = world * graphs / (1000.0 * sec_per_step)
+
+    x2h = prof['x2h']
+    x2h_ms = x2h['ms'] / max(1, x2h['launches'])
+    achieved = X2H_FLOP_PER_NODE * n_nodes / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
+    out = {
+        'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded random weights of the reference architecture; '
+        + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
+        'config': {'workload': desc, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
+                   'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
+        'roofline': {'bound': 'mfma', 'kernel': 'edge_attn_kernel<x2h>', 'achieved': achieved,
+                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': None,
+                     'launch_ms': x2h_ms, 'launches': x2h['launches'],
+                     'share_of_step': (x2h['ms'] / args.steps) / (sec_per_step * 1e3)},
+    }
+    if rank == 0:
+        if args.profile_all:
+            for k, v in prof.items():
+                if v['launches']:
+                    print(f'  {k:10s} {v["ms"] / args.steps:9.3f} ms/step  ({v["launches"] // args.steps} launches/step)',
+                          file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(pockets[0], sizes)
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -124,6 +124,14 @@ int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_l
                   const int32_t *d_ligand_ptr, int64_t B, float *d_offset, int32_t compute_offset,
                   int32_t sign, void *stream);
 
+/* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
+ *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;
+ *      td_profile_end synchronises the device and returns per-class summed milliseconds and launch counts.
+ *      Classes: 0 knn, 1 edge gate, 2 node projections, 3 x2h, 4 h2x, 5 compose, 6 head, 7 posterior. */
+#define TD_PROFILE_CLASSES 8
+int td_profile_begin(uint32_t class_mask);
+int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
+
 /* ---- test hook (not a reference seam): node-side GEMMs of one attention stage of layer `layer`
  *      (stage 0 = x2h: hk/hv/hq, stage 1 = h2x: xk/xv/xq).  d_P [N,512] = [k_i | k_j | v_i | v_j] node
  *      projections of the 340-wide first Linear (h_i part incl. bias), d_q [N,128] = MLP_q(h). */

@@ -47,7 +47,27 @@ SIGNATURES = {
     'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
+    'td_profile_begin': (c_int32, [ctypes.c_uint32]),
+    'td_profile_end': (c_int32, [POINTER(c_float), POINTER(c_int32), c_int32]),
 }
+
+PROFILE_CLASSES = ('knn', 'gate', 'node_proj', 'x2h', 'h2x', 'compose', 'head', 'posterior')
+
+
+def profile_begin(classes=PROFILE_CLASSES):
+    mask = 0
+    for c in classes:
+        mask |= 1 << PROFILE_CLASSES.index(c)
+    _check(load_library().td_profile_begin(mask), 'td_profile_begin')
+
+
+def profile_end() -> dict:
+    n = len(PROFILE_CLASSES)
+    ms = (c_float * n)()
+    cnt = (c_int32 * n)()
+    _check(load_library().td_profile_end(ms, cnt, n), 'td_profile_end')
+    return {name: {'ms': float(ms[i]), 'launches': int(cnt[i])} for i, name in enumerate(PROFILE_CLASSES)}
+
 
 _lib = None
 

@@ -22,6 +22,63 @@ void td_set_error(const char *fmt, ...) {
 extern "C" const char *td_last_error(void) { return g_err; }
 extern "C" int td_abi_version(void) { return TD_ABI_VERSION; }
 
+// ------------------------------------------------------------------------------------------ kernel timers
+// Optional per-kernel-class HIP-event timers (bench.py's roofline leg): events are recorded on the launch
+// stream around the selected classes; td_profile_end synchronises and sums hipEventElapsedTime.
+namespace {
+enum { PC_KNN = 0, PC_GATE, PC_NODE, PC_X2H, PC_H2X, PC_COMPOSE, PC_HEAD, PC_POST, PC_COUNT };
+struct Profiler {
+    unsigned mask = 0;
+    std::vector<hipEvent_t> ev[PC_COUNT];     // start/stop pairs
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Profiler g_prof;
+struct ProfScope {
+    int cls; hipStream_t s; bool on;
+    ProfScope(int c, hipStream_t st) : cls(c), s(st), on((g_prof.mask >> c) & 1u) {
+        if (on) { hipEvent_t e = g_prof.get(); (void)hipEventRecord(e, s); g_prof.ev[cls].push_back(e); }
+    }
+    ~ProfScope() {
+        if (on) { hipEvent_t e = g_prof.get(); (void)hipEventRecord(e, s); g_prof.ev[cls].push_back(e); }
+    }
+};
+}  // namespace
+
+extern "C" int td_profile_begin(uint32_t class_mask) {
+    for (int c = 0; c < PC_COUNT; ++c) {
+        for (hipEvent_t e : g_prof.ev[c]) g_prof.pool.push_back(e);
+        g_prof.ev[c].clear();
+    }
+    g_prof.mask = class_mask;
+    return TD_OK;
+}
+
+extern "C" int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes) {
+    g_prof.mask = 0;
+    TD_CHECK_HIP(hipDeviceSynchronize());
+    for (int c = 0; c < PC_COUNT; ++c) {
+        float total = 0.f;
+        int n = 0;
+        for (size_t i = 0; i + 1 < g_prof.ev[c].size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_prof.ev[c][i], g_prof.ev[c][i + 1]) == hipSuccess) { total += ms; ++n; }
+        }
+        if (c < num_classes) {
+            if (ms_out) ms_out[c] = total;
+            if (count_out) count_out[c] = n;
+        }
+        for (hipEvent_t e : g_prof.ev[c]) g_prof.pool.push_back(e);
+        g_prof.ev[c].clear();
+    }
+    return TD_OK;
+}
+
 // ------------------------------------------------------------------------------------------ blob layout
 namespace {
 
@@ -325,16 +382,17 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
                  float4 **x_final, hipStream_t s) {
     int rc;
-    if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
-    if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, w.ew, s)) != TD_OK) return rc;
+    { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
+    { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, w.ew, s)) != TD_OK) return rc; }
     float4 *xc = w.x4a, *xn = w.x4b;
     if (!fix_x && Nl > 0) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < m->cfg.num_layers; ++l) {
         const TdLayer &L = m->layers[l];
-        if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc;
-        if ((rc = td_launch_x2h(L, xc, w.nbr, w.ew, w.P, w.q, N, h, s)) != TD_OK) return rc;
+        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H, s); if ((rc = td_launch_x2h(L, xc, w.nbr, w.ew, w.P, w.q, N, h, s)) != TD_OK) return rc; }
         if (!fix_x && Nl > 0) {
-            if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc;
+            { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc; }
+            ProfScope ps(PC_H2X, s);
             if ((rc = td_launch_h2x(L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, s)) != TD_OK) return rc;
             float4 *t = xc; xc = xn; xn = t;
         }
@@ -435,11 +493,15 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     float *h = d_final_h ? d_final_h : w.h;
-    if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
-                                d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, s)) != TD_OK)
-        return rc;
+    {
+        ProfScope ps(PC_COMPOSE, s);
+        if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
+                                    d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, s)) != TD_OK)
+            return rc;
+    }
     float4 *xf = nullptr;
     if ((rc = run_backbone(m, w, h, N, N_l, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
+    ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, h, xf, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
 }
@@ -456,6 +518,7 @@ extern "C" int td_posterior_step(const td_model *m, const int32_t *d_t, const in
         td_set_error("td_posterior_step: null pointer");
         return TD_EINVAL;
     }
+    ProfScope ps(PC_POST, static_cast<hipStream_t>(stream));
     return td_launch_posterior(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, N_l, B, m->cfg.ligand_num_classes,
                                d_ligand_pos, d_ligand_v, d_pred_pos, d_pred_v, d_noise, d_uniform, d_pos_next,
                                d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream));

@@ -288,6 +288,13 @@ class ScorePosNet3D(nn.Module):
         return self(protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand, fix_x=True)
 
     # ------------------------------------------------------------------------------------------ sampling
+    def begin_sampling(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
+                       num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None):
+        """Set up the reverse-diffusion state on the device and return a :class:`ReverseSampler`
+        (``.step()`` = one iteration of the loop at models/molopt_score_model.py:650-693)."""
+        return ReverseSampler(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
+                              batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source)
+
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                          num_steps=None, center_pos_mode=None, pos_only=False, max_graph_nodes=0,
@@ -302,49 +309,81 @@ class ScorePosNet3D(nn.Module):
         order."""
         if pos_only:
             raise NotImplementedError('pos_only=True is not built yet')
+        sampler = self.begin_sampling(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
+                                      batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source)
+        while not sampler.done:
+            sampler.step()
+        return sampler.finish()
+
+
+class ReverseSampler:
+    """Device-resident state of one ``sample_diffusion`` call."""
+
+    @torch.no_grad()
+    def __init__(self, model, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
+                 num_steps, center_pos_mode, max_graph_nodes, noise_source):
         if center_pos_mode not in ('protein', 'none', None):
             raise NotImplementedError(center_pos_mode)
         dev = protein_pos.device
-        native = self._native(dev)
-        T = self.num_timesteps
+        self.native = native = model._native(dev)
+        T = model.num_timesteps
         num_steps = T if num_steps is None else num_steps
-        B = int(batch_protein.max().item()) + 1
-        pptr = native.graph_ptr(batch_protein.contiguous(), B)
-        lptr = native.graph_ptr(batch_ligand.contiguous(), B)
-        ppos = protein_pos.detach().clone().contiguous().float()
-        lpos = init_ligand_pos.detach().clone().contiguous().float()
-        lv = init_ligand_v.detach().clone().contiguous()
-        pv = protein_v.contiguous().float()
-        Nl, C = lpos.shape[0], self.num_classes
-        offset = None
+        self.B = B = int(batch_protein.max().item()) + 1                                 # :638 (once, not per step)
+        self.pptr = native.graph_ptr(batch_protein.contiguous(), B)
+        self.lptr = native.graph_ptr(batch_ligand.contiguous(), B)
+        self.ppos = protein_pos.detach().clone().contiguous().float()
+        self.lpos = init_ligand_pos.detach().clone().contiguous().float()
+        self.lv = init_ligand_v.detach().clone().contiguous()
+        self.pv = protein_v.contiguous().float()
+        self.batch_ligand = batch_ligand
+        self.Nl, self.C = self.lpos.shape[0], model.num_classes
+        self.offset = None
         if center_pos_mode == 'protein':
-            offset = native.center_pos(ppos, pptr, lpos, lptr)                         # :642
-        steps = list(reversed(range(T - num_steps, T)))                                 # :649
-        S = len(steps)
-        pos_traj = torch.empty(S, Nl, 3, dtype=torch.float32, device=dev)
-        v_traj = torch.empty(S, Nl, dtype=torch.int64, device=dev)
-        v0_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
-        vt_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
-        t_all = torch.tensor(steps, dtype=torch.int32, device=dev).view(S, 1).expand(S, B).contiguous()
-        bufs = {}
-        for s in range(S):
-            preds = native.model_forward(ppos, pv, pptr, lpos, lv, lptr, max_graph_nodes=max_graph_nodes,
-                                         want_final_h=False, out=bufs)
-            bufs = preds
-            if noise_source is None:
-                noise = torch.randn_like(lpos)                                          # :677
-                uniform = torch.rand(Nl, C, dtype=torch.float32, device=dev)            # :161
-            else:
-                noise = noise_source(s, 'noise', lpos)
-                uniform = noise_source(s, 'uniform', v0_traj[s])
-            native.posterior_step(t_all[s], lptr, lpos, lv, preds['pred_ligand_pos'], preds['pred_ligand_v'],
-                                  noise, uniform, pos_next=pos_traj[s], v_next=v_traj[s], log_v0=v0_traj[s],
-                                  log_post=vt_traj[s])
-            lpos, lv = pos_traj[s], v_traj[s]
-        if offset is not None:
-            pos_traj += offset[batch_ligand].unsqueeze(0)                               # :691
-        final_pos = pos_traj[-1].clone() if S else (lpos + (offset[batch_ligand] if offset is not None else 0))
-        final_v = v_traj[-1].clone() if S else lv
+            self.offset = native.center_pos(self.ppos, self.pptr, self.lpos, self.lptr)   # :642
+        steps = list(reversed(range(T - num_steps, T)))                                   # :649
+        self.S = S = len(steps)
+        Nl, C = self.Nl, self.C
+        self.pos_traj = torch.empty(S, Nl, 3, dtype=torch.float32, device=dev)
+        self.v_traj = torch.empty(S, Nl, dtype=torch.int64, device=dev)
+        self.v0_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
+        self.vt_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
+        self.t_all = torch.tensor(steps, dtype=torch.int32, device=dev).view(S, 1).expand(S, B).contiguous()
+        self.max_graph_nodes = max_graph_nodes
+        self.noise_source = noise_source
+        self.bufs = {}
+        self.s = 0
+
+    @property
+    def done(self):
+        return self.s >= self.S
+
+    @torch.no_grad()
+    def step(self):
+        s, native = self.s, self.native
+        preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
+                                     max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
+        self.bufs = preds
+        if self.noise_source is None:
+            noise = torch.randn_like(self.lpos)                                            # :677
+            uniform = torch.rand(self.Nl, self.C, dtype=torch.float32, device=self.lpos.device)   # :161
+        else:
+            noise = self.noise_source(s, 'noise', self.lpos)
+            uniform = self.noise_source(s, 'uniform', self.v0_traj[s])
+        native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
+                              preds['pred_ligand_v'], noise, uniform, pos_next=self.pos_traj[s],
+                              v_next=self.v_traj[s], log_v0=self.v0_traj[s], log_post=self.vt_traj[s])
+        self.lpos, self.lv = self.pos_traj[s], self.v_traj[s]
+        self.s += 1
+
+    @torch.no_grad()
+    def finish(self):
+        S = self.s
+        pos_traj, v_traj, v0_traj, vt_traj = self.pos_traj[:S], self.v_traj[:S], self.v0_traj[:S], self.vt_traj[:S]
+        shift = self.offset[self.batch_ligand] if self.offset is not None else None
+        if shift is not None:
+            pos_traj = pos_traj + shift.unsqueeze(0)                                       # :691
+        final_pos = pos_traj[-1].clone() if S else (self.lpos + shift if shift is not None else self.lpos.clone())
+        final_v = v_traj[-1].clone() if S else self.lv
         pos_cpu, v_cpu, v0_cpu, vt_cpu = pos_traj.cpu(), v_traj.cpu(), v0_traj.cpu(), vt_traj.cpu()
         return {'pos': final_pos, 'v': final_v, 'pos_traj': list(pos_cpu.unbind(0)), 'v_traj': list(v_cpu.unbind(0)),
                 'v0_traj': list(v0_cpu.unbind(0)), 'vt_traj': list(vt_cpu.unbind(0))}
