@@ -138,6 +138,14 @@ int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
 int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N, float *d_P,
                         float *d_q, void *stream);
 
+/* ---- test hook: while d_buf != NULL, x2h launches run an instrumented variant in which lane 0 of every wave of
+ *      workgroup 0 stores clock64() stamps: d_buf[(wave * segs + segment) * 8 + stamp] (int64). */
+int td_debug_edge_timing(int64_t *d_buf, int32_t segs);
+
+/* ---- test hook: one wave evaluates the cross-lane reduction helpers on 64 inputs; out[6][64] =
+ *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */
+int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,8 @@ OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libtargetdiff_hip.so')
 SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'edge.hip', 'misc.hip']
 ARCH = 'gfx950'
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function',
-         '-ffp-contract=off']   # fp contraction off: kNN distances and LayerNorm follow the stated association
+# NB: the kNN distance uses __fmul_rn/__fadd_rn explicitly (td_dist2), so the default fp contraction is safe.
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function']
 
 
 def hipcc() -> str:

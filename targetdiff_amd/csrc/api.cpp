@@ -544,3 +544,12 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
     const TdLayer &L = m->layers[layer];
     return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, d_P, d_q, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int td_debug_edge_timing(int64_t *d_buf, int32_t segs) {
+    td_set_edge_timing(reinterpret_cast<long long *>(d_buf), segs);
+    return TD_OK;
+}
+
+extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream) {
+    return td_launch_reductions(d_in64, d_out6x64, static_cast<hipStream_t>(stream));
+}

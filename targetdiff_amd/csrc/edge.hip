@@ -121,12 +121,28 @@ struct EdgeArgs {
     TdEdgeMlp mk, mv;
     const float *offsets;
     float coeff;
+    long long *dbg;          // TIMING variant: [8 waves][dbg_segs][8 stamps] cycle counters of workgroup 0
+    int dbg_segs;
 };
 
-template <bool H2X>
+// Raw geometry loads of one dst node, issued one pipeline stage ahead of their use.
+struct GeoRaw {
+    int64_t i;
+    int j;
+    float4 xi, xj;
+    int4 jq[4];      // neighbour ids of this lane's 16 C-layout rows: rows 8q+4hi .. 8q+4hi+3
+};
+
+#define TD_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (TIMING && blockIdx.x == 0 && lane == 0 && seg < a.dbg_segs)                               \
+            a.dbg[((size_t)wid * a.dbg_segs + seg) * 8 + (k)] = clock64();                            \
+    } while (0)
+
+template <bool H2X, bool TIMING>
 __global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float Z[2][32][ZS];         // [role][edge][hidden]
-    __shared__ __attribute__((aligned(16))) float ALPHA[2][TD_HEADS][32];  // [buf][head][edge]  alpha * e_w
+    __shared__ __attribute__((aligned(16))) float ALPHA[2][TD_HEADS][32];  // [node parity][head][edge]  alpha * e_w
     __shared__ __attribute__((aligned(16))) float GB[2][2][TD_H];       // [role][gamma|beta][hidden]
     __shared__ __attribute__((aligned(16))) float XVP[4][32][16];       // h2x: per-wave partial xv
 
@@ -160,7 +176,6 @@ __global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
     }
     float rf[2][TD_SLOT_STEPS];
     int cur_cls = -1;
-    __syncthreads();
 
     // ---- XCD-aware contiguous node ranges: workgroup b runs on XCD b % 8 -> give XCD x the x-th eighth -----
     const int G = gridDim.x;
@@ -169,162 +184,223 @@ __global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
     const int64_t per = (a.count + G - 1) / G;
     const int64_t begin = (int64_t)chunk * per;
     const int64_t end = begin + per < a.count ? begin + per : a.count;
+    const int cnt = end > begin ? (int)(end - begin) : 0;
 
-    for (int64_t it = begin; it < end; ++it) {
-        const int64_t i = H2X ? (int64_t)a.lig_node[it] : it;
-        const int buf = (int)(it - begin) & 1;
+    auto load_geo = [&](int t) {
+        GeoRaw g;
+        g.i = H2X ? (int64_t)a.lig_node[begin + t] : begin + t;
+        g.j = a.nbr[g.i * TD_K + c];
+        g.xi = a.x4[g.i];
+        g.xj = a.x4[g.j >= 0 ? g.j : g.i];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            g.jq[qd] = *reinterpret_cast<const int4 *>(a.nbr + g.i * TD_K + 8 * qd + 4 * hi);
+        return g;
+    };
 
-        // ---- geometry of the 32 in-edges (redundant per wave: 1 index load + 1 float4 gather per lane) ----
-        const int j = a.nbr[i * TD_K + c];
-        const bool valid = j >= 0;
-        const float4 xi = a.x4[i];
-        const float4 xj = a.x4[valid ? j : i];
-        const float relx = xi.x - xj.x, rely = xi.y - xj.y, relz = xi.z - xj.z;     // x[dst] - x[src]
-        const float d = sqrtf(relx * relx + rely * rely + relz * relz);
-        const int slot = xj.w > 0.5f ? 0 : 1;          // source class: 0 ligand, 1 protein
-        const int cls = xi.w > 0.5f ? 0 : 1;           // destination class (wave uniform)
-        const bool has_a = __ballot(valid && slot == 0) != 0ull;
-        const bool has_b = __ballot(valid && slot == 1) != 0ull;
-        if (cls != cur_cls) {
-            cur_cls = cls;
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int s = 0; s < TD_SLOT_STEPS; ++s)
-                    rf[sl][s] = mlp.R[(size_t)((((cls * 4 + w) * 2 + sl) * TD_SLOT_STEPS) + s) * 64 + lane];
-        }
+    // state of the node a wave is working on (first layer in one segment, second layer in the next)
+    GeoRaw nxt;
+    if (cnt > 0) nxt = load_geo(0);
+    int64_t ci = 0;            // node id
+    unsigned cvalid = 0;       // bit r: C-layout row r of this lane is a real edge
+    float crx = 0.f, cry = 0.f, crz = 0.f;     // x_i - x_j of edge c   (h2x)
+    float4 cxi = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 
-        // ---- first layer ---------------------------------------------------------------------------------
-        int jr[16];
+    // ---- software pipeline over segments --------------------------------------------------------------------
+    // The two roles run half a node out of phase so that, on every SIMD, one wave's 64-MFMA second layer
+    // overlaps the other wave's gather / first layer / softmax:
+    //   segment 2t   : k role first(t)            | v role second(t-1) + reduce with alpha(t-1)
+    //   segment 2t+1 : k role second(t) -> alpha  | v role first(t)
+    // One barrier per segment.  Z[role] is written in the role's "first" segment and read in its "second".
+    for (int seg = 0; seg <= 2 * cnt; ++seg) {
+        const bool first_phase = ((seg & 1) == role);
+        const int t = first_phase ? (seg - role) >> 1 : (seg - 1 - role) >> 1;   // node handled in this segment
+        TD_STAMP(0);
+        if (first_phase && t < cnt) {
+            // ================= first layer of node t =======================================================
+            const GeoRaw g = nxt;
+            ci = g.i; cxi = g.xi;
+            const bool valid = g.j >= 0;
+            crx = g.xi.x - g.xj.x; cry = g.xi.y - g.xj.y; crz = g.xi.z - g.xj.z;        // x[dst] - x[src]
+            const float d = sqrtf(crx * crx + cry * cry + crz * crz);
+            const int slot = g.xj.w > 0.5f ? 0 : 1;         // source class: 0 ligand, 1 protein
+            const int cls = g.xi.w > 0.5f ? 0 : 1;          // destination class (wave uniform)
+            const bool has_a = __ballot(valid && slot == 0) != 0ull;
+            const bool has_b = __ballot(valid && slot == 1) != 0ull;
+            if (cls != cur_cls) {
+                cur_cls = cls;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) jr[r] = __shfl(j, td_erow(r, hi));
-        float bj[16];
-        const float *Pj = a.P + role * 256 + TD_H + n;
+                for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bj[r] = Pj[(size_t)(jr[r] >= 0 ? jr[r] : (int)i) * (4 * TD_H)];
-        const float pi = a.P[(size_t)i * (4 * TD_H) + role * 256 + n];
-        floatx16 acc;
+                    for (int s = 0; s < TD_SLOT_STEPS; ++s)
+                        rf[sl][s] = mlp.R[(size_t)((((cls * 4 + w) * 2 + sl) * TD_SLOT_STEPS) + s) * 64 + lane];
+            }
+            float bj[16];
+            const float *Pj = a.P + role * 256 + TD_H + n;
+            cvalid = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = pi;
-        float gv[TD_SLOT_STEPS];
+            for (int r = 0; r < 16; ++r) {
+                const int4 jv = g.jq[r >> 2];
+                const int jr = (r & 3) == 0 ? jv.x : (r & 3) == 1 ? jv.y : (r & 3) == 2 ? jv.z : jv.w;
+                cvalid |= jr >= 0 ? (1u << r) : 0u;
+                bj[r] = Pj[(size_t)(jr >= 0 ? jr : (int)g.i) * (4 * TD_H)];
+            }
+            const float pi = a.P[(size_t)g.i * (4 * TD_H) + role * 256 + n];
+            TD_STAMP(1);
+            floatx16 acc;
 #pragma unroll
-        for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-            const int k = td_kmap(s, hi);
-            const float u = d - offk[s];
-            gv[s] = k < TD_NG ? expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
-        }
-        if (has_a) {
-            const bool on = valid && slot == 0;
+            for (int r = 0; r < 16; ++r) acc[r] = pi;
+            float gv[TD_SLOT_STEPS];
 #pragma unroll
-            for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[0][s], acc);
-        }
-        if (has_b) {
-            const bool on = valid && slot == 1;
+            for (int s = 0; s < TD_SLOT_STEPS; ++s) {
+                const int k = td_kmap(s, hi);
+                const float u = d - offk[s];
+                gv[s] = k < TD_NG ? expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
+            }
+            if (has_a) {
+                const bool on = valid && slot == 0;
 #pragma unroll
-            for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[1][s], acc);
-        }
+                for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[0][s], acc);
+            }
+            if (has_b) {
+                const bool on = valid && slot == 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Z[role][td_erow(r, hi)][n] = acc[r] + bj[r];
-        __syncthreads();                                                            // B2: Z complete
-
-        // ---- LayerNorm + ReLU in A layout: lane (edge c, half hi) owns k in {8m+4hi .. 8m+4hi+3} ---------
-        // Two LDS passes instead of holding the half row in 64 VGPRs: (1) shifted sums -> mean / variance,
-        // (2) normalise + ReLU each 16-byte chunk right before the 4 MFMAs that consume it.
-        const float *zrow = &Z[role][c][4 * hi];
-        const float *gam = &GB[role][0][4 * hi];
-        const float *bet = &GB[role][1][4 * hi];
-        const float shift = Z[role][c][0];
-        float s1 = 0.f, s2 = 0.f;
+                for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[1][s], acc);
+            }
+            TD_STAMP(2);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
-            v.x -= shift; v.y -= shift; v.z -= shift; v.w -= shift;
-            s1 += (v.x + v.y) + (v.z + v.w);
-            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-        }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        const float dmean = s1 * (1.0f / TD_H);
-        const float mean = shift + dmean;
-        const float var = fmaxf(s2 * (1.0f / TD_H) - dmean * dmean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        floatx16 acc2;
-        if (full2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[r] = b2n;
+            for (int r = 0; r < 16; ++r) Z[role][td_erow(r, hi)][n] = acc[r] + bj[r];
+            TD_STAMP(3);
+        } else if (!first_phase && t >= 0 && t < cnt) {
+            // ================= second layer of node t ======================================================
+            if (t + 1 < cnt) nxt = load_geo(t + 1);       // prefetch: lands while the MFMAs below run
+            float hres = 0.f;
+            if (!H2X && role == 1 && hi == 0) hres = a.h[(size_t)ci * TD_H + n];   // residual, needed after the MFMAs
+            const int buf = t & 1;
+            // LayerNorm + ReLU in A layout: lane (edge c, half hi) owns k in {8m+4hi .. 8m+4hi+3}.
+            // Two LDS passes: (1) shifted sums -> mean / variance, (2) normalise each 16-byte chunk right
+            // before the 4 MFMAs that consume it.
+            const float *zrow = &Z[role][c][4 * hi];
+            const float *gam = &GB[role][0][4 * hi];
+            const float *bet = &GB[role][1][4 * hi];
+            const float shift = Z[role][c][0];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                const float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
-                const float4 gm = *reinterpret_cast<const float4 *>(gam + 8 * m);
-                const float4 bm = *reinterpret_cast<const float4 *>(bet + 8 * m);
-                const float z0 = fmaxf((v.x - mean) * rstd * gm.x + bm.x, 0.f);
-                const float z1 = fmaxf((v.y - mean) * rstd * gm.y + bm.y, 0.f);
-                const float z2 = fmaxf((v.z - mean) * rstd * gm.z + bm.z, 0.f);
-                const float z3 = fmaxf((v.w - mean) * rstd * gm.w + bm.w, 0.f);
-                acc2 = td_mfma(z0, w2[4 * m + 0], acc2);
-                acc2 = td_mfma(z1, w2[4 * m + 1], acc2);
-                acc2 = td_mfma(z2, w2[4 * m + 2], acc2);
-                acc2 = td_mfma(z3, w2[4 * m + 3], acc2);
+                float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
+                v.x -= shift; v.y -= shift; v.z -= shift; v.w -= shift;
+                s1 += (v.x + v.y) + (v.z + v.w);
+                s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
-        } else {
-            // h2x value MLP: second Linear is 128 -> 16; wave w contracts hidden units [32w, 32w+32) (K split).
+            s1 = td_sum_halves(s1);
+            s2 = td_sum_halves(s2);
+            const float dmean = s1 * (1.0f / TD_H);
+            const float mean = shift + dmean;
+            const float var = fmaxf(s2 * (1.0f / TD_H) - dmean * dmean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            TD_STAMP(1);
+            floatx16 acc2;
+            const float nms = -mean * rstd;                 // z = relu((v*rstd + nms) * gamma + beta)
+            auto norm4 = [&](const float4 &v, const float4 &gm, const float4 &bm) {
+                return make_float4(fmaxf(fmaf(fmaf(v.x, rstd, nms), gm.x, bm.x), 0.f),
+                                   fmaxf(fmaf(fmaf(v.y, rstd, nms), gm.y, bm.y), 0.f),
+                                   fmaxf(fmaf(fmaf(v.z, rstd, nms), gm.z, bm.z), 0.f),
+                                   fmaxf(fmaf(fmaf(v.w, rstd, nms), gm.w, bm.w), 0.f));
+            };
+            if (full2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc2[r] = b2n;
+                // Software pipeline: while the 4 dependent MFMAs of chunk m occupy the matrix pipe (4 x 64
+                // cycles), the VALU normalises chunk m+1 and the LDS returns chunk m+2.
+                float4 zc = norm4(*reinterpret_cast<const float4 *>(zrow), *reinterpret_cast<const float4 *>(gam),
+                                  *reinterpret_cast<const float4 *>(bet));
+                float4 vn = *reinterpret_cast<const float4 *>(zrow + 8);
+                float4 gn = *reinterpret_cast<const float4 *>(gam + 8);
+                float4 bn = *reinterpret_cast<const float4 *>(bet + 8);
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm) {
-                const int m = 4 * w + mm;
-                const float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
-                const float4 gm = *reinterpret_cast<const float4 *>(gam + 8 * m);
-                const float4 bm = *reinterpret_cast<const float4 *>(bet + 8 * m);
-                const float z0 = fmaxf((v.x - mean) * rstd * gm.x + bm.x, 0.f);
-                const float z1 = fmaxf((v.y - mean) * rstd * gm.y + bm.y, 0.f);
-                const float z2 = fmaxf((v.z - mean) * rstd * gm.z + bm.z, 0.f);
-                const float z3 = fmaxf((v.w - mean) * rstd * gm.w + bm.w, 0.f);
-                acc2 = td_mfma(z0, w2[4 * mm + 0], acc2);
-                acc2 = td_mfma(z1, w2[4 * mm + 1], acc2);
-                acc2 = td_mfma(z2, w2[4 * mm + 2], acc2);
-                acc2 = td_mfma(z3, w2[4 * mm + 3], acc2);
+                for (int m = 0; m < 16; ++m) {
+                    float4 zn = zc;
+                    if (m + 1 < 16) zn = norm4(vn, gn, bn);
+                    if (m + 2 < 16) {
+                        vn = *reinterpret_cast<const float4 *>(zrow + 8 * (m + 2));
+                        gn = *reinterpret_cast<const float4 *>(gam + 8 * (m + 2));
+                        bn = *reinterpret_cast<const float4 *>(bet + 8 * (m + 2));
+                    }
+                    acc2 = td_mfma(zc.x, w2[4 * m + 0], acc2);
+                    acc2 = td_mfma(zc.y, w2[4 * m + 1], acc2);
+                    acc2 = td_mfma(zc.z, w2[4 * m + 2], acc2);
+                    acc2 = td_mfma(zc.w, w2[4 * m + 3], acc2);
+                    zc = zn;
+                    // issue order hint: MFMA | 3 VALU + 1 LDS read | MFMA | ...   (masks: 0x8 MFMA, 0x2 VALU, 0x100 DS read)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            } else {
+                // h2x value MLP: second Linear is 128 -> 16; wave w contracts hidden units [32w, 32w+32) (K split).
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    const int m = 4 * w + mm;
+                    const float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
+                    const float4 gm = *reinterpret_cast<const float4 *>(gam + 8 * m);
+                    const float4 bm = *reinterpret_cast<const float4 *>(bet + 8 * m);
+                    const float4 z = norm4(v, gm, bm);
+                    acc2 = td_mfma(z.x, w2[4 * mm + 0], acc2);
+                    acc2 = td_mfma(z.y, w2[4 * mm + 1], acc2);
+                    acc2 = td_mfma(z.z, w2[4 * mm + 2], acc2);
+                    acc2 = td_mfma(z.w, w2[4 * mm + 3], acc2);
+                }
             }
-            if (c < 16) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) XVP[w][td_erow(r, hi)][c] = acc2[r];
-            }
-        }
 
-        if (role == 0) {
-            // ---- attention logits + segment softmax over the 32 in-edges (scatter_softmax) ---------------
-            const float qn = a.q[(size_t)i * TD_H + n];
-            const float ewl = a.ew[i * TD_K + c];
-            float lg[16];
-            float mx = -INFINITY;
+            TD_STAMP(2);
+            if (role == 0) {
+                // ---- attention logits + segment softmax over the 32 in-edges (scatter_softmax) -----------
+                const float qn = a.q[(size_t)ci * TD_H + n];
+                float4 ewq[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                lg[r] = td_sum8(acc2[r] * qn) * TD_ATT_SCALE;
-                if (jr[r] < 0) lg[r] = -INFINITY;
-                mx = fmaxf(mx, lg[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (mx == -INFINITY) mx = 0.f;
-            float sm = 0.f;
+                for (int qd = 0; qd < 4; ++qd)
+                    ewq[qd] = *reinterpret_cast<const float4 *>(a.ew + ci * TD_K + 8 * qd + 4 * hi);
+                float lg[16];
+                float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                lg[r] = jr[r] >= 0 ? expf(lg[r] - mx) : 0.f;
-                sm += lg[r];
-            }
-            sm += __shfl_xor(sm, 32);
-            const float inv = sm > 0.f ? 1.0f / sm : 0.f;
-            const int head = 4 * w + (c >> 3);
+                for (int r = 0; r < 16; ++r) {
+                    lg[r] = ((cvalid >> r) & 1u) ? td_sum8(acc2[r] * qn) * TD_ATT_SCALE : -INFINITY;
+                    mx = fmaxf(mx, lg[r]);
+                }
+                mx = td_max_halves(mx);
+                if (mx == -INFINITY) mx = 0.f;
+                float sm = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ewr = __shfl(ewl, td_erow(r, hi));
-                if ((c & 7) == 0) ALPHA[buf][head][td_erow(r, hi)] = lg[r] * inv * ewr;
-            }
-        }
-        __syncthreads();                                                            // B3: ALPHA ready, Z free
-
-        if (role == 1) {
-            if (!H2X) {
-                // ---- out_i = sum_e alpha_e * e_w * v_e ; h_i += out_i (scatter_sum + residual, :77-83) ------
+                for (int r = 0; r < 16; ++r) {
+                    lg[r] = ((cvalid >> r) & 1u) ? __expf(lg[r] - mx) : 0.f;
+                    sm += lg[r];
+                }
+                sm = td_sum_halves(sm);
+                const float inv = sm > 0.f ? 1.0f / sm : 0.f;
+                const int head = 4 * w + (c >> 3);
+                if ((c & 7) == 0) {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const float4 e4 = ewq[qd];
+                        *reinterpret_cast<float4 *>(&ALPHA[buf][head][8 * qd + 4 * hi]) =
+                            make_float4(lg[4 * qd] * inv * e4.x, lg[4 * qd + 1] * inv * e4.y, lg[4 * qd + 2] * inv * e4.z,
+                                        lg[4 * qd + 3] * inv * e4.w);
+                    }
+                }
+            } else if (!H2X) {
+                // ---- out_i = sum_e alpha_e * e_w * v_e ; h_i += out_i (scatter_sum + residual, :77-83) -----
+                // alpha(t) was published by the k role one segment ago.
                 const float *al = &ALPHA[buf][4 * w + (c >> 3)][4 * hi];
                 float out = 0.f;
 #pragma unroll
@@ -335,25 +411,40 @@ __global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
                     out += av.z * acc2[4 * qd + 2];
                     out += av.w * acc2[4 * qd + 3];
                 }
-                out += __shfl_xor(out, 32);
-                if (hi == 0) a.h[(size_t)i * TD_H + n] += out;
-            } else if (w == 0) {
-                // ---- delta_x_i = mean_heads sum_e alpha_e e_w xv_e (x_i - x_j)   (:131-140) ------------------
-                float sacc = 0.f;
+                out = td_sum_halves(out);
+                if (hi == 0) a.h[(size_t)ci * TD_H + n] = hres + out;
+            } else {
+                if (c < 16) {
 #pragma unroll
-                for (int hh = 0; hh < 8; ++hh) {
-                    const int hd = 8 * hi + hh;
-                    const float xv = ((XVP[0][c][hd] + XVP[1][c][hd]) + (XVP[2][c][hd] + XVP[3][c][hd])) + a.mv.b2[hd];
-                    sacc += ALPHA[buf][hd][c] * xv;
+                    for (int r = 0; r < 16; ++r) XVP[w][td_erow(r, hi)][c] = acc2[r];
                 }
-                const float dxs = td_sum64(sacc * relx) * (1.0f / TD_HEADS);
-                const float dys = td_sum64(sacc * rely) * (1.0f / TD_HEADS);
-                const float dzs = td_sum64(sacc * relz) * (1.0f / TD_HEADS);
-                if (lane == 0) a.x4_out[i] = make_float4(xi.x + dxs, xi.y + dys, xi.z + dzs, xi.w);
             }
+        }
+        TD_STAMP(4);
+        __syncthreads();
+        TD_STAMP(5);
+        if (H2X && role == 1 && w == 0 && !first_phase && t >= 0 && t < cnt) {
+            // partial xv of node t are complete after the barrier; alpha(t) is in ALPHA[t & 1] (the k role
+            // writes the other parity during the next segment).  This wave still holds node t's geometry.
+            const int buf = t & 1;
+            float sacc = 0.f;
+#pragma unroll
+            for (int hh = 0; hh < 8; ++hh) {
+                const int hd = 8 * hi + hh;
+                const float xv = ((XVP[0][c][hd] + XVP[1][c][hd]) + (XVP[2][c][hd] + XVP[3][c][hd])) + a.mv.b2[hd];
+                sacc += ALPHA[buf][hd][c] * xv;
+            }
+            const float dxs = td_sum64(sacc * crx) * (1.0f / TD_HEADS);
+            const float dys = td_sum64(sacc * cry) * (1.0f / TD_HEADS);
+            const float dzs = td_sum64(sacc * crz) * (1.0f / TD_HEADS);
+            if (lane == 0) a.x4_out[ci] = make_float4(cxi.x + dxs, cxi.y + dys, cxi.z + dzs, cxi.w);
         }
     }
 }
+
+static long long *g_timing_buf = nullptr;
+static int g_timing_segs = 0;
+void td_set_edge_timing(long long *buf, int segs) { g_timing_buf = buf; g_timing_segs = segs; }
 
 static int edge_grid(int64_t count) {
     int64_t g = count < 256 ? count : 256;
@@ -367,7 +458,9 @@ int td_launch_x2h(const TdLayer &L, const float4 *x4, const int32_t *nbr, const 
     EdgeArgs a;
     a.x4 = x4; a.x4_out = nullptr; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = nullptr; a.h = h;
     a.count = N; a.mk = L.hk; a.mv = L.hv; a.offsets = L.offsets; a.coeff = L.coeff;
-    edge_attn_kernel<false><<<dim3(edge_grid(N)), dim3(512), 0, s>>>(a);
+    a.dbg = g_timing_buf; a.dbg_segs = g_timing_segs;
+    if (g_timing_buf) edge_attn_kernel<false, true><<<dim3(edge_grid(N)), dim3(512), 0, s>>>(a);
+    else edge_attn_kernel<false, false><<<dim3(edge_grid(N)), dim3(512), 0, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -378,7 +471,8 @@ int td_launch_h2x(const TdLayer &L, const float4 *x4_in, float4 *x4_out, const i
     EdgeArgs a;
     a.x4 = x4_in; a.x4_out = x4_out; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = lig_node; a.h = nullptr;
     a.count = Nl; a.mk = L.xk; a.mv = L.xv; a.offsets = L.offsets; a.coeff = L.coeff;
-    edge_attn_kernel<true><<<dim3(edge_grid(Nl)), dim3(512), 0, s>>>(a);
+    a.dbg = nullptr; a.dbg_segs = 0;
+    edge_attn_kernel<true, false><<<dim3(edge_grid(Nl)), dim3(512), 0, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -219,3 +219,20 @@ int td_launch_center(float *ppos, const int32_t *pptr, float *lpos, const int32_
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
+
+// ------------------------------------------------------------------------------------------ test hook
+__global__ void reductions_kernel(const float *__restrict__ in, float *__restrict__ out) {
+    const int l = threadIdx.x;
+    const float v = in[l];
+    out[0 * 64 + l] = td_sum8(v);
+    out[1 * 64 + l] = td_sum32(v);
+    out[2 * 64 + l] = td_sum64(v);
+    out[3 * 64 + l] = td_sum_halves(v);
+    out[4 * 64 + l] = td_max_halves(v);
+    out[5 * 64 + l] = td_swap32(v);
+}
+int td_launch_reductions(const float *in, float *out, hipStream_t s) {
+    reductions_kernel<<<dim3(1), dim3(64), 0, s>>>(in, out);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

@@ -20,28 +20,64 @@ __device__ __forceinline__ floatx16 td_mfma(float a, float b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- cross-lane reductions without LDS round trips (DPP modifiers + gfx950 v_permlane32_swap) -------------
+template <int CTRL>
+__device__ __forceinline__ float td_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141; // lane i <-> 7 - i inside each group of 8
+constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <-> 15 - i inside each row of 16
+constexpr int DPP_ROW_ROR8 = 0x128;        // rotate right by 8 inside each row of 16
+
 // Sum over the 8 consecutive lanes of a head group (lanes 8g .. 8g+7), result in every lane of the group.
 __device__ __forceinline__ float td_sum8(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+    v += td_dpp<DPP_QUAD_XOR1>(v);
+    v += td_dpp<DPP_QUAD_XOR2>(v);
+    v += td_dpp<DPP_ROW_HALF_MIRROR>(v);
     return v;
+}
+
+// v_permlane32_swap: lanes 32-63 of the first operand trade places with lanes 0-31 of the second.  Fed with two
+// copies of v it yields lo = [v_lo, v_lo] and hi = [v_hi, v_hi] in one instruction.
+// Inline asm on purpose: clang (ROCm 7.2) lowers BOTH elements of __builtin_amdgcn_permlane32_swap's result to
+// extractvalue 0, i.e. r[1] silently aliases r[0].  The leading s_nop 1 covers the "VALU write -> permlane read"
+// hazard (2 wait states), which the compiler does not pad inside an asm statement.
+__device__ __forceinline__ void td_split_halves(float v, float &lo, float &hi) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+// other half-wave's value (lane l <-> l ^ 32)
+__device__ __forceinline__ float td_swap32(float v) {
+    float lo, hi;
+    td_split_halves(v, lo, hi);
+    return (threadIdx.x & 32) ? lo : hi;
+}
+__device__ __forceinline__ float td_sum_halves(float v) {
+    float lo, hi;
+    td_split_halves(v, lo, hi);
+    return lo + hi;
+}
+__device__ __forceinline__ float td_max_halves(float v) {
+    float lo, hi;
+    td_split_halves(v, lo, hi);
+    return fmaxf(lo, hi);
 }
 
 // Sum over the 32 lanes of a half-wave (lanes with equal l >> 5), result in every lane of the half.
 __device__ __forceinline__ float td_sum32(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
+    v = td_sum8(v);
+    v += td_dpp<DPP_ROW_ROR8>(v);          // the two groups of 8 inside a row of 16
+    v += __shfl_xor(v, 16);                // the two rows of a half-wave
     return v;
 }
 
 __device__ __forceinline__ float td_sum64(float v) {
     v = td_sum32(v);
-    v += __shfl_xor(v, 32);
-    return v;
+    return td_sum_halves(v);
 }
 
 // distance^2 with the project's fixed association and no FMA contraction (oracle/shims.py)

@@ -113,6 +113,7 @@ int td_launch_x2h(const TdLayer &L, const float4 *x4, const int32_t *nbr, const 
                   const float *q, int64_t N, float *h, hipStream_t s);
 int td_launch_h2x(const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr, const float *ew,
                   const float *P, const float *q, const int32_t *lig_node, int64_t Nl, hipStream_t s);
+void td_set_edge_timing(long long *buf, int segs);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);
@@ -122,3 +123,4 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
                         int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
 int td_launch_center(float *ppos, const int32_t *pptr, float *lpos, const int32_t *lptr, int64_t B, float *offset,
                      int compute, int sign, hipStream_t s);
+int td_launch_reductions(const float *in, float *out, hipStream_t s);

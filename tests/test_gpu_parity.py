@@ -51,6 +51,29 @@ def _native_with_layers(state_dict, num_layers, dev):
         return capi.NativeModel(cfg, state_dict, sched, device=dev)
 
 
+# ------------------------------------------------------------------------------------------ device helpers
+def test_cross_lane_reductions():
+    """DPP / permlane32 reduction helpers used by the softmax and LayerNorm code paths (integer-valued inputs:
+    every partial sum is exact in fp32, so the comparison is bit exact)."""
+    from ctypes import c_void_p
+    from targetdiff_amd import capi
+    dev = _dev()
+    lib = capi.load_library()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(-1000, 1000, (64,), generator=g).float()
+    out = torch.empty(6, 64, device=dev)
+    xd = x.to(dev)
+    rc = lib.td_debug_reductions(c_void_p(xd.data_ptr()), c_void_p(out.data_ptr()), c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    out = out.cpu()
+    assert torch.equal(out[0], x.view(8, 8).sum(1, keepdim=True).expand(8, 8).reshape(64))
+    assert torch.equal(out[1], x.view(2, 32).sum(1, keepdim=True).expand(2, 32).reshape(64))
+    assert torch.equal(out[2], x.sum().expand(64))
+    assert torch.equal(out[3], (x[:32] + x[32:]).repeat(2))
+    assert torch.equal(out[4], torch.maximum(x[:32], x[32:]).repeat(2))
+    assert torch.equal(out[5], torch.cat([x[32:], x[:32]]))
+
+
 # ------------------------------------------------------------------------------------------ graph ops
 def test_graph_ptr(model):
     dev = _dev()
