@@ -13,9 +13,10 @@ rank per GPU over RCCL) every rank samples its own pocket replica -- pockets sha
 collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = edge_attn_kernel<x2h>; achieved = algorithmic FLOPs per launch
-               (2.441216 MFLOP per dst node) / mean launch time from HIP events recorded on
-               the launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, dense).
+  roofline     dominant kernel = edge_mlp_kernel<0> (x2h key pass; the value pass <1> is its twin);
+               achieved = algorithmic FLOPs per launch (1.220608 MFLOP per dst node) / mean launch
+               time from HIP events recorded on the launch stream inside the timed region;
+               peak = 157.3 TFLOP/s (fp32 MFMA, dense).
   cpu_baseline the oracle restatement (torch CPU, same weights) timed on this host's cores over a bounded
                sample of the same workload (the same pocket, fewer samples, a few steps).
 """
@@ -37,7 +38,9 @@ from targetdiff_amd import capi, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
-X2H_FLOP_PER_NODE = 2 * (2 * 32 * 128 * 20 + 2 * 32 * 128 * 128 + 2 * 32 * 128)   # = 2,441,216
+# one pass (key OR value MLP) of edge_mlp_kernel over one dst node: 32 edges x 128 hidden x (20 radial + 128 second
+# layer + 1 attention) MACs
+EDGE_PASS_FLOP_PER_NODE = 2 * (32 * 128 * 20 + 32 * 128 * 128 + 32 * 128)   # = 1,220,608
 METRIC = 'ligands/sec (1000-step sampling, 100 samples/pocket) at 1/2/4/8 MI355X'
 
 # configs/training.yml:9-42
@@ -160,7 +163,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h',)
+    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k',)
     fence()
     capi.profile_begin(classes)
     t0 = time.perf_counter()
@@ -177,9 +180,9 @@ def main():
     graphs = len(pockets) * spp
     value = world * graphs / (1000.0 * sec_per_step)
 
-    x2h = prof['x2h']
+    x2h = prof['x2h_k']
     x2h_ms = x2h['ms'] / max(1, x2h['launches'])
-    achieved = X2H_FLOP_PER_NODE * n_nodes / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
+    achieved = EDGE_PASS_FLOP_PER_NODE * n_nodes / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
     out = {
         'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -187,7 +190,7 @@ def main():
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
         'config': {'workload': desc, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
-        'roofline': {'bound': 'mfma', 'kernel': 'edge_attn_kernel<x2h>', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'edge_mlp_kernel<0> (x2h key pass)', 'achieved': achieved,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': None,
                      'launch_ms': x2h_ms, 'launches': x2h['launches'],

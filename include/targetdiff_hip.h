@@ -127,8 +127,9 @@ int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_l
 /* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
  *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;
  *      td_profile_end synchronises the device and returns per-class summed milliseconds and launch counts.
- *      Classes: 0 knn, 1 edge gate, 2 node projections, 3 x2h, 4 h2x, 5 compose, 6 head, 7 posterior. */
-#define TD_PROFILE_CLASSES 8
+ *      Classes: 0 knn, 1 edge gate, 2 node projections, 3 x2h key pass, 4 x2h value pass, 5 h2x key pass,
+ *      6 h2x value pass, 7 compose, 8 head, 9 posterior. */
+#define TD_PROFILE_CLASSES 10
 int td_profile_begin(uint32_t class_mask);
 int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
 
@@ -138,9 +139,9 @@ int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
 int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N, float *d_P,
                         float *d_q, void *stream);
 
-/* ---- test hook: while d_buf != NULL, x2h launches run an instrumented variant in which lane 0 of every wave of
- *      workgroup 0 stores clock64() stamps: d_buf[(wave * segs + segment) * 8 + stamp] (int64). */
-int td_debug_edge_timing(int64_t *d_buf, int32_t segs);
+/* ---- test hook: while d_buf != NULL, x2h key-pass launches run an instrumented variant in which lane 0 of every wave
+ *      of workgroup 0 stores clock64() stamps: d_buf[(wave * nodes + node_no) * 8 + stamp] (int64). */
+int td_debug_edge_timing(int64_t *d_buf, int32_t nodes);
 
 /* ---- test hook: one wave evaluates the cross-lane reduction helpers on 64 inputs; out[6][64] =
  *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */

@@ -47,13 +47,13 @@ SIGNATURES = {
     'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
-    'td_debug_edge_timing': (c_int32, [_P, c_int32]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
+    'td_debug_edge_timing': (c_int32, [_P, c_int32]),
     'td_profile_begin': (c_int32, [ctypes.c_uint32]),
     'td_profile_end': (c_int32, [POINTER(c_float), POINTER(c_int32), c_int32]),
 }
 
-PROFILE_CLASSES = ('knn', 'gate', 'node_proj', 'x2h', 'h2x', 'compose', 'head', 'posterior')
+PROFILE_CLASSES = ('knn', 'gate', 'node_proj', 'x2h_k', 'x2h_v', 'h2x_k', 'h2x_v', 'compose', 'head', 'posterior')
 
 
 def profile_begin(classes=PROFILE_CLASSES):

@@ -26,7 +26,7 @@ extern "C" int td_abi_version(void) { return TD_ABI_VERSION; }
 // Optional per-kernel-class HIP-event timers (bench.py's roofline leg): events are recorded on the launch
 // stream around the selected classes; td_profile_end synchronises and sums hipEventElapsedTime.
 namespace {
-enum { PC_KNN = 0, PC_GATE, PC_NODE, PC_X2H, PC_H2X, PC_COMPOSE, PC_HEAD, PC_POST, PC_COUNT };
+enum { PC_KNN = 0, PC_GATE, PC_NODE, PC_X2H_K, PC_X2H_V, PC_H2X_K, PC_H2X_V, PC_COMPOSE, PC_HEAD, PC_POST, PC_COUNT };
 struct Profiler {
     unsigned mask = 0;
     std::vector<hipEvent_t> ev[PC_COUNT];     // start/stop pairs
@@ -145,44 +145,36 @@ struct EdgeOff { size_t R, gamma, beta, W2, b2; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim) {
     EdgeOff o;
-    // first layer radial / type table: [cls][wave][slot][kstep][lane]
-    o.R = pk.alloc((size_t)2 * 4 * 2 * TD_SLOT_STEPS * 64);
+    // first layer radial / type table: [cls][slot][kstep][lane][ntile]
+    o.R = pk.alloc((size_t)2 * 2 * TD_SLOT_STEPS * 64 * 4);
     float *d = pk.data.data() + o.R;
     for (int cls = 0; cls < 2; ++cls)
-        for (int w = 0; w < 4; ++w)
-            for (int sl = 0; sl < 2; ++sl) {
-                // edge type (models/uni_transformer.py:292-297): 0 l<-l, 1 src lig/dst prot, 2 src prot/dst lig, 3 p<-p
-                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
-                for (int s = 0; s < TD_SLOT_STEPS; ++s)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int kk = td_kmap(s, lane >> 5), n = 32 * w + (lane & 31);
+        for (int sl = 0; sl < 2; ++sl) {
+            // edge type (models/uni_transformer.py:292-297): 0 l<-l, 1 src lig/dst prot, 2 src prot/dst lig, 3 p<-p
+            const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+            for (int s = 0; s < TD_SLOT_STEPS; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int kk = td_kmap(s, lane >> 5), n = 32 * t + (lane & 31);
                         float v = 0.f;
                         if (kk < TD_NG) v = m.w0[(size_t)n * in_dim + 4 + TD_NG * type + kk];   // r_feat, type-major
                         else if (kk == TD_NG) v = m.w0[(size_t)n * in_dim + type];              // one-hot edge type column
-                        d[((((size_t)cls * 4 + w) * 2 + sl) * TD_SLOT_STEPS + s) * 64 + lane] = v;
+                        d[((((size_t)cls * 2 + sl) * TD_SLOT_STEPS + s) * 64 + lane) * 4 + t] = v;
                     }
-            }
+        }
     o.gamma = pack_vec(pk, m.g, TD_H);
     o.beta = pack_vec(pk, m.b, TD_H);
     if (out_dim == TD_H) {
-        o.W2 = pk.alloc((size_t)4 * TD_KSTEPS * 64);
-        float *q = pk.data.data() + o.W2;
-        for (int w = 0; w < 4; ++w)
-            for (int s = 0; s < TD_KSTEPS; ++s)
-                for (int lane = 0; lane < 64; ++lane)
-                    q[((size_t)w * TD_KSTEPS + s) * 64 + lane] =
-                        m.w3[(size_t)(32 * w + (lane & 31)) * TD_H + td_kmap(s, lane >> 5)];
+        o.W2 = pack_B128(pk, m.w3, TD_H, 0);
         o.b2 = pack_vec(pk, m.b3, TD_H);
-    } else {   // xv: [16][128] -> K-split over 4 waves, N padded 16 -> 32
-        o.W2 = pk.alloc((size_t)4 * 16 * 64);
+    } else {   // xv: [16][128] -> one N tile padded 16 -> 32 columns
+        o.W2 = pk.alloc((size_t)TD_KSTEPS * 64);
         float *q = pk.data.data() + o.W2;
-        for (int w = 0; w < 4; ++w)
-            for (int s = 0; s < 16; ++s)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int cc = lane & 31;
-                    q[((size_t)w * 16 + s) * 64 + lane] =
-                        cc < out_dim ? m.w3[(size_t)cc * TD_H + td_kmap(16 * w + s, lane >> 5)] : 0.f;
-                }
+        for (int s = 0; s < TD_KSTEPS; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int cc = lane & 31;
+                q[(size_t)s * 64 + lane] = cc < out_dim ? m.w3[(size_t)cc * TD_H + td_kmap(s, lane >> 5)] : 0.f;
+            }
         o.b2 = pack_vec(pk, m.b3, out_dim, TD_HEADS);
     }
     return o;
@@ -354,7 +346,7 @@ namespace {
 struct Workspace {
     float4 *x4a, *x4b;
     int32_t *gid, *nbr, *lig_node, *node_ptr;
-    float *ew, *P, *q, *h;
+    float *ew, *P, *q, *h, *alpha;
     size_t bytes;
 };
 
@@ -373,6 +365,7 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     w.P = reinterpret_cast<float *>(take(n * 4 * TD_H * sizeof(float)));
     w.q = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
     w.h = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
+    w.alpha = reinterpret_cast<float *>(take(n * TD_HEADS * TD_K * sizeof(float)));
     w.bytes = off;
     return w;
 }
@@ -389,11 +382,12 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     for (int l = 0; l < m->cfg.num_layers; ++l) {
         const TdLayer &L = m->layers[l];
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H, s); if ((rc = td_launch_x2h(L, xc, w.nbr, w.ew, w.P, w.q, N, h, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
         if (!fix_x && Nl > 0) {
             { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc; }
-            ProfScope ps(PC_H2X, s);
-            if ((rc = td_launch_h2x(L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, s)) != TD_OK) return rc;
+            { ProfScope ps(PC_H2X_K, s); if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_H2X_V, s); if ((rc = td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc; }
             float4 *t = xc; xc = xn; xn = t;
         }
     }
@@ -545,11 +539,11 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
     return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, d_P, d_q, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int td_debug_edge_timing(int64_t *d_buf, int32_t segs) {
-    td_set_edge_timing(reinterpret_cast<long long *>(d_buf), segs);
-    return TD_OK;
-}
-
 extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream) {
     return td_launch_reductions(d_in64, d_out6x64, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_debug_edge_timing(int64_t *d_buf, int32_t nodes) {
+    td_set_edge_timing(reinterpret_cast<long long *>(d_buf), nodes);
+    return TD_OK;
 }

@@ -4,28 +4,31 @@
 //   * edge_attn_kernel  -- x2h  (BaseX2HAttLayer.forward, models/uni_transformer.py:42-84) and
 //                          h2x  (BaseH2XAttLayer.forward, :108-140 + the masked update :205-206)
 //
-// Structure of edge_attn_kernel.  The kNN graph gives every node exactly 32 in-edges, stored as a dense
-// row nbr[i][0..31]; scatter_softmax / scatter_sum over dst (torch_scatter, :73,78,135,139) are therefore
-// fixed-length segment reductions over ONE 32-row MFMA tile -- no atomics, no edge lists.
-// One workgroup (8 waves) walks a contiguous range of dst nodes.  Per node:
-//   waves 0-3 ("k role") evaluate the key MLP, waves 4-7 ("v role") the value MLP.  Wave w of a role owns
-//   hidden/output columns [32w, 32w+32): its 128x32 slice of the second Linear lives in 64 VGPRs for the
-//   whole kernel (weight-stationary), the first Linear's radial/type table for the current dst class in
-//   24 more.
+// Structure of edge_mlp_kernel (one wavefront per dst node, no inter-wave communication).
+// The kNN graph gives every node exactly 32 in-edges, stored as a dense row nbr[i][0..31]; scatter_softmax /
+// scatter_sum over dst (torch_scatter, :73,78,135,139) are therefore fixed-length segment reductions over ONE
+// 32-row MFMA tile -- no atomics, no edge lists.  A workgroup (8 waves) stages the MLP's second Linear
+// (64 KiB of B fragments) and the first Linear's radial/type tables (48 KiB) in LDS once, then every wave walks
+// its own dst nodes.  Per node and MLP:
 //   (1) first layer:   pre[e][n] = P_i[n] + P_j[j_e][n] + sum_m R[type_e][m][n] g_m(d_e)
-//       = node projections (node.hip) gathered per edge + a 32x(24|48)x32 MFMA whose A operand
-//       (Gaussians of the edge length, masked by the edge's source class) is built in registers.
-//   (2) pre -> LDS (C layout -> row-major), barrier, each lane re-reads HALF A ROW (16 x ds_read_b128),
-//       LayerNorm + ReLU in registers (row statistics need one cross-half shuffle),
-//   (3) second layer:  64 MFMAs against the stationary W2 slice,
-//   (4) k role: logits = <q_i, k_e> per head (8-lane reductions), softmax over the 32 rows, times e_w,
-//       -> LDS;  barrier;  v role: out = sum_e alpha_e v_e, residual add, store h (x2h) /
+//       = node projections (node.hip) gathered straight into the MFMA accumulators (C layout: lane = column,
+//       register = row) + a 32 x (24|48) x 128 MFMA whose A operand (Gaussians of the edge length, masked by the
+//       edge's source class) is built in registers,
+//   (2) LayerNorm + ReLU in C layout (row statistics: DPP reductions over the 32 lanes of a half wave),
+//   (3) C -> A layout through a wave-private 4.5 KiB LDS tile, one 32-column tile at a time,
+//   (4) second layer:  64 k-steps x 4 N-tiles of MFMA, B fragments streamed from LDS (one ds_read_b128 per
+//       4 MFMAs; 4 independent accumulator chains keep the matrix pipe issue-bound),
+//   (5) epilogue.  Key MLP: logits = <q_i, k_e> per head (8-lane DPP sums), softmax over the 32 rows, times the
+//       edge gate -> alpha[N][16][32].  Value MLP: out = sum_e alpha_e v_e, residual add (x2h) /
 //       delta_x = mean_heads sum_e alpha_e v_e rel_e (h2x).
-// Two barriers per node; alpha is double buffered so the v role of node t overlaps the k role of t+1.
+// Key and value MLPs run as separate launches (their weights would not fit LDS together); alpha (2 KiB per
+// node) crosses through L2.  Compared with an N-split over waves this does every per-edge VALU operation
+// (geometry, LayerNorm, softmax) exactly once instead of 4-8 times and needs no barriers.
+#include <cstdlib>
+
 #include "td_device.h"
 #include "td_internal.h"
 
-constexpr int ZS = 132;                  // LDS row stride of the pre-activation tile (128 + 4)
 constexpr float TD_ATT_SCALE = 0.35355339059327373f;   // 1/sqrt(8)   (models/uni_transformer.py:73,135)
 
 // ------------------------------------------------------------------------------------------ edge gate
@@ -108,274 +111,235 @@ int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_
 }
 
 // ------------------------------------------------------------------------------------------ x2h / h2x
+enum { MODE_X2H_K = 0, MODE_X2H_V = 1, MODE_H2X_K = 2, MODE_H2X_V = 3 };
+
 struct EdgeArgs {
     const float4 *x4;        // [N] (x, y, z, is_ligand)
-    float4 *x4_out;          // h2x: updated coordinates (ligand rows only are written)
+    float4 *x4_out;          // h2x value pass: updated coordinates (ligand rows only are written)
     const int32_t *nbr;      // [N][32]
     const float *ew;         // [N][32] global edge gate
     const float *P;          // [N][512] node projections of this stage
     const float *q;          // [N][128] query vectors of this stage
     const int32_t *lig_node; // h2x: list of dst nodes
-    float *h;                // x2h: updated in place
+    float *h;                // x2h value pass: updated in place
+    float *alpha;            // [N][16 heads][32 edges]: softmax weight * edge gate (key pass writes, value pass reads)
     int64_t count;           // number of dst nodes to process
-    TdEdgeMlp mk, mv;
+    TdEdgeMlp mlp;
     const float *offsets;
     float coeff;
-    long long *dbg;          // TIMING variant: [8 waves][dbg_segs][8 stamps] cycle counters of workgroup 0
-    int dbg_segs;
+    int stagger_sleeps;      // initial delay of waves 4-7 in units of s_sleep(127) (~8k cycles)
+    long long *dbg;          // TIMING variant: [8 waves][dbg_nodes][8] cycle stamps of workgroup 0
+    int dbg_nodes;
 };
 
-// Raw geometry loads of one dst node, issued one pipeline stage ahead of their use.
-struct GeoRaw {
-    int64_t i;
-    int j;
-    float4 xi, xj;
-    int4 jq[4];      // neighbour ids of this lane's 16 C-layout rows: rows 8q+4hi .. 8q+4hi+3
-};
+constexpr int TB_STRIDE = 36;                                   // 32 + 4: conflict-free b128 reads of a 32-column tile
+constexpr int LDS_W2_FLOATS = TD_KSTEPS * 64 * 4;               // 16384
+constexpr int LDS_R_FLOATS = 2 * 2 * TD_SLOT_STEPS * 64 * 4;    // 12288
+constexpr int LDS_TB_FLOATS = 8 * 32 * TB_STRIDE;               // 9216
+constexpr size_t EDGE_LDS_BYTES = (size_t)(LDS_W2_FLOATS + LDS_R_FLOATS + LDS_TB_FLOATS + 8 * 32 * 4) * sizeof(float);
 
-#define TD_STAMP(k)                                                                                   \
-    do {                                                                                              \
-        if (TIMING && blockIdx.x == 0 && lane == 0 && seg < a.dbg_segs)                               \
-            a.dbg[((size_t)wid * a.dbg_segs + seg) * 8 + (k)] = clock64();                            \
+#define TD_STAMP(k)                                                                                    \
+    do {                                                                                               \
+        if (TIMING && blockIdx.x == 0 && lane == 0 && nodeno < a.dbg_nodes)                            \
+            a.dbg[((size_t)wid * a.dbg_nodes + nodeno) * 8 + (k)] = clock64();                         \
     } while (0)
 
-template <bool H2X, bool TIMING>
-__global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) float Z[2][32][ZS];         // [role][edge][hidden]
-    __shared__ __attribute__((aligned(16))) float ALPHA[2][TD_HEADS][32];  // [node parity][head][edge]  alpha * e_w
-    __shared__ __attribute__((aligned(16))) float GB[2][2][TD_H];       // [role][gamma|beta][hidden]
-    __shared__ __attribute__((aligned(16))) float XVP[4][32][16];       // h2x: per-wave partial xv
+template <int MODE, bool TIMING>
+__global__ __launch_bounds__(512) void edge_mlp_kernel(EdgeArgs a) {
+    constexpr bool IS_K = MODE == MODE_X2H_K || MODE == MODE_H2X_K;
+    constexpr bool IS_H2X = MODE == MODE_H2X_K || MODE == MODE_H2X_V;
+    constexpr bool NARROW = MODE == MODE_H2X_V;                 // second Linear 128 -> 16: one (half-empty) N tile
+    constexpr int NT2 = NARROW ? 1 : 4;                         // N tiles of the second layer
+    constexpr int POFF = IS_K ? 0 : 2 * TD_H;                   // column offset of this MLP inside P: [k_i k_j v_i v_j]
 
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4 *W2s = reinterpret_cast<float4 *>(lds);                                   // [64 kstep][64 lane] x 4 tiles
+    float *W2n = lds;                                                                // NARROW: [64 kstep][64 lane]
+    const float4 *Rs = reinterpret_cast<const float4 *>(lds + LDS_W2_FLOATS);        // [cls][slot][12][64] x 4 tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int role = wid >> 2, w = wid & 3;
     const int c = lane & 31, hi = lane >> 5;
-    const int n = 32 * w + c;
-    const TdEdgeMlp mlp = role ? a.mv : a.mk;
-    const bool full2 = !H2X || role == 0;       // second Linear with 128 outputs (N-split) vs xv's 16 (K-split)
+    float *TB = lds + LDS_W2_FLOATS + LDS_R_FLOATS + wid * 32 * TB_STRIDE;            // wave-private transpose tile
+    float *RELB = lds + LDS_W2_FLOATS + LDS_R_FLOATS + LDS_TB_FLOATS + wid * 32 * 4; // wave-private rel_x (h2x value)
 
-    // ---- prologue: stationary weights ---------------------------------------------------------------
-    float w2[TD_KSTEPS];
-    if (full2) {
-#pragma unroll
-        for (int s = 0; s < TD_KSTEPS; ++s) w2[s] = mlp.W2[(size_t)(w * TD_KSTEPS + s) * 64 + lane];
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) w2[s] = mlp.W2[(size_t)(w * 16 + s) * 64 + lane];
-    }
-    const float b2n = full2 ? mlp.b2[n] : 0.f;
+    // ---- stage the weights in LDS (once per workgroup) ---------------------------------------------------------
     {
-        const int t = tid & 255;
-        if (t < TD_H) GB[role][0][t] = mlp.gamma[t];
-        else GB[role][1][t - TD_H] = mlp.beta[t - TD_H];
+        const float4 *src = reinterpret_cast<const float4 *>(a.mlp.W2);
+        const int n4 = NARROW ? TD_KSTEPS * 64 / 4 : TD_KSTEPS * 64;
+        for (int idx = tid; idx < n4; idx += 512) W2s[idx] = src[idx];
+        const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R);
+        float4 *rdst = reinterpret_cast<float4 *>(lds + LDS_W2_FLOATS);
+        for (int idx = tid; idx < LDS_R_FLOATS / 4; idx += 512) rdst[idx] = rsrc[idx];
     }
+    // per-lane constants: this lane's 4 hidden columns 32t + c
+    float gam[4], bet[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        gam[t] = a.mlp.gamma[32 * t + c];
+        bet[t] = a.mlp.beta[32 * t + c];
+    }
+    float b2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) b2[t] = NARROW ? (c < TD_HEADS ? a.mlp.b2[c] : 0.f) : a.mlp.b2[32 * t + c];
     float offk[TD_SLOT_STEPS];
 #pragma unroll
     for (int s = 0; s < TD_SLOT_STEPS; ++s) {
         const int k = td_kmap(s, hi);
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
-    float rf[2][TD_SLOT_STEPS];
-    int cur_cls = -1;
+    __syncthreads();
 
-    // ---- XCD-aware contiguous node ranges: workgroup b runs on XCD b % 8 -> give XCD x the x-th eighth -----
+    // ---- XCD-aware contiguous node ranges: workgroup b runs on XCD b % 8 -> give XCD x the x-th eighth --------
     const int G = gridDim.x;
     int chunk = blockIdx.x;
     if ((G & 7) == 0) chunk = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     const int64_t per = (a.count + G - 1) / G;
     const int64_t begin = (int64_t)chunk * per;
     const int64_t end = begin + per < a.count ? begin + per : a.count;
-    const int cnt = end > begin ? (int)(end - begin) : 0;
 
-    auto load_geo = [&](int t) {
-        GeoRaw g;
-        g.i = H2X ? (int64_t)a.lig_node[begin + t] : begin + t;
-        g.j = a.nbr[g.i * TD_K + c];
-        g.xi = a.x4[g.i];
-        g.xj = a.x4[g.j >= 0 ? g.j : g.i];
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd)
-            g.jq[qd] = *reinterpret_cast<const int4 *>(a.nbr + g.i * TD_K + 8 * qd + 4 * hi);
-        return g;
-    };
+    // Waves w and w + 4 share a SIMD.  Identical work keeps them in lockstep (both in the 256-MFMA second layer,
+    // then both in VALU phases with the matrix pipe idle); starting the second wave of each pair half a node
+    // period late makes one wave's MFMA burst overlap the other's gather / LayerNorm / softmax.
+    if (a.stagger_sleeps > 0 && wid >= 4)
+        for (int k = 0; k < a.stagger_sleeps; ++k) __builtin_amdgcn_s_sleep(127);
 
-    // state of the node a wave is working on (first layer in one segment, second layer in the next)
-    GeoRaw nxt;
-    if (cnt > 0) nxt = load_geo(0);
-    int64_t ci = 0;            // node id
-    unsigned cvalid = 0;       // bit r: C-layout row r of this lane is a real edge
-    float crx = 0.f, cry = 0.f, crz = 0.f;     // x_i - x_j of edge c   (h2x)
-    float4 cxi = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // ---- software pipeline over segments --------------------------------------------------------------------
-    // The two roles run half a node out of phase so that, on every SIMD, one wave's 64-MFMA second layer
-    // overlaps the other wave's gather / first layer / softmax:
-    //   segment 2t   : k role first(t)            | v role second(t-1) + reduce with alpha(t-1)
-    //   segment 2t+1 : k role second(t) -> alpha  | v role first(t)
-    // One barrier per segment.  Z[role] is written in the role's "first" segment and read in its "second".
-    for (int seg = 0; seg <= 2 * cnt; ++seg) {
-        const bool first_phase = ((seg & 1) == role);
-        const int t = first_phase ? (seg - role) >> 1 : (seg - 1 - role) >> 1;   // node handled in this segment
+    int nodeno = -1;
+    for (int64_t it = begin + wid; it < end; it += 8) {
+        ++nodeno;
         TD_STAMP(0);
-        if (first_phase && t < cnt) {
-            // ================= first layer of node t =======================================================
-            const GeoRaw g = nxt;
-            ci = g.i; cxi = g.xi;
-            const bool valid = g.j >= 0;
-            crx = g.xi.x - g.xj.x; cry = g.xi.y - g.xj.y; crz = g.xi.z - g.xj.z;        // x[dst] - x[src]
-            const float d = sqrtf(crx * crx + cry * cry + crz * crz);
-            const int slot = g.xj.w > 0.5f ? 0 : 1;         // source class: 0 ligand, 1 protein
-            const int cls = g.xi.w > 0.5f ? 0 : 1;          // destination class (wave uniform)
-            const bool has_a = __ballot(valid && slot == 0) != 0ull;
-            const bool has_b = __ballot(valid && slot == 1) != 0ull;
-            if (cls != cur_cls) {
-                cur_cls = cls;
+        const int64_t i = IS_H2X ? (int64_t)a.lig_node[it] : it;
+        // ---- geometry of the 32 in-edges: lane (c, hi) looks at edge c ---------------------------------------------
+        const int j = a.nbr[i * TD_K + c];
+        const bool valid = j >= 0;
+        const float4 xi = a.x4[i];
+        const float4 xj = a.x4[valid ? j : i];
+        const float relx = xi.x - xj.x, rely = xi.y - xj.y, relz = xi.z - xj.z;       // x[dst] - x[src]
+        const float d = sqrtf(relx * relx + rely * rely + relz * relz);
+        const int slot = xj.w > 0.5f ? 0 : 1;          // source class: 0 ligand, 1 protein
+        const int cls = xi.w > 0.5f ? 0 : 1;           // destination class (wave uniform)
+        const bool has_a = __ballot(valid && slot == 0) != 0ull;
+        const bool has_b = __ballot(valid && slot == 1) != 0ull;
+        if (MODE == MODE_H2X_V && hi == 0) *reinterpret_cast<float4 *>(RELB + 4 * c) = make_float4(relx, rely, relz, 0.f);
+
+        // ---- first layer: gather P_j straight into the accumulators (C layout rows 8q + 4hi + rr) ------------------
+        floatx16 acc[4];
+        unsigned vmask = 0;
+        const float *Pj = a.P + POFF + TD_H + c;
 #pragma unroll
-                for (int sl = 0; sl < 2; ++sl)
+        for (int qd = 0; qd < 4; ++qd) {
+            const int4 jv = *reinterpret_cast<const int4 *>(a.nbr + i * TD_K + 8 * qd + 4 * hi);
 #pragma unroll
-                    for (int s = 0; s < TD_SLOT_STEPS; ++s)
-                        rf[sl][s] = mlp.R[(size_t)((((cls * 4 + w) * 2 + sl) * TD_SLOT_STEPS) + s) * 64 + lane];
+            for (int rr = 0; rr < 4; ++rr) {
+                const int jr = rr == 0 ? jv.x : rr == 1 ? jv.y : rr == 2 ? jv.z : jv.w;
+                vmask |= jr >= 0 ? (1u << (4 * qd + rr)) : 0u;
+                const float *row = Pj + (size_t)(jr >= 0 ? jr : (int)i) * (4 * TD_H);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][4 * qd + rr] = row[32 * t];
             }
-            float bj[16];
-            const float *Pj = a.P + role * 256 + TD_H + n;
-            cvalid = 0;
+        }
+        float pi[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int4 jv = g.jq[r >> 2];
-                const int jr = (r & 3) == 0 ? jv.x : (r & 3) == 1 ? jv.y : (r & 3) == 2 ? jv.z : jv.w;
-                cvalid |= jr >= 0 ? (1u << r) : 0u;
-                bj[r] = Pj[(size_t)(jr >= 0 ? jr : (int)g.i) * (4 * TD_H)];
-            }
-            const float pi = a.P[(size_t)g.i * (4 * TD_H) + role * 256 + n];
-            TD_STAMP(1);
-            floatx16 acc;
+        for (int t = 0; t < 4; ++t) pi[t] = a.P[(size_t)i * (4 * TD_H) + POFF + 32 * t + c];
+        TD_STAMP(1);
+        float gv[TD_SLOT_STEPS];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = pi;
-            float gv[TD_SLOT_STEPS];
+        for (int s = 0; s < TD_SLOT_STEPS; ++s) {
+            const int k = td_kmap(s, hi);
+            const float u = d - offk[s];
+            gv[s] = k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
+        }
+        if (has_a) {
+            const bool on = valid && slot == 0;
+            const float4 *Rp = Rs + (size_t)((cls * 2 + 0) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-                const int k = td_kmap(s, hi);
-                const float u = d - offk[s];
-                gv[s] = k < TD_NG ? expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
+                const float4 b = Rp[s * 64];
+                const float av = on ? gv[s] : 0.f;
+                acc[0] = td_mfma(av, b.x, acc[0]);
+                acc[1] = td_mfma(av, b.y, acc[1]);
+                acc[2] = td_mfma(av, b.z, acc[2]);
+                acc[3] = td_mfma(av, b.w, acc[3]);
             }
-            if (has_a) {
-                const bool on = valid && slot == 0;
+        }
+        if (has_b) {
+            const bool on = valid && slot == 1;
+            const float4 *Rp = Rs + (size_t)((cls * 2 + 1) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
-                for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[0][s], acc);
+            for (int s = 0; s < TD_SLOT_STEPS; ++s) {
+                const float4 b = Rp[s * 64];
+                const float av = on ? gv[s] : 0.f;
+                acc[0] = td_mfma(av, b.x, acc[0]);
+                acc[1] = td_mfma(av, b.y, acc[1]);
+                acc[2] = td_mfma(av, b.z, acc[2]);
+                acc[3] = td_mfma(av, b.w, acc[3]);
             }
-            if (has_b) {
-                const bool on = valid && slot == 1;
-#pragma unroll
-                for (int s = 0; s < TD_SLOT_STEPS; ++s) acc = td_mfma(on ? gv[s] : 0.f, rf[1][s], acc);
-            }
-            TD_STAMP(2);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Z[role][td_erow(r, hi)][n] = acc[r] + bj[r];
-            TD_STAMP(3);
-        } else if (!first_phase && t >= 0 && t < cnt) {
-            // ================= second layer of node t ======================================================
-            if (t + 1 < cnt) nxt = load_geo(t + 1);       // prefetch: lands while the MFMAs below run
-            float hres = 0.f;
-            if (!H2X && role == 1 && hi == 0) hres = a.h[(size_t)ci * TD_H + n];   // residual, needed after the MFMAs
-            const int buf = t & 1;
-            // LayerNorm + ReLU in A layout: lane (edge c, half hi) owns k in {8m+4hi .. 8m+4hi+3}.
-            // Two LDS passes: (1) shifted sums -> mean / variance, (2) normalise each 16-byte chunk right
-            // before the 4 MFMAs that consume it.
-            const float *zrow = &Z[role][c][4 * hi];
-            const float *gam = &GB[role][0][4 * hi];
-            const float *bet = &GB[role][1][4 * hi];
-            const float shift = Z[role][c][0];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
-                v.x -= shift; v.y -= shift; v.z -= shift; v.w -= shift;
-                s1 += (v.x + v.y) + (v.z + v.w);
-                s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            }
-            s1 = td_sum_halves(s1);
-            s2 = td_sum_halves(s2);
-            const float dmean = s1 * (1.0f / TD_H);
-            const float mean = shift + dmean;
-            const float var = fmaxf(s2 * (1.0f / TD_H) - dmean * dmean, 0.f);
-            const float rstd = 1.0f / sqrtf(var + 1e-5f);
-            TD_STAMP(1);
-            floatx16 acc2;
-            const float nms = -mean * rstd;                 // z = relu((v*rstd + nms) * gamma + beta)
-            auto norm4 = [&](const float4 &v, const float4 &gm, const float4 &bm) {
-                return make_float4(fmaxf(fmaf(fmaf(v.x, rstd, nms), gm.x, bm.x), 0.f),
-                                   fmaxf(fmaf(fmaf(v.y, rstd, nms), gm.y, bm.y), 0.f),
-                                   fmaxf(fmaf(fmaf(v.z, rstd, nms), gm.z, bm.z), 0.f),
-                                   fmaxf(fmaf(fmaf(v.w, rstd, nms), gm.w, bm.w), 0.f));
-            };
-            if (full2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[r] = b2n;
-                // Software pipeline: while the 4 dependent MFMAs of chunk m occupy the matrix pipe (4 x 64
-                // cycles), the VALU normalises chunk m+1 and the LDS returns chunk m+2.
-                float4 zc = norm4(*reinterpret_cast<const float4 *>(zrow), *reinterpret_cast<const float4 *>(gam),
-                                  *reinterpret_cast<const float4 *>(bet));
-                float4 vn = *reinterpret_cast<const float4 *>(zrow + 8);
-                float4 gn = *reinterpret_cast<const float4 *>(gam + 8);
-                float4 bn = *reinterpret_cast<const float4 *>(bet + 8);
-#pragma unroll
-                for (int m = 0; m < 16; ++m) {
-                    float4 zn = zc;
-                    if (m + 1 < 16) zn = norm4(vn, gn, bn);
-                    if (m + 2 < 16) {
-                        vn = *reinterpret_cast<const float4 *>(zrow + 8 * (m + 2));
-                        gn = *reinterpret_cast<const float4 *>(gam + 8 * (m + 2));
-                        bn = *reinterpret_cast<const float4 *>(bet + 8 * (m + 2));
-                    }
-                    acc2 = td_mfma(zc.x, w2[4 * m + 0], acc2);
-                    acc2 = td_mfma(zc.y, w2[4 * m + 1], acc2);
-                    acc2 = td_mfma(zc.z, w2[4 * m + 2], acc2);
-                    acc2 = td_mfma(zc.w, w2[4 * m + 3], acc2);
-                    zc = zn;
-                    // issue order hint: MFMA | 3 VALU + 1 LDS read | MFMA | ...   (masks: 0x8 MFMA, 0x2 VALU, 0x100 DS read)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-            } else {
-                // h2x value MLP: second Linear is 128 -> 16; wave w contracts hidden units [32w, 32w+32) (K split).
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#pragma unroll
-                for (int mm = 0; mm < 4; ++mm) {
-                    const int m = 4 * w + mm;
-                    const float4 v = *reinterpret_cast<const float4 *>(zrow + 8 * m);
-                    const float4 gm = *reinterpret_cast<const float4 *>(gam + 8 * m);
-                    const float4 bm = *reinterpret_cast<const float4 *>(bet + 8 * m);
-                    const float4 z = norm4(v, gm, bm);
-                    acc2 = td_mfma(z.x, w2[4 * mm + 0], acc2);
-                    acc2 = td_mfma(z.y, w2[4 * mm + 1], acc2);
-                    acc2 = td_mfma(z.z, w2[4 * mm + 2], acc2);
-                    acc2 = td_mfma(z.w, w2[4 * mm + 3], acc2);
-                }
-            }
+        }
 
-            TD_STAMP(2);
-            if (role == 0) {
-                // ---- attention logits + segment softmax over the 32 in-edges (scatter_softmax) -----------
-                const float qn = a.q[(size_t)ci * TD_H + n];
-                float4 ewq[4];
+        TD_STAMP(2);
+        // ---- LayerNorm + ReLU in C layout: row r of this half wave lives in acc[0..3][r] across 32 lanes -----------
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    ewq[qd] = *reinterpret_cast<const float4 *>(a.ew + ci * TD_K + 8 * qd + 4 * hi);
+        for (int r = 0; r < 16; ++r) {
+            const float v0 = acc[0][r] + pi[0], v1 = acc[1][r] + pi[1], v2 = acc[2][r] + pi[2], v3 = acc[3][r] + pi[3];
+            const float mean = td_sum32((v0 + v1) + (v2 + v3)) * (1.0f / TD_H);
+            const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+            const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            acc[0][r] = fmaxf(fmaf(d0 * rstd, gam[0], bet[0]), 0.f);
+            acc[1][r] = fmaxf(fmaf(d1 * rstd, gam[1], bet[1]), 0.f);
+            acc[2][r] = fmaxf(fmaf(d2 * rstd, gam[2], bet[2]), 0.f);
+            acc[3][r] = fmaxf(fmaf(d3 * rstd, gam[3], bet[3]), 0.f);
+        }
+
+        TD_STAMP(3);
+        // ---- C layout -> A layout, one 32-column tile at a time (lane (e = c, hi) gets k = 8m + 4hi .. + 3) -------
+        float4 az[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TB[td_erow(r, hi) * TB_STRIDE + c] = acc[t][r];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+                az[4 * t + mm] = *reinterpret_cast<const float4 *>(TB + c * TB_STRIDE + 8 * mm + 4 * hi);
+        }
+
+        TD_STAMP(4);
+        // ---- second layer ------------------------------------------------------------------------------------------
+        floatx16 o[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = b2[t];
+#pragma unroll
+        for (int s = 0; s < TD_KSTEPS; ++s) {
+            const float4 am = az[s >> 2];
+            const float av = (s & 3) == 0 ? am.x : (s & 3) == 1 ? am.y : (s & 3) == 2 ? am.z : am.w;
+            if (NARROW) {
+                o[0] = td_mfma(av, W2n[s * 64 + lane], o[0]);
+            } else {
+                const float4 b = W2s[s * 64 + lane];
+                o[0] = td_mfma(av, b.x, o[0]);
+                o[NT2 > 1 ? 1 : 0] = td_mfma(av, b.y, o[NT2 > 1 ? 1 : 0]);
+                o[NT2 > 2 ? 2 : 0] = td_mfma(av, b.z, o[NT2 > 2 ? 2 : 0]);
+                o[NT2 > 3 ? 3 : 0] = td_mfma(av, b.w, o[NT2 > 3 ? 3 : 0]);
+            }
+        }
+
+        TD_STAMP(5);
+        // ---- epilogue ----------------------------------------------------------------------------------------------
+        if (IS_K) {
+            // attention logits per head (8 columns = 8 lanes), softmax over the 32 in-edges (scatter_softmax),
+            // multiplied by the global edge gate (v = v * e_w in the reference) -> alpha[i][head][edge]
+            float4 ewq[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                ewq[qd] = *reinterpret_cast<const float4 *>(a.ew + i * TD_K + 8 * qd + 4 * hi);
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const float qn = a.q[(size_t)i * TD_H + 32 * t + c];
                 float lg[16];
                 float mx = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    lg[r] = ((cvalid >> r) & 1u) ? td_sum8(acc2[r] * qn) * TD_ATT_SCALE : -INFINITY;
+                    lg[r] = ((vmask >> r) & 1u) ? td_sum8(o[t][r] * qn) * TD_ATT_SCALE : -INFINITY;
                     mx = fmaxf(mx, lg[r]);
                 }
                 mx = td_max_halves(mx);
@@ -383,96 +347,113 @@ __global__ __launch_bounds__(512) void edge_attn_kernel(EdgeArgs a) {
                 float sm = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    lg[r] = ((cvalid >> r) & 1u) ? __expf(lg[r] - mx) : 0.f;
+                    lg[r] = ((vmask >> r) & 1u) ? __expf(lg[r] - mx) : 0.f;
                     sm += lg[r];
                 }
                 sm = td_sum_halves(sm);
                 const float inv = sm > 0.f ? 1.0f / sm : 0.f;
-                const int head = 4 * w + (c >> 3);
                 if ((c & 7) == 0) {
+                    float *dst = a.alpha + ((size_t)i * TD_HEADS + 4 * t + (c >> 3)) * TD_K + 4 * hi;
 #pragma unroll
                     for (int qd = 0; qd < 4; ++qd) {
                         const float4 e4 = ewq[qd];
-                        *reinterpret_cast<float4 *>(&ALPHA[buf][head][8 * qd + 4 * hi]) =
+                        *reinterpret_cast<float4 *>(dst + 8 * qd) =
                             make_float4(lg[4 * qd] * inv * e4.x, lg[4 * qd + 1] * inv * e4.y, lg[4 * qd + 2] * inv * e4.z,
                                         lg[4 * qd + 3] * inv * e4.w);
                     }
                 }
-            } else if (!H2X) {
-                // ---- out_i = sum_e alpha_e * e_w * v_e ; h_i += out_i (scatter_sum + residual, :77-83) -----
-                // alpha(t) was published by the k role one segment ago.
-                const float *al = &ALPHA[buf][4 * w + (c >> 3)][4 * hi];
+            }
+        } else if (MODE == MODE_X2H_V) {
+            // out_i = sum_e alpha_e * e_w * v_e ; h_i += out_i   (scatter_sum + residual, :77-83)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const float *al = a.alpha + ((size_t)i * TD_HEADS + 4 * t + (c >> 3)) * TD_K + 4 * hi;
                 float out = 0.f;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const float4 av = *reinterpret_cast<const float4 *>(al + 8 * qd);
-                    out += av.x * acc2[4 * qd + 0];
-                    out += av.y * acc2[4 * qd + 1];
-                    out += av.z * acc2[4 * qd + 2];
-                    out += av.w * acc2[4 * qd + 3];
+                    out = fmaf(av.x, o[t][4 * qd + 0], out);
+                    out = fmaf(av.y, o[t][4 * qd + 1], out);
+                    out = fmaf(av.z, o[t][4 * qd + 2], out);
+                    out = fmaf(av.w, o[t][4 * qd + 3], out);
                 }
                 out = td_sum_halves(out);
-                if (hi == 0) a.h[(size_t)ci * TD_H + n] = hres + out;
-            } else {
-                if (c < 16) {
+                if (hi == 0) a.h[(size_t)i * TD_H + 32 * t + c] += out;
+            }
+        } else {
+            // h2x value pass: lane (head = c < 16, hi) holds xv[row][head];
+            // delta_x_i = mean_heads sum_e alpha_e e_w xv_e (x_i - x_j)   (:131-140), masked update (:205-206)
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            if (c < TD_HEADS) {
+                const float *al = a.alpha + ((size_t)i * TD_HEADS + c) * TD_K + 4 * hi;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) XVP[w][td_erow(r, hi)][c] = acc2[r];
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 av = *reinterpret_cast<const float4 *>(al + 8 * qd);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float wgt = (rr == 0 ? av.x : rr == 1 ? av.y : rr == 2 ? av.z : av.w) * o[0][4 * qd + rr];
+                        const float4 rel = *reinterpret_cast<const float4 *>(RELB + 4 * (8 * qd + 4 * hi + rr));
+                        sx = fmaf(wgt, rel.x, sx);
+                        sy = fmaf(wgt, rel.y, sy);
+                        sz = fmaf(wgt, rel.z, sz);
+                    }
                 }
             }
+            sx = td_sum64(sx) * (1.0f / TD_HEADS);
+            sy = td_sum64(sy) * (1.0f / TD_HEADS);
+            sz = td_sum64(sz) * (1.0f / TD_HEADS);
+            if (lane == 0) a.x4_out[i] = make_float4(xi.x + sx, xi.y + sy, xi.z + sz, xi.w);
         }
-        TD_STAMP(4);
-        __syncthreads();
-        TD_STAMP(5);
-        if (H2X && role == 1 && w == 0 && !first_phase && t >= 0 && t < cnt) {
-            // partial xv of node t are complete after the barrier; alpha(t) is in ALPHA[t & 1] (the k role
-            // writes the other parity during the next segment).  This wave still holds node t's geometry.
-            const int buf = t & 1;
-            float sacc = 0.f;
-#pragma unroll
-            for (int hh = 0; hh < 8; ++hh) {
-                const int hd = 8 * hi + hh;
-                const float xv = ((XVP[0][c][hd] + XVP[1][c][hd]) + (XVP[2][c][hd] + XVP[3][c][hd])) + a.mv.b2[hd];
-                sacc += ALPHA[buf][hd][c] * xv;
-            }
-            const float dxs = td_sum64(sacc * crx) * (1.0f / TD_HEADS);
-            const float dys = td_sum64(sacc * cry) * (1.0f / TD_HEADS);
-            const float dzs = td_sum64(sacc * crz) * (1.0f / TD_HEADS);
-            if (lane == 0) a.x4_out[ci] = make_float4(cxi.x + dxs, cxi.y + dys, cxi.z + dzs, cxi.w);
-        }
+        TD_STAMP(6);
     }
 }
 
-static long long *g_timing_buf = nullptr;
-static int g_timing_segs = 0;
-void td_set_edge_timing(long long *buf, int segs) { g_timing_buf = buf; g_timing_segs = segs; }
-
 static int edge_grid(int64_t count) {
-    int64_t g = count < 256 ? count : 256;
+    int64_t g = (count + 7) / 8;                 // at least one node per wave
+    if (g > 256) g = 256;
     if (g >= 8) g = (g / 8) * 8;
     return (int)(g < 1 ? 1 : g);
 }
 
-int td_launch_x2h(const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
-                  const float *q, int64_t N, float *h, hipStream_t s) {
-    if (N == 0) return TD_OK;
-    EdgeArgs a;
-    a.x4 = x4; a.x4_out = nullptr; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = nullptr; a.h = h;
-    a.count = N; a.mk = L.hk; a.mv = L.hv; a.offsets = L.offsets; a.coeff = L.coeff;
-    a.dbg = g_timing_buf; a.dbg_segs = g_timing_segs;
-    if (g_timing_buf) edge_attn_kernel<false, true><<<dim3(edge_grid(N)), dim3(512), 0, s>>>(a);
-    else edge_attn_kernel<false, false><<<dim3(edge_grid(N)), dim3(512), 0, s>>>(a);
+static long long *g_timing_buf = nullptr;
+static int g_timing_nodes = 0;
+void td_set_edge_timing(long long *buf, int nodes) { g_timing_buf = buf; g_timing_nodes = nodes; }
+
+template <int MODE>
+static int launch_edge(EdgeArgs a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_mlp_kernel<MODE, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_mlp_kernel<MODE, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_LDS_BYTES));
+        attr_set = true;
+    }
+    a.dbg = g_timing_buf; a.dbg_nodes = g_timing_nodes;
+    if (g_timing_buf && MODE == MODE_X2H_K)
+        edge_mlp_kernel<MODE, true><<<dim3(edge_grid(a.count)), dim3(512), EDGE_LDS_BYTES, s>>>(a);
+    else
+        edge_mlp_kernel<MODE, false><<<dim3(edge_grid(a.count)), dim3(512), EDGE_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
-int td_launch_h2x(const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr, const float *ew,
-                  const float *P, const float *q, const int32_t *lig_node, int64_t Nl, hipStream_t s) {
-    if (Nl == 0) return TD_OK;
+int td_launch_edge_pass(int mode, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
+                        const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
+                        float *h, float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
     EdgeArgs a;
-    a.x4 = x4_in; a.x4_out = x4_out; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = lig_node; a.h = nullptr;
-    a.count = Nl; a.mk = L.xk; a.mv = L.xv; a.offsets = L.offsets; a.coeff = L.coeff;
-    a.dbg = nullptr; a.dbg_segs = 0;
-    edge_attn_kernel<true, false><<<dim3(edge_grid(Nl)), dim3(512), 0, s>>>(a);
-    TD_CHECK_HIP(hipGetLastError());
-    return TD_OK;
+    a.x4 = x4_in; a.x4_out = x4_out; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = lig_node; a.h = h;
+    a.alpha = alpha; a.count = count; a.offsets = L.offsets; a.coeff = L.coeff;
+    static int stagger = -1;
+    if (stagger < 0) { const char *e = getenv("TD_EDGE_STAGGER"); stagger = e ? atoi(e) : 2; }
+    a.stagger_sleeps = stagger;
+    switch (mode) {
+        case MODE_X2H_K: a.mlp = L.hk; return launch_edge<MODE_X2H_K>(a, s);
+        case MODE_X2H_V: a.mlp = L.hv; return launch_edge<MODE_X2H_V>(a, s);
+        case MODE_H2X_K: a.mlp = L.xk; return launch_edge<MODE_H2X_K>(a, s);
+        case MODE_H2X_V: a.mlp = L.xv; return launch_edge<MODE_H2X_V>(a, s);
+    }
+    td_set_error("td_launch_edge_pass: bad mode %d", mode);
+    return TD_EINVAL;
 }

@@ -67,12 +67,19 @@ __device__ __forceinline__ float td_max_halves(float v) {
     return fmaxf(lo, hi);
 }
 
-// Sum over the 32 lanes of a half-wave (lanes with equal l >> 5), result in every lane of the half.
+// v_permlane16_swap: rows (16 lanes) 1 and 3 of the first operand trade places with rows 0 and 2 of the second.
+// Fed with two copies of v: a = [r0, r0, r2, r2], b = [r1, r1, r3, r3], so a + b is the xor-16 butterfly sum.
+__device__ __forceinline__ float td_sum_rows16(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Sum over the 32 lanes of a half-wave (lanes with equal l >> 5), result in every lane of the half.  All VALU.
 __device__ __forceinline__ float td_sum32(float v) {
     v = td_sum8(v);
     v += td_dpp<DPP_ROW_ROR8>(v);          // the two groups of 8 inside a row of 16
-    v += __shfl_xor(v, 16);                // the two rows of a half-wave
-    return v;
+    return td_sum_rows16(v);               // the two rows of a half-wave
 }
 
 __device__ __forceinline__ float td_sum64(float v) {

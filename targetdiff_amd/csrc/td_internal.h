@@ -33,10 +33,10 @@ void td_set_error(const char *fmt, ...);
 //  * the 340-wide first Linear is split into node-side projections (proj_*), a per-(dst class, src class)
 //    radial/type table R and a bias;  * the second Linear is stored as per-wave MFMA B fragments.
 struct TdEdgeMlp {
-    const float *R;        // [2 dst class][4 wave][2 slot][12 kstep][64 lane]  first-layer radial+type B fragments
+    const float *R;        // [2 dst class][2 slot][12 kstep][64 lane][4 ntile]  first-layer radial+type B fragments
     const float *gamma;    // [128] LayerNorm weight
     const float *beta;     // [128] LayerNorm bias
-    const float *W2;       // out=128: [4 wave][64 kstep][64 lane];  out=16 (xv): [4 wave(K slice)][16 kstep][64 lane]
+    const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]
 };
 
@@ -109,11 +109,11 @@ int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, float *P, float *q, hipStream_t s);
 // edge.hip
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, float *ew, hipStream_t s);
-int td_launch_x2h(const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
-                  const float *q, int64_t N, float *h, hipStream_t s);
-int td_launch_h2x(const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr, const float *ew,
-                  const float *P, const float *q, const int32_t *lig_node, int64_t Nl, hipStream_t s);
-void td_set_edge_timing(long long *buf, int segs);
+// mode: 0 x2h key pass, 1 x2h value pass (updates h), 2 h2x key pass, 3 h2x value pass (writes x4_out)
+int td_launch_edge_pass(int mode, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
+                        const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
+                        float *h, float *alpha, hipStream_t s);
+void td_set_edge_timing(long long *buf, int nodes);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);

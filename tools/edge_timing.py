@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Dump per-segment cycle stamps of workgroup 0 of one x2h launch (C2 workload)."""
+"""Per-node phase timeline (cycle stamps) of workgroup 0 of one x2h key-pass launch on the C2 workload."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,21 +19,20 @@ lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets, spp, sizes), ge
 sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
                                lpos.to(dev), lv.to(dev), batch.ligand_element_batch, num_steps=3, center_pos_mode='protein')
 sampler.step()
-SEGS = 64
-buf = torch.zeros(8 * SEGS * 8, dtype=torch.int64, device=dev)
+NODES = 32
+buf = torch.zeros(8 * NODES * 8, dtype=torch.int64, device=dev)
 lib = capi.load_library()
-lib.td_debug_edge_timing(c_void_p(buf.data_ptr()), SEGS)
+lib.td_debug_edge_timing(c_void_p(buf.data_ptr()), NODES)
 sampler.step()
 torch.cuda.synchronize()
 lib.td_debug_edge_timing(None, 0)
-a = buf.cpu().numpy().reshape(8, SEGS, 8)
+a = buf.cpu().numpy().reshape(8, NODES, 8)
 t0 = a[:, :, 0][a[:, :, 0] > 0].min()
-np.set_printoptions(linewidth=200)
-for seg in range(20, 28):
-    print(f'--- segment {seg}')
-    for w in (0, 4):
-        st = a[w, seg]
-        rel = [int(x - a[w, seg, 0]) if x > 0 else -1 for x in st[:6]]
-        print(f'  wave {w} ({"k" if w < 4 else "v"}-role): start@{int(st[0] - t0):8d}  stamps(rel) {rel}')
-seg_len = np.diff(a[0, 10:60, 0])
-print('segment length (wave 0) cycles: mean', seg_len.mean(), 'even', seg_len[0::2].mean(), 'odd', seg_len[1::2].mean())
+names = ['geo+gather issue', 'exp+MFMA1', 'LayerNorm', 'transpose', 'MFMA2', 'epilogue']
+for w in (0, 4, 1):
+    print(f'--- wave {w}: node start (rel. to kernel start) and phase lengths [cycles]: {names}')
+    for nd in range(8, 14):
+        st = a[w, nd]
+        print(f'   node {nd}: start {int(st[0] - t0):8d}  phases {[int(st[k + 1] - st[k]) for k in range(6)]}  total {int(st[6] - st[0])}')
+ph = np.diff(a[:, 4:28, :7], axis=2).reshape(-1, 6)
+print('mean phase lengths over waves/nodes:', dict(zip(names, ph.mean(0).round().astype(int).tolist())), 'total', int(ph.sum(1).mean()))
