@@ -2,6 +2,7 @@
 // See include/targetdiff_hip.h for the contract of every entry point and the reference seam it replaces.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -141,10 +142,11 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt; };
 
-EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim) {
+EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int alt) {
     EdgeOff o;
+    o.Walt = 0;
     // first layer radial / type table: [cls][slot][kstep][lane][ntile]
     o.R = pk.alloc((size_t)2 * 2 * TD_SLOT_STEPS * 64 * 4);
     float *d = pk.data.data() + o.R;
@@ -176,6 +178,26 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim) {
                 q[(size_t)s * 64 + lane] = cc < out_dim ? m.w3[(size_t)cc * TD_H + td_kmap(s, lane >> 5)] : 0.f;
             }
         o.b2 = pack_vec(pk, m.b3, out_dim, TD_HEADS);
+    }
+    if (alt == 1) {          // key MLP: per-head slices of W2 in the order the U_i build consumes them
+        o.Walt = pk.alloc((size_t)4 * 16 * 2 * 2 * 16 * 4);
+        float *q = pk.data.data() + o.Walt;
+        for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 16; ++r)
+                for (int jq = 0; jq < 2; ++jq)
+                    for (int hi = 0; hi < 2; ++hi)
+                        for (int c = 0; c < 16; ++c)
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;      // hidden unit of C-layout row r
+                                q[((((((size_t)t * 16 + r) * 2 + jq) * 2 + hi) * 16 + c) * 4) + jj] =
+                                    m.w3[(size_t)(8 * c + 4 * jq + jj) * TD_H + n];
+                            }
+    } else if (alt == 2) {   // value MLP of x2h: W2vK[k/4][n][k%4]
+        o.Walt = pk.alloc((size_t)32 * TD_H * 4);
+        float *q = pk.data.data() + o.Walt;
+        for (int kq = 0; kq < 32; ++kq)
+            for (int n = 0; n < TD_H; ++n)
+                for (int kk = 0; kk < 4; ++kk) q[((size_t)kq * TD_H + n) * 4 + kk] = m.w3[(size_t)n * TD_H + 4 * kq + kk];
     }
     return o;
 }
@@ -281,10 +303,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         lo[l].coeff = gaussian_coeff(off);
         lo[l].nx = pack_node_stage(pk, hk, hv, hq, KV);
         lo[l].nh = pack_node_stage(pk, xk, xv, xq, KV);
-        lo[l].hk = pack_edge_mlp(pk, hk, KV, H);
-        lo[l].hv = pack_edge_mlp(pk, hv, KV, H);
-        lo[l].xk = pack_edge_mlp(pk, xk, KV, H);
-        lo[l].xv = pack_edge_mlp(pk, xv, KV, c.n_heads);
+        lo[l].hk = pack_edge_mlp(pk, hk, KV, H, 1);
+        lo[l].hv = pack_edge_mlp(pk, hv, KV, H, 2);
+        lo[l].xk = pack_edge_mlp(pk, xk, KV, H, 1);
+        lo[l].xv = pack_edge_mlp(pk, xv, KV, c.n_heads, 0);
     }
     // ---- head
     const float *V0 = cur.take((size_t)H * H), *vb0 = cur.take(H), *V2 = cur.take((size_t)C * H), *vb2 = cur.take(C);
@@ -317,7 +339,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     const float *D = m->blob;
     m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
-    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2}; };
+    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.Walt}; };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias};
     };
@@ -370,6 +392,14 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     return w;
 }
 
+// TD_EDGE_IMPL=plain selects the straightforward key/value kernels (edge.hip: per-edge k and v vectors are
+// materialised) instead of the re-associated ones (edge_fast.hip); used for A/B timing and as a cross-check.
+bool fast_edges() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("TD_EDGE_IMPL"); v = (e && strcmp(e, "plain") == 0) ? 0 : 1; }
+    return v == 1;
+}
+
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
 // the buffer holding the final coordinates through *x_final.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
@@ -382,11 +412,22 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     for (int l = 0; l < m->cfg.num_layers; ++l) {
         const TdLayer &L = m->layers[l];
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+        if (fast_edges()) {
+            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(false, L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L.hv, L, xc, w.nbr, w.P, N, h, w.alpha, s)) != TD_OK) return rc; }
+        } else {
+            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+        }
         if (!fix_x && Nl > 0) {
             { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_H2X_K, s); if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc; }
+            if (fast_edges()) {
+                ProfScope ps(PC_H2X_K, s);
+                if ((rc = td_launch_edge_key(true, L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, w.alpha, s)) != TD_OK) return rc;
+            } else {
+                ProfScope ps(PC_H2X_K, s);
+                if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc;
+            }
             { ProfScope ps(PC_H2X_V, s); if ((rc = td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc; }
             float4 *t = xc; xc = xn; xn = t;
         }

@@ -38,6 +38,7 @@ struct TdEdgeMlp {
     const float *beta;     // [128] LayerNorm bias
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]
+    const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
 };
 
 // Node-side weights of one stage (x2h or h2x): 4 projections (k_i,k_j,v_i,v_j) + the query MLP.
@@ -114,6 +115,12 @@ int td_launch_edge_pass(int mode, const TdLayer &L, const float4 *x4_in, float4 
                         const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
                         float *h, float *alpha, hipStream_t s);
 void td_set_edge_timing(long long *buf, int nodes);
+// edge_fast.hip
+int td_launch_edge_key(bool h2x, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr,
+                       const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
+                       float *alpha, hipStream_t s);
+int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
+                         int64_t count, float *h, const float *alpha, hipStream_t s);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);
