@@ -411,7 +411,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     if (!fix_x && Nl > 0) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < m->cfg.num_layers; ++l) {
         const TdLayer &L = m->layers[l];
-        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, w.P, w.q, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
         if (fast_edges()) {
             { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(false, L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
             { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L.hv, L, xc, w.nbr, w.P, N, h, w.alpha, s)) != TD_OK) return rc; }
@@ -420,7 +420,11 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
         }
         if (!fix_x && Nl > 0) {
-            { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, w.P, w.q, s)) != TD_OK) return rc; }
+            {   // h2x: src-side projections (k_j, v_j) for every node; dst-side projections and queries for ligand atoms only
+                ProfScope ps(PC_NODE, s);
+                if ((rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.P, w.q, s)) != TD_OK) return rc;
+                if ((rc = td_launch_node_proj(L.nodeH2x, h, Nl, w.lig_node, 0x15, w.P, w.q, s)) != TD_OK) return rc;
+            }
             if (fast_edges()) {
                 ProfScope ps(PC_H2X_K, s);
                 if ((rc = td_launch_edge_key(true, L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, w.alpha, s)) != TD_OK) return rc;
@@ -577,7 +581,7 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
         return TD_EINVAL;
     }
     const TdLayer &L = m->layers[layer];
-    return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, d_P, d_q, static_cast<hipStream_t>(stream));
+    return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, nullptr, 0x1f, d_P, d_q, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream) {

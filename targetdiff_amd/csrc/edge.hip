@@ -33,7 +33,7 @@ constexpr float TD_ATT_SCALE = 0.35355339059327373f;   // 1/sqrt(8)   (models/un
 
 // ------------------------------------------------------------------------------------------ edge gate
 // One wave per dst node, all 128 hidden units (4 N-tiles).  Pure register kernel: no LDS, no barriers.
-__global__ __launch_bounds__(256) void edge_gate_kernel(TdGate g, const float4 *__restrict__ x4,
+__global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float4 *__restrict__ x4,
                                                         const int32_t *__restrict__ nbr, int64_t N,
                                                         float *__restrict__ ew) {
     const int lane = threadIdx.x & 63;

@@ -16,11 +16,19 @@
 
 constexpr int ZSTRIDE = 132;     // 128 + 4: conflict-free ds_read_b128 of rows (stride/4 odd)
 
+// 128-deep GEMM of one 32-row A tile against all 4 N tiles.  B fragments stream from L2 (~600-900 cycles); a
+// ring of PF 16-byte loads is kept in flight explicitly (hipcc on its own keeps 1-2, which left the kernel
+// latency-bound: 4 MFMAs = 256 cycles per k-step).
+constexpr int PF = 6;
 __device__ __forceinline__ void gemm128(const float4 (&a)[16], const float4 *__restrict__ B, int lane,
                                         floatx16 (&acc)[4]) {
+    float4 ring[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) ring[s] = B[s * 64 + lane];
 #pragma unroll
     for (int s = 0; s < TD_KSTEPS; ++s) {
-        const float4 b = B[s * 64 + lane];
+        const float4 b = ring[s % PF];
+        if (s + PF < TD_KSTEPS) ring[s % PF] = B[(s + PF) * 64 + lane];
         const float4 am = a[s >> 2];
         const float av = (s & 3) == 0 ? am.x : (s & 3) == 1 ? am.y : (s & 3) == 2 ? am.z : am.w;
         acc[0] = td_mfma(av, b.x, acc[0]);
@@ -30,23 +38,35 @@ __device__ __forceinline__ void gemm128(const float4 (&a)[16], const float4 *__r
     }
 }
 
-__global__ __launch_bounds__(256) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
+// mat_mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP.  rows != nullptr: process only
+// the listed node ids (h2x needs the dst-side projections and queries of ligand atoms only).
+__global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
+                                                        const int32_t *__restrict__ rows, unsigned mat_mask,
                                                         float *__restrict__ P, float *__restrict__ q) {
     extern __shared__ __attribute__((aligned(16))) float zbuf[];     // [4 waves][32 rows][ZSTRIDE]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, hi = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
-    const int64_t arow = row0 + c;
+    const int64_t aslot = row0 + c;
+    const int64_t arow = aslot < N ? (rows ? (int64_t)rows[aslot] : aslot) : -1;
 
     float4 a[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m)
-        a[m] = (arow < N) ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        a[m] = (arow >= 0) ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    // output row of each C-layout register row
+    int64_t orow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t slot = row0 + td_erow(r, hi);
+        orow[r] = slot < N ? (rows ? (int64_t)rows[slot] : slot) : -1;
+    }
 
     const float4 *Bp = reinterpret_cast<const float4 *>(st.projB);
     floatx16 acc[4];
     for (int mat = 0; mat < 4; ++mat) {
+        if (!((mat_mask >> mat) & 1u)) continue;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float bias = st.projBias[mat * TD_H + 32 * t + c];
@@ -56,13 +76,13 @@ __global__ __launch_bounds__(256) void node_proj_kernel(TdNodeStage st, const fl
         gemm128(a, Bp + (size_t)mat * TD_KSTEPS * 64, lane, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + td_erow(r, hi);
-            if (row < N) {
+            if (orow[r] >= 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) P[row * (4 * TD_H) + mat * TD_H + 32 * t + c] = acc[t][r];
+                for (int t = 0; t < 4; ++t) P[orow[r] * (4 * TD_H) + mat * TD_H + 32 * t + c] = acc[t][r];
             }
         }
     }
+    if (!((mat_mask >> 4) & 1u)) return;      // uniform over the workgroup: no barrier is skipped by a subset
 
     // ---- query MLP: Linear -> LayerNorm -> ReLU -> Linear (models/common.py:60-80) -------------------
 #pragma unroll
@@ -86,7 +106,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(TdNodeStage st, const fl
         float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
         float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         const float var = td_sum32(s2) * (1.0f / TD_H);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float rstd = __frsqrt_rn(var + 1e-5f);
         const int row = td_erow(r, hi);
         zw[row * ZSTRIDE + c] = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f);
         zw[row * ZSTRIDE + 32 + c] = fmaxf(d1 * rstd * gam[1] + bet[1], 0.f);
@@ -106,16 +126,16 @@ __global__ __launch_bounds__(256) void node_proj_kernel(TdNodeStage st, const fl
     gemm128(a2, reinterpret_cast<const float4 *>(st.q3B), lane, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + td_erow(r, hi);
-        if (row < N) {
+        if (orow[r] >= 0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) q[row * TD_H + 32 * t + c] = acc[t][r];
+            for (int t = 0; t < 4; ++t) q[orow[r] * TD_H + 32 * t + c] = acc[t][r];
         }
     }
 }
 
-int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, float *P, float *q, hipStream_t s) {
-    if (N == 0) return TD_OK;
+int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
+                        float *P, float *q, hipStream_t s) {
+    if (N == 0 || mat_mask == 0) return TD_OK;
     static bool attr_set = false;
     const size_t lds = 4 * 32 * ZSTRIDE * sizeof(float);
     if (!attr_set) {
@@ -123,7 +143,7 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, float 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    node_proj_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), lds, s>>>(st, h, N, P, q);
+    node_proj_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), lds, s>>>(st, h, N, rows, mat_mask, P, q);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -107,7 +107,9 @@ int td_launch_compose(const td_model *m, const float *ppos, const float *pv, con
                       float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, hipStream_t s);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
 // node.hip
-int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, float *P, float *q, hipStream_t s);
+// rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
+int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
+                        float *P, float *q, hipStream_t s);
 // edge.hip
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, float *ew, hipStream_t s);
 // mode: 0 x2h key pass, 1 x2h value pass (updates h), 2 h2x key pass, 3 h2x value pass (writes x4_out)
