@@ -1,0 +1,109 @@
+"""CPU-only checks of the host side: C-ABI library loads and exports every declared symbol, the Python mirror is
+state_dict-compatible with the reference layout, the product fails loudly without a HIP device, input packing and the
+pocket partition follow the reference driver."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, small_inputs
+from oracle import weights
+from targetdiff_amd import capi, workloads
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'targetdiff_hip.h')).read()
+    declared = set(re.findall(r'\b(td_[a-z_0-9]+)\s*\(', header))
+    declared -= {'td_model'}                      # the opaque struct tag
+    assert {'td_model_create', 'td_knn', 'td_refine_forward', 'td_model_forward', 'td_posterior_step'} <= declared
+    lib = capi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in targetdiff_hip.h but not exported'
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    assert lib.td_abi_version() == 1
+
+
+def test_weight_blob_layout_matches_library():
+    lib = capi.load_library()
+    cfg = capi.TdConfig(hidden_dim=128, n_heads=16, knn=32, num_layers=9, num_r_gaussian=20, edge_feat_dim=4,
+                        protein_feat_dim=27, ligand_num_classes=13, num_timesteps=1000)
+    blob = capi.flatten_state_dict(weights.make_state_dict(2021), 9)
+    assert blob.size == lib.td_model_num_weights(ctypes.byref(cfg)) == 2670780
+    # init_h_emb_layer (154,112 dead parameters) is the only learnable block left out
+    total = sum(int(np.prod(s)) for _, s, kind, _ in weights.parameter_spec())
+    dead = sum(int(np.prod(s)) for k, s, kind, _ in weights.parameter_spec() if 'init_h_emb_layer' in k)
+    per_layer_offsets = 0          # offsets are part of both counts
+    assert total - dead == blob.size + per_layer_offsets
+
+
+def test_unsupported_config_is_rejected_not_emulated():
+    lib = capi.load_library()
+    cfg = capi.TdConfig(hidden_dim=256, n_heads=16, knn=32, num_layers=9, num_r_gaussian=20, edge_feat_dim=4,
+                        protein_feat_dim=27, ligand_num_classes=13, num_timesteps=1000)
+    h = ctypes.c_void_p()
+    dummy = (ctypes.c_float * 4)()
+    rc = lib.td_model_create(ctypes.byref(cfg), dummy, 4, None, 0, ctypes.byref(h))
+    assert rc == -1 and b'unsupported configuration' in lib.td_last_error()
+    from targetdiff_amd.models import ScorePosNet3D
+    bad = dict(weights.DEFAULT_MODEL_CONFIG, cutoff_mode='radius')
+    with pytest.raises(NotImplementedError):
+        ScorePosNet3D(bad, 27, 13)
+
+
+def test_model_mirror_state_dict_and_loud_failure(state_dict):
+    from targetdiff_amd.models import ScorePosNet3D
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    sd = m.state_dict()
+    assert len(sd) == 384
+    assert set(state_dict) <= set(sd)
+    res = m.load_state_dict(state_dict, strict=False)
+    assert not res.unexpected_keys and all(k.count('.') == 0 for k in res.missing_keys)   # only schedule consts/buffers
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 2824692
+    g = load_golden('schedules.npz')
+    for k, v in g.items():
+        np.testing.assert_array_equal(getattr(m, k).detach().numpy(), v, err_msg=k)
+    inp = small_inputs(load_golden('forward_small.npz'))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            m(inp['protein_pos'], inp['protein_v'], inp['batch_protein'], inp['ligand_pos'], inp['ligand_v'],
+              inp['batch_ligand'])
+        with pytest.raises(RuntimeError):
+            m.sample_diffusion(inp['protein_pos'], inp['protein_v'], inp['batch_protein'], inp['ligand_pos'],
+                               inp['ligand_v'], inp['batch_ligand'], num_steps=1, center_pos_mode='protein')
+
+
+def test_pack_samples_matches_reference_batching():
+    p1, p2 = workloads.synthetic_pocket(1, 20), workloads.synthetic_pocket(2, 31)
+    b = workloads.pack_samples([p1, p2], 2, [3, 4, 5, 6])
+    assert b.num_graphs == 4 and b.protein_pos.shape == (2 * 20 + 2 * 31, 3)
+    assert b.protein_element_batch.tolist() == [0] * 20 + [1] * 20 + [2] * 31 + [3] * 31
+    assert b.ligand_element_batch.tolist() == [0] * 3 + [1] * 4 + [2] * 5 + [3] * 6
+    assert b.protein_atom_feature.shape[1] == 27 and b.protein_atom_feature.sum(1).min() >= 2   # element + residue
+    g = torch.Generator().manual_seed(0)
+    pos, v = workloads.init_ligand(b, generator=g)
+    assert pos.shape == (18, 3) and v.dtype == torch.int64 and int(v.max()) < 13
+    centre = torch.from_numpy(p1.pos).mean(0)
+    assert float((pos[:3] - centre).norm(dim=1).max()) < 6.0     # centroid + N(0, I)
+
+
+def test_pdb_parser_and_featuriser(tmp_path):
+    block = ('HEADER    POCKET\n'
+             'ATOM    219  N   LEU A  36      36.155  52.241  55.687  1.00 30.88         A N\n'
+             'ATOM    220  CA  LEU A  36      35.391  51.712  54.566  1.00 30.88         A C\n'
+             'ATOM    221  SG  CYS A  37      35.560  50.200  54.537  1.00 30.88         A S\n')
+    p = workloads.pocket_from_pdb(block)
+    assert p.num_atoms == 3 and p.feat.shape == (3, 27)
+    np.testing.assert_allclose(p.pos[0], [36.155, 52.241, 55.687], rtol=1e-6)
+    assert p.feat[0, 2] == 1 and p.feat[1, 1] == 1 and p.feat[2, 4] == 1        # N, C, S one-hots
+    assert p.feat[0, 6 + workloads.AA_NAMES.index('LEU')] == 1 and p.feat[2, 6 + workloads.AA_NAMES.index('CYS')] == 1
+    assert p.feat[:, 26].tolist() == [1, 1, 0]                                  # backbone flag
+
+
+def test_partition_is_the_reference_round_robin():
+    # scripts/batch_sample_diffusion.sh:15-20: task i -> worker i % NODE_ALL, starting at START_IDX
+    parts = [workloads.partition_pockets(100, 8, r) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(100)) and parts[3][:3] == [3, 11, 19]
+    assert workloads.partition_pockets(10, 4, 1, start_idx=4) == [5, 9]
