@@ -128,6 +128,7 @@ def main():
     ap.add_argument('--workload', default='c2', choices=['c1', 'c2', 'c3', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel class, print a breakdown to stderr')
+    ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -159,7 +160,7 @@ def main():
         raise SystemExit('warmup + steps must be <= 1000 (one sampling run)')
     sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
                                    lpos, lv, batch.ligand_element_batch, num_steps=total, center_pos_mode='protein',
-                                   max_graph_nodes=max_nodes)
+                                   max_graph_nodes=max_nodes, use_session=not args.no_session)
     for _ in range(args.warmup):
         sampler.step()
 

@@ -124,6 +124,24 @@ int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_l
                   const int32_t *d_ligand_ptr, int64_t B, float *d_offset, int32_t compute_offset,
                   int32_t sign, void *stream);
 
+/* ---- sampling session (replaces the loop-invariant part of ScorePosNet3D.sample_diffusion,
+ *      models/molopt_score_model.py:633-661: protein_pos / protein_v / batch_protein are the same tensors in every
+ *      one of the ~1000 forward calls and protein coordinates never move, models/uni_transformer.py:206).
+ *      td_session_create takes the CENTRED protein once and precomputes embeddings, protein-only sorted neighbour
+ *      lists and -- for protein atoms whose 32-NN row no ligand atom enters -- the edge-gate row and the layer-0 x2h
+ *      output.  td_session_forward = ScorePosNet3D.forward for the current ligand state; its results equal
+ *      td_model_forward's (same kernels, same per-row arithmetic; neighbour rows bit-identical).  The session owns its
+ *      device memory; one forward at a time per session. */
+typedef struct td_session td_session;
+int td_session_create(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
+                      const int32_t *d_protein_ptr, int64_t N_p, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                      int32_t max_graph_nodes, void *stream, td_session **out);
+void td_session_destroy(td_session *s);
+int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *d_ligand_v, float *d_pred_ligand_pos,
+                       float *d_pred_ligand_v, float *d_final_ligand_h, void *stream);
+/* number of rows (ligand + displaced protein rows) the last td_session_forward recomputed at layer 0; synchronises */
+int td_session_dirty_rows(td_session *s, int32_t *host_count, void *stream);
+
 /* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
  *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;
  *      td_profile_end synchronises the device and returns per-class summed milliseconds and launch counts.

@@ -46,6 +46,10 @@ SIGNATURES = {
                                    _P, _P, _P, c_size_t, _P]),
     'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
+    'td_session_create': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, POINTER(c_void_p)]),
+    'td_session_destroy': (None, [_P]),
+    'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
+    'td_session_dirty_rows': (c_int32, [_P, POINTER(c_int32), _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
     'td_debug_edge_timing': (c_int32, [_P, c_int32]),
@@ -271,3 +275,48 @@ class NativeModel:
         _check(self.lib.td_debug_node_stage(self.handle, layer, stage, _ptr(h, torch.float32, 'h'), N, _ptr(P), _ptr(q),
                                             _stream()), 'td_debug_node_stage')
         return P, q
+
+
+class NativeSession:
+    """Loop-invariant state of one sample_diffusion call (td_session): the centred protein is handed over once."""
+
+    def __init__(self, native: NativeModel, protein_pos, protein_v, protein_ptr, ligand_ptr, num_ligand_atoms: int,
+                 max_graph_nodes: int = 0):
+        self.native = native
+        self.lib = native.lib
+        self.Nl = int(num_ligand_atoms)
+        self.C = native.num_classes
+        self.device = protein_pos.device
+        handle = c_void_p()
+        _check(self.lib.td_session_create(
+            native.handle, _ptr(protein_pos, torch.float32, 'protein_pos'), _ptr(protein_v, torch.float32, 'protein_v'),
+            _ptr(protein_ptr, torch.int32, 'protein_ptr'), protein_pos.shape[0], _ptr(ligand_ptr, torch.int32, 'ligand_ptr'),
+            self.Nl, protein_ptr.numel() - 1, max_graph_nodes, _stream(), ctypes.byref(handle)), 'td_session_create')
+        self.handle = handle
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and getattr(self, 'lib', None) is not None:
+            self.lib.td_session_destroy(h)
+
+    def forward(self, ligand_pos, ligand_v, out=None):
+        out = out or {}
+        dev = ligand_pos.device
+        pred_pos = out.get('pred_ligand_pos')
+        if pred_pos is None:
+            pred_pos = torch.empty(self.Nl, 3, dtype=torch.float32, device=dev)
+        pred_v = out.get('pred_ligand_v')
+        if pred_v is None:
+            pred_v = torch.empty(self.Nl, self.C, dtype=torch.float32, device=dev)
+        lig_h = out.get('final_ligand_h')
+        if lig_h is None:
+            lig_h = torch.empty(self.Nl, HIDDEN, dtype=torch.float32, device=dev)
+        _check(self.lib.td_session_forward(self.handle, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
+                                           _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(pred_pos), _ptr(pred_v),
+                                           _ptr(lig_h), _stream()), 'td_session_forward')
+        return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': None, 'final_ligand_h': lig_h}
+
+    def dirty_rows(self) -> int:
+        n = c_int32(0)
+        _check(self.lib.td_session_dirty_rows(self.handle, ctypes.byref(n), _stream()), 'td_session_dirty_rows')
+        return int(n.value)

@@ -403,22 +403,26 @@ bool fast_edges() {
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
 // the buffer holding the final coordinates through *x_final.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
-                 float4 **x_final, hipStream_t s) {
+                 float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false) {
     int rc;
+    if (!graph_ready) {
     { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
-    { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, w.ew, s)) != TD_OK) return rc; }
+    { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
+    }
     float4 *xc = w.x4a, *xn = w.x4b;
-    if (!fix_x && Nl > 0) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (!fix_x && Nl > 0 && !graph_ready) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
     for (int l = 0; l < m->cfg.num_layers; ++l) {
         const TdLayer &L = m->layers[l];
+        if (l == 0 && layer0_x2h_done) goto h2x_stage;
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
         if (fast_edges()) {
-            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(false, L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L.hv, L, xc, w.nbr, w.P, N, h, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L.hv, L, xc, w.nbr, w.P, nullptr, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
         } else {
             { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
             { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
         }
+    h2x_stage:
         if (!fix_x && Nl > 0) {
             {   // h2x: src-side projections (k_j, v_j) for every node; dst-side projections and queries for ligand atoms only
                 ProfScope ps(PC_NODE, s);
@@ -427,7 +431,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
             if (fast_edges()) {
                 ProfScope ps(PC_H2X_K, s);
-                if ((rc = td_launch_edge_key(true, L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, w.alpha, s)) != TD_OK) return rc;
+                if ((rc = td_launch_edge_key(L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, nullptr, Nl, w.alpha, s)) != TD_OK) return rc;
             } else {
                 ProfScope ps(PC_H2X_K, s);
                 if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc;
@@ -535,7 +539,7 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
     {
         ProfScope ps(PC_COMPOSE, s);
         if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
-                                    d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, s)) != TD_OK)
+                                    d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, nullptr, s)) != TD_OK)
             return rc;
     }
     float4 *xf = nullptr;
@@ -590,5 +594,150 @@ extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *
 
 extern "C" int td_debug_edge_timing(int64_t *d_buf, int32_t nodes) {
     td_set_edge_timing(reinterpret_cast<long long *>(d_buf), nodes);
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sampling session
+// State of one ScorePosNet3D.sample_diffusion call (models/molopt_score_model.py:633-703).  Everything that depends
+// only on the protein is loop-invariant there (protein_pos, protein_v, batch_protein are passed unchanged to every
+// forward, :652-661; protein coordinates are never updated, models/uni_transformer.py:206) and is computed once:
+// embeddings, protein-only sorted neighbour lists, and -- for protein atoms that no ligand atom displaces from
+// their 32-NN row ("clean" rows, 80-90 % of them) -- the edge gate row and the layer-0 x2h output.
+struct td_session {
+    const td_model *m;
+    int64_t N, Np, Nl, B;
+    int max_graph_nodes;
+    char *block;
+    Workspace w;                 // per-step buffers (x4a/x4b, gid, nbr, lig_node, node_ptr, ew, P, q, h, alpha)
+    int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count;
+    unsigned long long *skeys;
+    float *ews, *h0, *h1s, *P0, *q0;
+    uint8_t *clean;
+};
+
+extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
+                                 const int32_t *d_protein_ptr, int64_t N_p, const int32_t *d_ligand_ptr, int64_t N_l,
+                                 int64_t B, int32_t max_graph_nodes, void *stream, td_session **out) {
+    if (!m || !out || N_p <= 0 || N_l <= 0 || B <= 0 || !d_protein_pos || !d_protein_v || !d_protein_ptr || !d_ligand_ptr) {
+        td_set_error("td_session_create: bad argument");
+        return TD_EINVAL;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t N = N_p + N_l;
+    td_session *S = new (std::nothrow) td_session();
+    if (!S) { td_set_error("td_session_create: out of host memory"); return TD_ENOMEM; }
+    S->m = m; S->N = N; S->Np = N_p; S->Nl = N_l; S->B = B; S->max_graph_nodes = max_graph_nodes;
+    // ---- one device block: [workspace | session-static buffers]
+    const size_t ws_bytes = carve(nullptr, N, B, N_l).bytes;
+    size_t off = ws_bytes;
+    auto reserve = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
+    const size_t n = (size_t)N;
+    const size_t o_prot = reserve((size_t)N_p * 4), o_pptr = reserve((size_t)(B + 1) * 4), o_lptr = reserve((size_t)(B + 1) * 4),
+                 o_snbr = reserve(n * TD_K * 4), o_skeys = reserve(n * TD_K * 8), o_ews = reserve(n * TD_K * 4),
+                 o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_P0 = reserve(n * 4 * TD_H * 4),
+                 o_q0 = reserve(n * TD_H * 4), o_clean = reserve(n), o_dirty = reserve(n * 4), o_dcnt = reserve(256),
+                 o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), off);
+    if (e != hipSuccess) {
+        td_set_error("td_session_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+        delete S;
+        return TD_ENOMEM;
+    }
+    char *b = S->block;
+    S->w = carve(b, N, B, N_l);
+    S->prot_node = reinterpret_cast<int32_t *>(b + o_prot);
+    S->pptr = reinterpret_cast<int32_t *>(b + o_pptr);
+    S->lptr = reinterpret_cast<int32_t *>(b + o_lptr);
+    S->snbr = reinterpret_cast<int32_t *>(b + o_snbr);
+    S->skeys = reinterpret_cast<unsigned long long *>(b + o_skeys);
+    S->ews = reinterpret_cast<float *>(b + o_ews);
+    S->h0 = reinterpret_cast<float *>(b + o_h0);
+    S->h1s = reinterpret_cast<float *>(b + o_h1s);
+    S->P0 = reinterpret_cast<float *>(b + o_P0);
+    S->q0 = reinterpret_cast<float *>(b + o_q0);
+    S->clean = reinterpret_cast<uint8_t *>(b + o_clean);
+    S->dirty_rows = reinterpret_cast<int32_t *>(b + o_dirty);
+    S->dirty_count = reinterpret_cast<int32_t *>(b + o_dcnt);
+    float *tmp_lpos = reinterpret_cast<float *>(b + o_tmp_lpos);
+    int64_t *tmp_lv = reinterpret_cast<int64_t *>(b + o_tmp_lv);
+    Workspace &w = S->w;
+    auto fail = [&](int rc) { (void)hipFree(S->block); delete S; return rc; };
+    int rc;
+#define TD_TRY(expr) do { if ((rc = (expr)) != TD_OK) return fail(rc); } while (0)
+#define TD_TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { td_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return fail(TD_EHIP); } } while (0)
+    TD_TRY_HIP(hipMemcpyAsync(S->pptr, d_protein_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
+    TD_TRY_HIP(hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
+    TD_TRY_HIP(hipMemsetAsync(tmp_lpos, 0, (size_t)N_l * 12, s));
+    TD_TRY_HIP(hipMemsetAsync(tmp_lv, 0, (size_t)N_l * 8, s));
+    // embeddings + packed order (ligand rows are placeholders until the first step), protein row list
+    TD_TRY(td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, tmp_lpos, tmp_lv, S->lptr, N_l, B, S->h0, w.x4a,
+                             w.node_ptr, w.gid, w.lig_node, S->prot_node, s));
+    TD_TRY_HIP(hipMemcpyAsync(w.x4b, w.x4a, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    // protein-only graph, its gate rows, layer-0 projections / queries, layer-0 x2h output
+    TD_TRY_HIP(hipMemsetAsync(S->snbr, 0xff, n * TD_K * 4, s));
+    TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s));
+    TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
+    const TdLayer &L0 = m->layers[0];
+    TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
+    TD_TRY(td_launch_edge_key(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
+    TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
+    TD_TRY(td_launch_edge_value(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, s));
+#undef TD_TRY
+#undef TD_TRY_HIP
+    *out = S;
+    return TD_OK;
+}
+
+extern "C" void td_session_destroy(td_session *S) {
+    if (!S) return;
+    if (S->block) (void)hipFree(S->block);
+    delete S;
+}
+
+extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, const int64_t *d_ligand_v,
+                                  float *d_pred_ligand_pos, float *d_pred_ligand_v, float *d_final_ligand_h,
+                                  void *stream) {
+    if (!S || !d_ligand_pos || !d_ligand_v || !d_pred_ligand_pos || !d_pred_ligand_v) {
+        td_set_error("td_session_forward: null pointer");
+        return TD_EINVAL;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const td_model *m = S->m;
+    Workspace &w = S->w;
+    const int64_t N = S->N, Nl = S->Nl, Np = S->Np;
+    int rc;
+    {
+        ProfScope ps(PC_COMPOSE, s);
+        if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
+    }
+    {
+        ProfScope ps(PC_KNN, s);
+        if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
+                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, s)) != TD_OK) return rc;
+        if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
+        if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
+    }
+    {
+        ProfScope ps(PC_GATE, s);
+        if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, S->dirty_rows, S->dirty_count, w.ew, s)) != TD_OK) return rc;
+    }
+    const TdLayer &L0 = m->layers[0];
+    {   // layer 0, x2h: only ligand rows need new projections, only dirty rows need the attention passes
+        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L0.nodeX2h, w.h, Nl, w.lig_node, 0x1f, S->P0, S->q0, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
+    }
+    float4 *xf = nullptr;
+    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true)) != TD_OK) return rc;
+    ProfScope ps(PC_HEAD, s);
+    return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
+                          d_pred_ligand_v, d_final_ligand_h, s);
+}
+
+extern "C" int td_session_dirty_rows(td_session *S, int32_t *host_count, void *stream) {
+    if (!S || !host_count) { td_set_error("td_session_dirty_rows: null pointer"); return TD_EINVAL; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TD_CHECK_HIP(hipMemcpyAsync(host_count, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }

@@ -35,7 +35,10 @@ constexpr float TD_ATT_SCALE = 0.35355339059327373f;   // 1/sqrt(8)   (models/un
 // One wave per dst node, all 128 hidden units (4 N-tiles).  Pure register kernel: no LDS, no barriers.
 __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float4 *__restrict__ x4,
                                                         const int32_t *__restrict__ nbr, int64_t N,
+                                                        const int32_t *__restrict__ rows,
+                                                        const int32_t *__restrict__ count_ptr,
                                                         float *__restrict__ ew) {
+    if (count_ptr) N = *count_ptr;
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, hi = lane >> 5;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
         offk[s] = k < TD_NG ? g.offsets[k] : 0.f;
     }
 
-    for (int64_t i = wave0; i < N; i += nwaves) {
+    for (int64_t it = wave0; it < N; it += nwaves) {
+        const int64_t i = rows ? (int64_t)rows[it] : it;
         const int j = nbr[i * TD_K + c];
         const bool valid = j >= 0;
         const float4 xi = x4[i];
@@ -101,11 +105,12 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
     }
 }
 
-int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, float *ew, hipStream_t s) {
+int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
+                   const int32_t *count_ptr, float *ew, hipStream_t s) {
     if (N == 0) return TD_OK;
     int64_t blocks = (N + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    edge_gate_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, x4, nbr, N, ew);
+    edge_gate_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, x4, nbr, N, rows, count_ptr, ew);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -27,7 +27,8 @@ struct FastArgs {
     const float *ew;
     const float *P;
     const float *q;
-    const int32_t *lig_node;   // key pass of h2x: list of dst nodes (else nullptr)
+    const int32_t *rows;       // optional list of dst nodes (h2x: ligand atoms; session layer 0: dirty rows)
+    const int32_t *count_ptr;  // optional device-side length of `rows` (overrides count)
     float *h;                  // value pass: updated in place
     float *alpha;              // [N][16][32]
     int64_t count;
@@ -51,7 +52,8 @@ __device__ __forceinline__ float td_max32(float v) {
     return fmaxf(a, b);
 }
 
-__device__ __forceinline__ void td_node_range(int64_t count, int64_t &begin, int64_t &end) {
+__device__ __forceinline__ void td_node_range(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end) {
+    if (count_ptr) count = *count_ptr;
     // XCD-aware contiguous node ranges: workgroup b runs on XCD b % 8 -> give XCD x the x-th eighth of the nodes
     const int G = gridDim.x;
     int chunk = blockIdx.x;
@@ -66,7 +68,6 @@ constexpr int KP_R_FLOATS = 2 * 2 * TD_SLOT_STEPS * 64 * 4;      // 12288
 constexpr int KP_WQ_FLOATS = 4 * 16 * 2 * 2 * 16 * 4;            // 16384
 constexpr size_t KP_LDS_BYTES = (size_t)(KP_R_FLOATS + KP_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
-template <bool H2X>
 __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rs = reinterpret_cast<const float4 *>(lds);                       // [cls][slot][12][64 lanes] x 4 tiles
@@ -92,12 +93,12 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
     }
     __syncthreads();
     int64_t begin, end;
-    td_node_range(a.count, begin, end);
+    td_node_range(a.count, a.count_ptr, begin, end);
     const int cq = c & 15;
     const float headmask = c < TD_HEADS ? 1.f : 0.f;
 
     for (int64_t it = begin + wid; it < end; it += 8) {
-        const int64_t i = H2X ? (int64_t)a.lig_node[it] : it;
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
         // ---- geometry: lane (c, hi) owns edge c (both half-waves see the same 32 edges) -----------------------------
         const int j = a.nbr[i * TD_K + c];
         const bool valid = j >= 0;
@@ -263,9 +264,10 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
     }
     __syncthreads();
     int64_t begin, end;
-    td_node_range(a.count, begin, end);
+    td_node_range(a.count, a.count_ptr, begin, end);
 
-    for (int64_t i = begin + wid; i < end; i += 8) {
+    for (int64_t it = begin + wid; it < end; it += 8) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
         // ---- geometry ------------------------------------------------------------------------------------------------
         const int j = a.nbr[i * TD_K + c];
         const bool valid = j >= 0;
@@ -402,29 +404,27 @@ static int fast_grid(int64_t count) {
     return (int)(g < 1 ? 1 : g);
 }
 
-int td_launch_edge_key(bool h2x, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr,
-                       const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
+int td_launch_edge_key(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
+                       const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                        float *alpha, hipStream_t s) {
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key_kernel<true>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)KP_LDS_BYTES));
         attr_set = true;
     }
     FastArgs a;
-    a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.lig_node = lig_node; a.h = nullptr; a.alpha = alpha;
-    a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    if (h2x) edge_key_kernel<true><<<dim3(fast_grid(count)), dim3(512), KP_LDS_BYTES, s>>>(a);
-    else edge_key_kernel<false><<<dim3(fast_grid(count)), dim3(512), KP_LDS_BYTES, s>>>(a);
+    a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
+    a.alpha = alpha; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    edge_key_kernel<<<dim3(fast_grid(count)), dim3(512), KP_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
 int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
-                         int64_t count, float *h, const float *alpha, hipStream_t s) {
+                         const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
+                         hipStream_t s) {
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -433,7 +433,7 @@ int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         attr_set = true;
     }
     FastArgs a;
-    a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.lig_node = nullptr; a.h = h;
+    a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff;
     a.p_off = 2 * TD_H;
     edge_value_kernel<<<dim3(fast_grid(count)), dim3(512), VP_LDS_BYTES, s>>>(a);

@@ -116,14 +116,19 @@ int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int
 // in lane r, i.e. the row comes out sorted ascending.  Graphs larger than 64*CH nodes are scanned in
 // passes; the running best-32 (one per lane 0..31) joins the next pass as an extra candidate.
 constexpr unsigned long long TD_KEY_MAX = ~0ull;
+constexpr int TD_COMPOSE_ATOMS = 16;
 
-template <int CH>
+// STATIC = true builds the protein-only neighbour lists of a sampling session: ligand candidates (x4.w > 0.5) are
+// skipped and the sorted keys are kept (skeys) so that later steps only have to merge the few ligand atoms in.
+template <int CH, bool STATIC>
 __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
-                                                  const int32_t *__restrict__ gid, int64_t N,
-                                                  int32_t *__restrict__ nbr) {
+                                                  const int32_t *__restrict__ gid, const int32_t *__restrict__ rows,
+                                                  int64_t N, int32_t *__restrict__ nbr,
+                                                  unsigned long long *__restrict__ skeys) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= N) return;
+    const int64_t i = rows ? (int64_t)rows[qi] : qi;
     const int g = gid[i];
     const int beg = ptr[g], end = ptr[g + 1];
     const float4 xi = x4[i];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
             if (j < end && j != (int)i) {
                 float4 xj = x4[j];
                 float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
-                key[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+                if (!STATIC || xj.w <= 0.5f) key[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
             }
         }
         unsigned long long carry = best;     // previous passes' winners compete again
@@ -162,34 +167,192 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
         }
         best = out;
     }
-    if (lane < TD_K) nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+    if (lane < TD_K) {
+        nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+        if (STATIC) skeys[i * TD_K + lane] = best;
+    }
+}
+
+template <bool STATIC>
+static int launch_knn_t(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t N,
+                        int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    if (max_graph_nodes > 0 && max_graph_nodes <= 256)
+        knn_kernel<4, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+    else if (max_graph_nodes > 0 && max_graph_nodes <= 384)
+        knn_kernel<6, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+    else if (max_graph_nodes <= 704)         // also the "unknown" (0) default
+        knn_kernel<11, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+    else
+        knn_kernel<17, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
 }
 
 int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, int max_graph_nodes,
                   int32_t *nbr, hipStream_t s) {
-    if (N == 0) return TD_OK;
-    dim3 grid((unsigned)((N + 3) / 4)), block(256);
-    if (max_graph_nodes > 0 && max_graph_nodes <= 256)
-        knn_kernel<4><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
-    else if (max_graph_nodes > 0 && max_graph_nodes <= 384)
-        knn_kernel<6><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
-    else if (max_graph_nodes <= 704)         // also the "unknown" (0) default
-        knn_kernel<11><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
-    else
-        knn_kernel<17><<<grid, block, 0, s>>>(x4, node_ptr, gid, N, nbr);
+    return launch_knn_t<false>(x4, node_ptr, gid, nullptr, N, max_graph_nodes, nbr, nullptr, s);
+}
+
+// kNN of the listed query rows only (ligand atoms of a session step): full search over the query's graph.
+int td_launch_knn_rows(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
+                       int max_graph_nodes, int32_t *nbr, hipStream_t s) {
+    return launch_knn_t<false>(x4, node_ptr, gid, rows, count, max_graph_nodes, nbr, nullptr, s);
+}
+
+// Protein-only neighbour lists + their sorted keys for the listed (protein) rows.
+int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
+                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s) {
+    return launch_knn_t<true>(x4, node_ptr, gid, rows, count, max_graph_nodes, nbr, skeys, s);
+}
+
+// ------------------------------------------------------------------------------------------ session step: kNN merge
+// Protein atoms never move (models/uni_transformer.py:206), so a protein query's neighbours among protein atoms are
+// step-invariant: per step only the <= ~90 ligand atoms of its graph are scored and merged into the static sorted
+// list.  If no ligand atom beats the 32nd static neighbour the row is unchanged ("clean"): its gate row and its
+// layer-0 output are step-invariant too and are copied from the session cache instead of being recomputed.
+// One wave per protein row.  Ligand rows of a graph are contiguous: [node_ptr[g] + n_prot(g), node_ptr[g+1]).
+__global__ __launch_bounds__(256) void knn_merge_kernel(
+    const float4 *__restrict__ x4, const int32_t *__restrict__ ptr, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ gid, const int32_t *__restrict__ prot_rows, int64_t Np,
+    const unsigned long long *__restrict__ skeys, const int32_t *__restrict__ snbr, const float *__restrict__ h0,
+    const float *__restrict__ h1s, const float *__restrict__ ews, int32_t *__restrict__ nbr, float *__restrict__ h,
+    float *__restrict__ ew, uint8_t *__restrict__ clean) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= Np) return;
+    const int64_t i = prot_rows[qi];
+    const int g = gid[i];
+    const int lbeg = ptr[g] + (pptr[g + 1] - pptr[g]), lend = ptr[g + 1];
+    const float4 xi = x4[i];
+    unsigned long long ks = lane < TD_K ? skeys[i * TD_K + lane] : TD_KEY_MAX;
+    const unsigned long long thr = __shfl(ks, TD_K - 1);          // 32nd static neighbour (MAX if fewer exist)
+    unsigned long long kl[2] = {TD_KEY_MAX, TD_KEY_MAX};
+    bool closer = false;
+    bool overflow = lend - lbeg > 128;                            // > 128 ligand atoms: handled by extra passes below
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = lbeg + lane + 64 * u;
+        if (j < lend) {
+            const float4 xj = x4[j];
+            const float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+            kl[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+            closer |= kl[u] < thr;
+        }
+    }
+    bool is_clean = !overflow && __ballot(closer) == 0ull;
+    if (!is_clean) {
+        // merge: 32 rounds of wave-minimum extraction over {static key, 2 ligand keys} (+ further ligand passes)
+        unsigned long long best = ks;
+        for (int base = lbeg; base < lend; base += 128) {
+            if (base != lbeg) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int j = base + lane + 64 * u;
+                    kl[u] = TD_KEY_MAX;
+                    if (j < lend) {
+                        const float4 xj = x4[j];
+                        const float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+                        kl[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+                    }
+                }
+            }
+            unsigned long long carry = best, out = TD_KEY_MAX;
+            for (int r = 0; r < TD_K; ++r) {
+                unsigned long long lmin = carry;
+                lmin = kl[0] < lmin ? kl[0] : lmin;
+                lmin = kl[1] < lmin ? kl[1] : lmin;
+                unsigned long long wmin = lmin;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    unsigned long long o = __shfl_xor(wmin, off);
+                    wmin = o < wmin ? o : wmin;
+                }
+                if (wmin != TD_KEY_MAX) {
+                    if (carry == wmin) carry = TD_KEY_MAX;
+                    if (kl[0] == wmin) kl[0] = TD_KEY_MAX;
+                    if (kl[1] == wmin) kl[1] = TD_KEY_MAX;
+                }
+                if (lane == r) out = wmin;
+            }
+            best = out;
+        }
+        if (lane < TD_K) nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+        // the winners are the 32 smallest of static U ligand; if none of them is a ligand atom the row is still clean
+        const bool lig_in = lane < TD_K && best != TD_KEY_MAX && (int)(unsigned)(best & 0xffffffffull) >= lbeg;
+        is_clean = __ballot(lig_in) == 0ull;
+    } else if (lane < TD_K) {
+        nbr[i * TD_K + lane] = snbr[i * TD_K + lane];
+    }
+    // prepare the step's node state for this row: h = cached layer-0 output (clean) or the embedding h0 (dirty)
+    const float2 hv = *reinterpret_cast<const float2 *>((is_clean ? h1s : h0) + i * TD_H + 2 * lane);
+    *reinterpret_cast<float2 *>(h + i * TD_H + 2 * lane) = hv;
+    if (is_clean && lane < TD_K) ew[i * TD_K + lane] = ews[i * TD_K + lane];
+    if (lane == 0) clean[i] = is_clean ? 1 : 0;
+}
+
+int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                        const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
+                        const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
+                        uint8_t *clean, hipStream_t s) {
+    if (Np == 0) return TD_OK;
+    knn_merge_kernel<<<dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, pptr, gid, prot_rows, Np, skeys,
+                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
+}
+
+// dirty rows = ligand rows + protein rows whose neighbour row changed; order is irrelevant (rows are independent)
+__global__ void compact_dirty_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4, int64_t N,
+                                     int32_t *__restrict__ rows, int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool dirty = i < N && (x4[i].w > 0.5f || !clean[i]);
+    const unsigned long long m = __ballot(dirty);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (dirty) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
+                            hipStream_t s) {
+    if (N == 0) return TD_OK;
+    TD_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    compact_dirty_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(clean, x4, N, rows, count);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// per-step refresh of the ligand rows: x4 = (pos, 1), h = Linear(one_hot(v)) ; 1
+__global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restrict__ lpos, const int64_t *__restrict__ lv,
+                                                            const int32_t *__restrict__ lig_node, int64_t Nl, int C,
+                                                            const float *__restrict__ WlT, const float *__restrict__ bl,
+                                                            float *__restrict__ h, float4 *__restrict__ x4) {
+    const int n = threadIdx.x;
+    const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
+    const float bias = bl[n];
+    for (int a = 0; a < TD_COMPOSE_ATOMS; ++a) {
+        const int64_t at = a0 + a;
+        if (at >= Nl) break;
+        const int64_t p = lig_node[at];
+        int v = (int)lv[at];
+        v = v < 0 ? 0 : (v >= C ? C - 1 : v);
+        h[p * TD_H + n] = WlT[v * TD_H + n] + bias;
+        if (n == 0) x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ compose
 // h0 = [Linear(protein_v) ; 0] / [Linear(one_hot(ligand_v)) ; 1], written straight into the packed
 // (graph-major, protein-then-ligand) node order that compose_context's stable sort produces.
-constexpr int TD_COMPOSE_ATOMS = 16;
 
 __global__ __launch_bounds__(128) void compose_protein_kernel(
     const float *__restrict__ ppos, const float *__restrict__ pv, const int32_t *__restrict__ pptr,
     const int32_t *__restrict__ lptr, int64_t Np, int B, int F, const float *__restrict__ WpT,
-    const float *__restrict__ bp, float *__restrict__ h, float4 *__restrict__ x4, int32_t *__restrict__ gid) {
+    const float *__restrict__ bp, float *__restrict__ h, float4 *__restrict__ x4, int32_t *__restrict__ gid,
+    int32_t *__restrict__ prot_node) {
     __shared__ float s_v[TD_COMPOSE_ATOMS][32];
     const int n = threadIdx.x;
     const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
@@ -214,6 +377,7 @@ __global__ __launch_bounds__(128) void compose_protein_kernel(
         if (n == 0) {
             x4[p] = make_float4(ppos[3 * at], ppos[3 * at + 1], ppos[3 * at + 2], 0.f);
             gid[p] = g;
+            if (prot_node) prot_node[at] = (int32_t)p;
         }
     }
 }
@@ -250,14 +414,15 @@ __global__ void node_ptr_kernel(const int32_t *__restrict__ pptr, const int32_t 
 
 int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
                       const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
-                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, hipStream_t s) {
+                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, int32_t *prot_node,
+                      hipStream_t s) {
     node_ptr_kernel<<<dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s>>>(pptr, lptr, (int)B, node_ptr);
     TD_CHECK_HIP(hipGetLastError());
     if (Np > 0) {
         unsigned nb = (unsigned)((Np + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
         compose_protein_kernel<<<dim3(nb), dim3(128), 0, s>>>(ppos, pv, pptr, lptr, Np, (int)B,
                                                              m->cfg.protein_feat_dim, m->emb.WpT, m->emb.bp, h, x4,
-                                                             gid);
+                                                             gid, prot_node);
         TD_CHECK_HIP(hipGetLastError());
     }
     if (Nl > 0) {
@@ -267,5 +432,15 @@ int td_launch_compose(const td_model *m, const float *ppos, const float *pv, con
                                                             gid, lig_node);
         TD_CHECK_HIP(hipGetLastError());
     }
+    return TD_OK;
+}
+
+int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
+                            float *h, float4 *x4, hipStream_t s) {
+    if (Nl == 0) return TD_OK;
+    unsigned nb = (unsigned)((Nl + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
+    ligand_update_kernel<<<dim3(nb), dim3(128), 0, s>>>(lpos, lv, lig_node, Nl, m->cfg.ligand_num_classes, m->emb.WlT,
+                                                      m->emb.bl, h, x4);
+    TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -104,25 +104,41 @@ int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid,
                   int32_t *nbr, hipStream_t s);
 int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
                       const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
-                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, hipStream_t s);
+                      float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, int32_t *prot_node,
+                      hipStream_t s);
+int td_launch_knn_rows(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
+                       int max_graph_nodes, int32_t *nbr, hipStream_t s);
+int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
+                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s);
+int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                        const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
+                        const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
+                        uint8_t *clean, hipStream_t s);
+int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
+                            hipStream_t s);
+int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
+                            float *h, float4 *x4, hipStream_t s);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
 // node.hip
 // rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
                         float *P, float *q, hipStream_t s);
 // edge.hip
-int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, float *ew, hipStream_t s);
+int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
+                   const int32_t *count_ptr, float *ew, hipStream_t s);
 // mode: 0 x2h key pass, 1 x2h value pass (updates h), 2 h2x key pass, 3 h2x value pass (writes x4_out)
 int td_launch_edge_pass(int mode, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
                         const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
                         float *h, float *alpha, hipStream_t s);
 void td_set_edge_timing(long long *buf, int nodes);
 // edge_fast.hip
-int td_launch_edge_key(bool h2x, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr,
-                       const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
+// rows / count_ptr: optional list of dst nodes and its device-side length (count = upper bound for the launch shape)
+int td_launch_edge_key(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
+                       const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                        float *alpha, hipStream_t s);
 int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
-                         int64_t count, float *h, const float *alpha, hipStream_t s);
+                         const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
+                         hipStream_t s);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);

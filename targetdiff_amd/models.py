@@ -289,11 +289,11 @@ class ScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------------------------------ sampling
     def begin_sampling(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
-                       num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None):
+                       num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None, use_session=True):
         """Set up the reverse-diffusion state on the device and return a :class:`ReverseSampler`
         (``.step()`` = one iteration of the loop at models/molopt_score_model.py:650-693)."""
         return ReverseSampler(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
-                              batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source)
+                              batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session)
 
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
@@ -321,7 +321,7 @@ class ReverseSampler:
 
     @torch.no_grad()
     def __init__(self, model, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
-                 num_steps, center_pos_mode, max_graph_nodes, noise_source):
+                 num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True):
         if center_pos_mode not in ('protein', 'none', None):
             raise NotImplementedError(center_pos_mode)
         dev = protein_pos.device
@@ -352,6 +352,10 @@ class ReverseSampler:
         self.noise_source = noise_source
         self.bufs = {}
         self.s = 0
+        # loop-invariant protein state lives in a native session (td_session); opt out with use_session=False
+        self.session = None
+        if use_session and self.Nl > 0 and self.ppos.shape[0] > 0:
+            self.session = capi.NativeSession(native, self.ppos, self.pv, self.pptr, self.lptr, self.Nl, max_graph_nodes)
 
     @property
     def done(self):
@@ -360,8 +364,11 @@ class ReverseSampler:
     @torch.no_grad()
     def step(self):
         s, native = self.s, self.native
-        preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
-                                     max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
+        if self.session is not None:
+            preds = self.session.forward(self.lpos, self.lv, out=self.bufs)
+        else:
+            preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
+                                         max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
         self.bufs = preds
         if self.noise_source is None:
             noise = torch.randn_like(self.lpos)                                            # :677

@@ -316,6 +316,50 @@ def test_forward_rotation_equivariance(model):
     assert int((dpos < 2e-4).sum()) >= 30 and int((dv < 2e-3).sum()) >= 30
 
 
+# ------------------------------------------------------------------------------------------ sampling session
+@pytest.mark.parametrize('case', ['small', '1h36', 'multi'])
+def test_session_forward_equals_stateless_forward(model, case):
+    """td_session (static-protein caching: merged kNN, cached gate rows / layer-0 rows) must reproduce
+    td_model_forward bit for bit, step after step, and must really skip work (dirty rows << N)."""
+    from targetdiff_amd import capi, workloads
+    dev = _dev()
+    nat = model._native(dev)
+    if case == 'small':
+        from oracle.make_golden import small_batch
+        b, lpos, lv = small_batch()
+    elif case == '1h36':
+        pocket, sizes = pocket_1h36()
+        b = workloads.pack_samples(pocket, 6, sizes[:6])
+        lpos, lv = workloads.init_ligand(b, generator=torch.Generator().manual_seed(5))
+    else:
+        pockets = [workloads.synthetic_pocket(300 + p, 150 + 40 * p) for p in range(3)]
+        b = workloads.pack_samples(pockets, 4, [20, 30, 25, 18] * 3)
+        lpos, lv = workloads.init_ligand(b, generator=torch.Generator().manual_seed(6))
+    b = b.to(dev)
+    lpos, lv = lpos.to(dev), lv.to(dev)
+    B = b.num_graphs
+    pptr = nat.graph_ptr(b.protein_element_batch, B)
+    lptr = nat.graph_ptr(b.ligand_element_batch, B)
+    ppos = b.protein_pos.clone()
+    nat.center_pos(ppos, pptr, lpos, lptr)
+    pv = b.protein_atom_feature.float()
+    sess = capi.NativeSession(nat, ppos, pv, pptr, lptr, lpos.shape[0])
+    g = torch.Generator(device='cpu').manual_seed(9)
+    N = ppos.shape[0] + lpos.shape[0]
+    for step in range(3):
+        want = nat.model_forward(ppos, pv, pptr, lpos, lv, lptr, want_final_h=False)
+        got = sess.forward(lpos, lv)
+        for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+            assert torch.equal(got[k], want[k]), (case, step, k, _maxdiff(got[k], want[k]))
+        dirty = sess.dirty_rows()
+        assert lpos.shape[0] <= dirty <= N
+        if case == '1h36':
+            assert dirty < 0.5 * N, (dirty, N)
+        # move the ligand like a sampling step would (and shuffle the types) before the next comparison
+        lpos = (0.98 * want['pred_ligand_pos'] * 0.02 + 0.98 * lpos + 0.3 * torch.randn(lpos.shape, generator=g).to(dev)).contiguous()
+        lv = torch.randint(0, 13, lv.shape, generator=g).to(dev)
+
+
 # ------------------------------------------------------------------------------------------ posterior / sampling
 def test_posterior_known_answers(model):
     dev = _dev()
