@@ -68,7 +68,8 @@ constexpr int KP_R_FLOATS = 2 * 2 * TD_SLOT_STEPS * 64 * 4;      // 12288
 constexpr int KP_WQ_FLOATS = 4 * 16 * 2 * 2 * 16 * 4;            // 16384
 constexpr size_t KP_LDS_BYTES = (size_t)(KP_R_FLOATS + KP_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
-__global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
+constexpr int KP_WAVES = 12;      // 158 VGPRs -> 3 waves per SIMD; no per-wave LDS, so 12 waves share one copy of the weights
+__global__ __launch_bounds__(KP_WAVES * 64) void edge_key_kernel(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rs = reinterpret_cast<const float4 *>(lds);                       // [cls][slot][12][64 lanes] x 4 tiles
     const float4 *Wq = reinterpret_cast<const float4 *>(lds + KP_R_FLOATS);         // [t][r][jq][hi][c < 16] x 4 j
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
     {
         const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R);
         float4 *rdst = reinterpret_cast<float4 *>(lds);
-        for (int idx = tid; idx < KP_R_FLOATS / 4; idx += 512) rdst[idx] = rsrc[idx];
+        for (int idx = tid; idx < KP_R_FLOATS / 4; idx += KP_WAVES * 64) rdst[idx] = rsrc[idx];
         const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt);
         float4 *wdst = reinterpret_cast<float4 *>(lds + KP_R_FLOATS);
-        for (int idx = tid; idx < KP_WQ_FLOATS / 4; idx += 512) wdst[idx] = wsrc[idx];
+        for (int idx = tid; idx < KP_WQ_FLOATS / 4; idx += KP_WAVES * 64) wdst[idx] = wsrc[idx];
         if (tid < TD_H) lds[KP_R_FLOATS + KP_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[KP_R_FLOATS + KP_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
     }
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
     const int cq = c & 15;
     const float headmask = c < TD_HEADS ? 1.f : 0.f;
 
-    for (int64_t it = begin + wid; it < end; it += 8) {
+    for (int64_t it = begin + wid; it < end; it += KP_WAVES) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
         // ---- geometry: lane (c, hi) owns edge c (both half-waves see the same 32 edges) -----------------------------
         const int j = a.nbr[i * TD_K + c];
@@ -116,32 +117,36 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
         floatx16 acc[4];
         {
             const float *pj = a.P + (size_t)(valid ? j : (int)i) * (4 * TD_H) + a.p_off + TD_H + 4 * hi;
-            const float *pi = a.P + (size_t)i * (4 * TD_H) + a.p_off + 4 * hi;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
                     const float4 vj = *reinterpret_cast<const float4 *>(pj + 32 * t + 8 * qd);
-                    const float4 vi = *reinterpret_cast<const float4 *>(pi + 32 * t + 8 * qd);
-                    acc[t][4 * qd + 0] = vj.x + vi.x;
-                    acc[t][4 * qd + 1] = vj.y + vi.y;
-                    acc[t][4 * qd + 2] = vj.z + vi.z;
-                    acc[t][4 * qd + 3] = vj.w + vi.w;
+                    acc[t][4 * qd + 0] = vj.x;
+                    acc[t][4 * qd + 1] = vj.y;
+                    acc[t][4 * qd + 2] = vj.z;
+                    acc[t][4 * qd + 3] = vj.w;
                 }
         }
+        // The dst-side projection P_i[n] (same for all 32 edges) rides along in the radial MFMA: the table's padding
+        // column k = 21 (k-step 9 of the hi half) gets A = P_i[32t + c], B = 1 for the edge's own source-class slot.
+        float pit[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pit[t] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 32 * t + c];
         float gv[TD_SLOT_STEPS];
 #pragma unroll
         for (int s = 0; s < TD_SLOT_STEPS; ++s) {
             const int k = td_kmap(s, hi);
             const float u = d - offk[s];
-            gv[s] = k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
+            gv[s] = k < TD_NG ? __expf(a.coeff * u * u) : (k <= TD_NG + 1 ? 1.f : 0.f);
         }
         if (has_a) {
             const bool on = valid && slot == 0;
             const float4 *Rp = Rs + (size_t)((cls * 2 + 0) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-                const float4 rfrag = Rp[s * 64];            // A operand: R[kk(s, hi)][32t + c]
+                float4 rfrag = Rp[s * 64];                  // A operand: R[kk(s, hi)][32t + c]
+                if (s == 9 && hi) rfrag = make_float4(pit[0], pit[1], pit[2], pit[3]);
                 const float bv = on ? gv[s] : 0.f;          // B operand: g_kk(d_edge c)
                 acc[0] = td_mfma(rfrag.x, bv, acc[0]);
                 acc[1] = td_mfma(rfrag.y, bv, acc[1]);
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
             const float4 *Rp = Rs + (size_t)((cls * 2 + 1) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-                const float4 rfrag = Rp[s * 64];
+                float4 rfrag = Rp[s * 64];
+                if (s == 9 && hi) rfrag = make_float4(pit[0], pit[1], pit[2], pit[3]);
                 const float bv = on ? gv[s] : 0.f;
                 acc[0] = td_mfma(rfrag.x, bv, acc[0]);
                 acc[1] = td_mfma(rfrag.y, bv, acc[1]);
@@ -229,8 +235,10 @@ __global__ __launch_bounds__(512) void edge_key_kernel(FastArgs a) {
 constexpr int VP_R_FLOATS = KP_R_FLOATS;                 // 12288
 constexpr int VP_W_FLOATS = 32 * TD_H * 4;               // 16384: W2vK[kq][n][4]
 constexpr int VP_ZB_STRIDE = 132;
-constexpr int VP_ZB_FLOATS = 8 * 8 * VP_ZB_STRIDE;       // 8 waves x 8 heads x 132
-constexpr size_t VP_LDS_BYTES = (size_t)(VP_R_FLOATS + VP_W_FLOATS + VP_ZB_FLOATS + 8 * 16 + TD_H) * sizeof(float);
+constexpr int VP_TB_STRIDE = 36;
+constexpr int VP_WAVE_FLOATS = 32 * VP_TB_STRIDE;        // 1152 >= 8 * 132: transpose tile, later reused as Zbar half
+constexpr size_t VP_LDS_BYTES =
+    (size_t)(VP_R_FLOATS + VP_W_FLOATS + 8 * VP_WAVE_FLOATS + 8 * 16 + 3 * TD_H) * sizeof(float);
 
 __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -238,9 +246,10 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
     const float4 *Wv = reinterpret_cast<const float4 *>(lds + VP_R_FLOATS);          // [kq 32][n 128] x 4 k
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = lane & 31, hi = lane >> 5;
-    float *ZB = lds + VP_R_FLOATS + VP_W_FLOATS + wid * 8 * VP_ZB_STRIDE;             // wave-private [8 heads][132]
-    float *SB = lds + VP_R_FLOATS + VP_W_FLOATS + VP_ZB_FLOATS + wid * 16;            // wave-private S[16 heads]
-    float *B2 = lds + VP_R_FLOATS + VP_W_FLOATS + VP_ZB_FLOATS + 8 * 16;              // b2v[128]
+    float *TB = lds + VP_R_FLOATS + VP_W_FLOATS + wid * VP_WAVE_FLOATS;               // wave-private scratch tile
+    float *SB = lds + VP_R_FLOATS + VP_W_FLOATS + 8 * VP_WAVE_FLOATS + wid * 16;      // wave-private S[16 heads]
+    float *B2 = lds + VP_R_FLOATS + VP_W_FLOATS + 8 * VP_WAVE_FLOATS + 8 * 16;        // b2v[128]
+    const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
     {
         const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R);
         float4 *rdst = reinterpret_cast<float4 *>(lds);
@@ -249,12 +258,8 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
         float4 *wdst = reinterpret_cast<float4 *>(lds + VP_R_FLOATS);
         for (int idx = tid; idx < VP_W_FLOATS / 4; idx += 512) wdst[idx] = wsrc[idx];
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
-    }
-    float gam[4], bet[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        gam[t] = a.mlp.gamma[32 * t + c];
-        bet[t] = a.mlp.beta[32 * t + c];
+        else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
+        else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
     }
     float offk[TD_SLOT_STEPS];
 #pragma unroll
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
 
     for (int64_t it = begin + wid; it < end; it += 8) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-        // ---- geometry ------------------------------------------------------------------------------------------------
+        // ---- geometry: lane (c, hi) owns edge c ------------------------------------------------------------------------
         const int j = a.nbr[i * TD_K + c];
         const bool valid = j >= 0;
         const float4 xi = a.x4[i];
@@ -280,41 +285,43 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
         const bool has_a = __ballot(valid && slot == 0) != 0ull;
         const bool has_b = __ballot(valid && slot == 1) != 0ull;
 
-        // ---- first layer in C layout: acc[t][r] = pre[edge erow(r, hi)][hidden 32t + c] -----------------------------
+        // ---- first layer, transposed (as in the key pass): acc[t][r] = pre[hidden 32t + erow(r, hi)][edge c] --------
         floatx16 acc[4];
-        const float *Pj = a.P + a.p_off + TD_H + c;
+        {
+            const float *pj = a.P + (size_t)(valid ? j : (int)i) * (4 * TD_H) + a.p_off + TD_H + 4 * hi;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int4 jv = *reinterpret_cast<const int4 *>(a.nbr + i * TD_K + 8 * qd + 4 * hi);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int jr = rr == 0 ? jv.x : rr == 1 ? jv.y : rr == 2 ? jv.z : jv.w;
-                const float *row = Pj + (size_t)(jr >= 0 ? jr : (int)i) * (4 * TD_H);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t][4 * qd + rr] = row[32 * t];
-            }
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 vj = *reinterpret_cast<const float4 *>(pj + 32 * t + 8 * qd);
+                    acc[t][4 * qd + 0] = vj.x;
+                    acc[t][4 * qd + 1] = vj.y;
+                    acc[t][4 * qd + 2] = vj.z;
+                    acc[t][4 * qd + 3] = vj.w;
+                }
         }
-        float pi[4];
+        float pit[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) pi[t] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 32 * t + c];
+        for (int t = 0; t < 4; ++t) pit[t] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 32 * t + c];
         float gv[TD_SLOT_STEPS];
 #pragma unroll
         for (int s = 0; s < TD_SLOT_STEPS; ++s) {
             const int k = td_kmap(s, hi);
             const float u = d - offk[s];
-            gv[s] = k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f);
+            gv[s] = k < TD_NG ? __expf(a.coeff * u * u) : (k <= TD_NG + 1 ? 1.f : 0.f);
         }
         if (has_a) {
             const bool on = valid && slot == 0;
             const float4 *Rp = Rs + (size_t)((cls * 2 + 0) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-                const float4 b = Rp[s * 64];
-                const float av = on ? gv[s] : 0.f;
-                acc[0] = td_mfma(av, b.x, acc[0]);
-                acc[1] = td_mfma(av, b.y, acc[1]);
-                acc[2] = td_mfma(av, b.z, acc[2]);
-                acc[3] = td_mfma(av, b.w, acc[3]);
+                float4 rfrag = Rp[s * 64];
+                if (s == 9 && hi) rfrag = make_float4(pit[0], pit[1], pit[2], pit[3]);   // P_i rides in padding column k = 21
+                const float bv = on ? gv[s] : 0.f;
+                acc[0] = td_mfma(rfrag.x, bv, acc[0]);
+                acc[1] = td_mfma(rfrag.y, bv, acc[1]);
+                acc[2] = td_mfma(rfrag.z, bv, acc[2]);
+                acc[3] = td_mfma(rfrag.w, bv, acc[3]);
             }
         }
         if (has_b) {
@@ -322,30 +329,35 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
             const float4 *Rp = Rs + (size_t)((cls * 2 + 1) * TD_SLOT_STEPS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < TD_SLOT_STEPS; ++s) {
-                const float4 b = Rp[s * 64];
-                const float av = on ? gv[s] : 0.f;
-                acc[0] = td_mfma(av, b.x, acc[0]);
-                acc[1] = td_mfma(av, b.y, acc[1]);
-                acc[2] = td_mfma(av, b.z, acc[2]);
-                acc[3] = td_mfma(av, b.w, acc[3]);
+                float4 rfrag = Rp[s * 64];
+                if (s == 9 && hi) rfrag = make_float4(pit[0], pit[1], pit[2], pit[3]);
+                const float bv = on ? gv[s] : 0.f;
+                acc[0] = td_mfma(rfrag.x, bv, acc[0]);
+                acc[1] = td_mfma(rfrag.y, bv, acc[1]);
+                acc[2] = td_mfma(rfrag.z, bv, acc[2]);
+                acc[3] = td_mfma(rfrag.w, bv, acc[3]);
             }
         }
 
-        // ---- LayerNorm + ReLU in C layout (row statistics: DPP reductions over the 32 lanes of a half wave) ---------
+        // ---- LayerNorm over the 128 hidden units of edge c: in-lane sums + one exchange between the half waves ------
+        float s1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v0 = acc[0][r] + pi[0], v1 = acc[1][r] + pi[1], v2 = acc[2][r] + pi[2], v3 = acc[3][r] + pi[3];
-            const float mean = td_sum32((v0 + v1) + (v2 + v3)) * (1.0f / TD_H);
-            const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
-            const float var = td_sum32(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3)) * (1.0f / TD_H);
-            const float rstd = __frsqrt_rn(var + 1e-5f);
-            acc[0][r] = fmaxf(fmaf(d0 * rstd, gam[0], bet[0]), 0.f);
-            acc[1][r] = fmaxf(fmaf(d1 * rstd, gam[1], bet[1]), 0.f);
-            acc[2][r] = fmaxf(fmaf(d2 * rstd, gam[2], bet[2]), 0.f);
-            acc[3][r] = fmaxf(fmaf(d3 * rstd, gam[3], bet[3]), 0.f);
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1 += acc[t][r];
+        const float mean = td_sum_halves(s1) * (1.0f / TD_H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dv = acc[t][r] - mean;
+                s2 = fmaf(dv, dv, s2);
+            }
+        const float rstd = __frsqrt_rn(td_sum_halves(s2) * (1.0f / TD_H) + 1e-5f);
+        const float nms = -mean * rstd;
 
-        // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k]: A = alpha^T (lane = head row), B = z as it sits in acc ----
+        // ---- attention weights of this node: A operand of the aggregation product (lane = head row) ----------------
         float al[16];
         {
             const float *ap = a.alpha + ((size_t)i * TD_HEADS + (c & 15)) * TD_K + 4 * hi;
@@ -361,20 +373,32 @@ __global__ __launch_bounds__(512) void edge_value_kernel(FastArgs a) {
         for (int s = 0; s < 16; ++s) ssum += al[s];
         ssum = td_sum_halves(ssum);                      // S[head c] = sum over all 32 edges
         if (lane < TD_HEADS) SB[lane] = ssum;
+
+        // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k].  z^T (lane = edge) is normalised tile by tile, flipped
+        //      through the wave-private LDS tile into the B-operand layout (lane = hidden unit) and consumed at once.
         floatx16 zb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float4 gm = *reinterpret_cast<const float4 *>(GAM + 32 * t + 8 * qd + 4 * hi);
+                const float4 bm = *reinterpret_cast<const float4 *>(BET + 32 * t + 8 * qd + 4 * hi);
+                float4 z;
+                z.x = fmaxf(fmaf(fmaf(acc[t][4 * qd + 0], rstd, nms), gm.x, bm.x), 0.f);
+                z.y = fmaxf(fmaf(fmaf(acc[t][4 * qd + 1], rstd, nms), gm.y, bm.y), 0.f);
+                z.z = fmaxf(fmaf(fmaf(acc[t][4 * qd + 2], rstd, nms), gm.z, bm.z), 0.f);
+                z.w = fmaxf(fmaf(fmaf(acc[t][4 * qd + 3], rstd, nms), gm.w, bm.w), 0.f);
+                *reinterpret_cast<float4 *>(TB + c * VP_TB_STRIDE + 8 * qd + 4 * hi) = z;      // row = edge c, col = erow(r, hi)
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) zb[t][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            zb[0] = td_mfma(al[s], acc[0][s], zb[0]);
-            zb[1] = td_mfma(al[s], acc[1][s], zb[1]);
-            zb[2] = td_mfma(al[s], acc[2][s], zb[2]);
-            zb[3] = td_mfma(al[s], acc[3][s], zb[3]);
+            for (int s = 0; s < 16; ++s)                 // B[e = erow(s, hi)][k = 32t + c]
+                zb[t] = td_mfma(al[s], TB[td_erow(s, hi) * VP_TB_STRIDE + c], zb[t]);
         }
 
         // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -----
+        float *ZB = TB;
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             // heads 8ph .. 8ph+7 live in rows r = 4ph + rr of half hi: head = rr + 8ph + 4hi
@@ -417,7 +441,7 @@ int td_launch_edge_key(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4,
     FastArgs a;
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    edge_key_kernel<<<dim3(fast_grid(count)), dim3(512), KP_LDS_BYTES, s>>>(a);
+    edge_key_kernel<<<dim3(fast_grid(count)), dim3(KP_WAVES * 64), KP_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
