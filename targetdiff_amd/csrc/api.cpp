@@ -142,11 +142,12 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int alt) {
     EdgeOff o;
     o.Walt = 0;
+    o.Walt16 = 0;
     // first layer radial / type table: [cls][slot][kstep][lane][ntile]
     o.R = pk.alloc((size_t)2 * 2 * TD_SLOT_STEPS * 64 * 4);
     float *d = pk.data.data() + o.R;
@@ -164,6 +165,24 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
                         d[((((size_t)cls * 2 + sl) * TD_SLOT_STEPS + s) * 64 + lane) * 4 + t] = v;
                     }
         }
+    // the same table for 16x16x4 tiles: [cls][slot][step][lane][hb], lane = (lo = hidden_local, g = k index in step)
+    o.R16 = pk.alloc((size_t)2 * 2 * 6 * 64 * 8);
+    {
+        float *d16 = pk.data.data() + o.R16;
+        for (int cls = 0; cls < 2; ++cls)
+            for (int sl = 0; sl < 2; ++sl) {
+                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+                for (int st = 0; st < 6; ++st)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int hb = 0; hb < 8; ++hb) {
+                            const int kk = 4 * st + (lane >> 4), n = 16 * hb + (lane & 15);
+                            float v = 0.f;
+                            if (kk < TD_NG) v = m.w0[(size_t)n * in_dim + 4 + TD_NG * type + kk];
+                            else if (kk == TD_NG) v = m.w0[(size_t)n * in_dim + type];
+                            d16[((((size_t)cls * 2 + sl) * 6 + st) * 64 + lane) * 8 + hb] = v;
+                        }
+            }
+    }
     o.gamma = pack_vec(pk, m.g, TD_H);
     o.beta = pack_vec(pk, m.b, TD_H);
     if (out_dim == TD_H) {
@@ -192,6 +211,17 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
                                 q[((((((size_t)t * 16 + r) * 2 + jq) * 2 + hi) * 16 + c) * 4) + jj] =
                                     m.w3[(size_t)(8 * c + 4 * jq + jj) * TD_H + n];
                             }
+        o.Walt16 = pk.alloc((size_t)8 * 4 * 2 * 64 * 4);
+        float *q16 = pk.data.data() + o.Walt16;
+        for (int hb = 0; hb < 8; ++hb)
+            for (int r = 0; r < 4; ++r)
+                for (int jq = 0; jq < 2; ++jq)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int head = lane & 15, k = 16 * hb + 4 * (lane >> 4) + r;
+                            q16[(((((size_t)hb * 4 + r) * 2 + jq) * 64 + lane) * 4) + jj] =
+                                m.w3[(size_t)(8 * head + 4 * jq + jj) * TD_H + k];
+                        }
     } else if (alt == 2) {   // value MLP of x2h: W2vK[k/4][n][k%4]
         o.Walt = pk.alloc((size_t)32 * TD_H * 4);
         float *q = pk.data.data() + o.Walt;
@@ -339,7 +369,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     const float *D = m->blob;
     m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
-    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.Walt}; };
+    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt}; };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias};
     };
@@ -394,10 +424,26 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
 
 // TD_EDGE_IMPL=plain selects the straightforward key/value kernels (edge.hip: per-edge k and v vectors are
 // materialised) instead of the re-associated ones (edge_fast.hip); used for A/B timing and as a cross-check.
-bool fast_edges() {
+// TD_EDGE_IMPL: "plain" (edge.hip, materialised k/v), "fast32" (edge_fast.hip, 32x32x2 tiles) or the default
+// "fast16" (edge16.hip, 16x16x4 tiles).
+int edge_impl() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("TD_EDGE_IMPL"); v = (e && strcmp(e, "plain") == 0) ? 0 : 1; }
-    return v == 1;
+    if (v < 0) {
+        const char *e = getenv("TD_EDGE_IMPL");
+        v = !e ? 2 : (strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "fast32") == 0 ? 1 : 2));
+    }
+    return v;
+}
+bool fast_edges() { return edge_impl() != 0; }
+int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
+             const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
+    return edge_impl() == 1 ? td_launch_edge_key(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s)
+                            : td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s);
+}
+int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
+               const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, hipStream_t s) {
+    return edge_impl() == 1 ? td_launch_edge_value(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s)
+                            : td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s);
 }
 
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
@@ -416,8 +462,8 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         if (l == 0 && layer0_x2h_done) goto h2x_stage;
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
         if (fast_edges()) {
-            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L.hv, L, xc, w.nbr, w.P, nullptr, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, nullptr, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
         } else {
             { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
             { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
@@ -431,7 +477,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
             if (fast_edges()) {
                 ProfScope ps(PC_H2X_K, s);
-                if ((rc = td_launch_edge_key(L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, nullptr, Nl, w.alpha, s)) != TD_OK) return rc;
+                if ((rc = key_pass(L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, nullptr, Nl, w.alpha, s)) != TD_OK) return rc;
             } else {
                 ProfScope ps(PC_H2X_K, s);
                 if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc;
@@ -679,9 +725,9 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
     const TdLayer &L0 = m->layers[0];
     TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
-    TD_TRY(td_launch_edge_key(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
+    TD_TRY(key_pass(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
     TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-    TD_TRY(td_launch_edge_value(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, s));
+    TD_TRY(value_pass(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, s));
 #undef TD_TRY
 #undef TD_TRY_HIP
     *out = S;
@@ -724,8 +770,8 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     const TdLayer &L0 = m->layers[0];
     {   // layer 0, x2h: only ligand rows need new projections, only dirty rows need the attention passes
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L0.nodeX2h, w.h, Nl, w.lig_node, 0x1f, S->P0, S->q0, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_key(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
     }
     float4 *xf = nullptr;
     if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true)) != TD_OK) return rc;

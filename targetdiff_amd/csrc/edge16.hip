@@ -1,0 +1,380 @@
+// Key / value passes on v_mfma_f32_16x16x4_f32 tiles (gfx950).  Same re-associated arithmetic as edge_fast.hip
+// (logits = z . U_i, out = W2v . (alpha^T z)); the 16-row tile matches the 16 attention heads exactly, so the two
+// head-shaped products cost 64 x 32 cycles instead of 64 x 64 and the U_i build uses all 64 lanes.
+//
+// Lane coordinates: lo = lane & 15, g = lane >> 4.   16x16x4 fragment maps (cdna_hip_programming.md section 3):
+//   A: lane holds A[row = lo][k = g]      B: lane holds B[k = g][col = lo]      C/D: reg r holds D[row = 4g + r][col = lo]
+//
+// First layer, transposed (rows = hidden units, columns = edges), 8 hidden blocks x 2 edge blocks of 16 x 16:
+//   acc[eb][hb][r] = pre[hidden 16hb + 4g + r][edge 16eb + lo]
+// so one lane owns, for each of its two edges, 32 of the 128 hidden units; the other 96 sit in lanes lo + 16 g'.
+// LayerNorm = in-lane sums + two lane-group exchanges.  The normalised z^T is directly the B operand of the
+// logits product (k-step (hb, r) pairs lane group g with hidden unit 16hb + 4g + r on both operands).
+#include "td_device.h"
+#include "td_internal.h"
+
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ floatx4_t td_mfma16(float a, float b, floatx4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr float TD_ATT_SCALE_16 = 0.35355339059327373f;   // 1/sqrt(8)
+constexpr int E16_STEPS = TD_SLOTK / 4;                    // 6 k-steps of 4 over the 24-wide radial/type slot
+constexpr int E16_R_FLOATS = 2 * 2 * E16_STEPS * 64 * 8;   // [cls][slot][step][lane][hb]   = 12288
+constexpr int E16_WQ_FLOATS = 8 * 4 * 2 * 64 * 4;          // [hb][r][jq][lane][4 j]        = 16384
+
+struct Args16 {
+    const float4 *x4;
+    const int32_t *nbr;
+    const float *ew;
+    const float *P;
+    const float *q;
+    const int32_t *rows;
+    const int32_t *count_ptr;
+    float *h;
+    float *alpha;
+    int64_t count;
+    TdEdgeMlp mlp;
+    const float *offsets;
+    float coeff;
+    int p_off;
+};
+
+__device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end) {
+    if (count_ptr) count = *count_ptr;
+    const int G = gridDim.x;
+    int chunk = blockIdx.x;
+    if ((G & 7) == 0) chunk = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD x gets the x-th eighth
+    const int64_t per = (count + G - 1) / G;
+    begin = (int64_t)chunk * per;
+    end = begin + per < count ? begin + per : count;
+}
+
+// sum / max over the 4 lane groups g (lanes lo, lo+16, lo+32, lo+48), result in all four
+__device__ __forceinline__ float td_sum_groups(float v) { return td_sum_halves(td_sum_rows16(v)); }
+
+// reductions over the 16 lanes of a DPP row (fixed g), result in every lane of the row
+__device__ __forceinline__ float td_sum16(float v) {
+    v += td_dpp<DPP_QUAD_XOR1>(v);
+    v += td_dpp<DPP_QUAD_XOR2>(v);
+    v += td_dpp<DPP_ROW_HALF_MIRROR>(v);
+    v += td_dpp<DPP_ROW_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float td_max16(float v) {
+    v = fmaxf(v, td_dpp<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, td_dpp<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, td_dpp<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, td_dpp<DPP_ROW_MIRROR>(v));
+    return v;
+}
+
+// ---- first layer + LayerNorm + ReLU of one dst node: z^T in acc[eb][hb] ------------------------------------------------
+struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
+    bool valid[2];
+    float ew[2];
+};
+
+template <bool LOAD_EW>
+__device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
+                                                 const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                 const float (&offk)[E16_STEPS], int64_t i, int lane,
+                                                 floatx4_t (&acc)[2][8], Edge2 &ed) {
+    const int lo = lane & 15, g = lane >> 4;
+    const float4 xi = a.x4[i];
+    const int cls = xi.w > 0.5f ? 0 : 1;
+    float dist[2];
+    int slot[2];
+    bool any_a = false, any_b = false;
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        const int j = a.nbr[i * TD_K + 16 * eb + lo];
+        ed.valid[eb] = j >= 0;
+        const float4 xj = a.x4[ed.valid[eb] ? j : i];
+        if (LOAD_EW) ed.ew[eb] = a.ew[i * TD_K + 16 * eb + lo];
+        const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
+        dist[eb] = sqrtf(rx * rx + ry * ry + rz * rz);
+        slot[eb] = xj.w > 0.5f ? 0 : 1;
+        any_a |= ed.valid[eb] && slot[eb] == 0;
+        any_b |= ed.valid[eb] && slot[eb] == 1;
+        // neighbour-side projection P_j, 16 bytes per hidden block: hidden 16hb + 4g .. + 3
+        const float *pj = a.P + (size_t)(ed.valid[eb] ? j : (int)i) * (4 * TD_H) + a.p_off + TD_H + 4 * g;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            const float4 v = *reinterpret_cast<const float4 *>(pj + 16 * hb);
+            acc[eb][hb][0] = v.x; acc[eb][hb][1] = v.y; acc[eb][hb][2] = v.z; acc[eb][hb][3] = v.w;
+        }
+    }
+    const bool has_a = __ballot(any_a) != 0ull, has_b = __ballot(any_b) != 0ull;
+    // dst-side projection P_i rides in the table's padding column k = 21 (k-step 5, lane group 1)
+    float pit[8];
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) pit[hb] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 16 * hb + lo];
+    float gv[2][E16_STEPS];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int s = 0; s < E16_STEPS; ++s) {
+            const int k = 4 * s + g;
+            const float u = dist[eb] - offk[s];
+            gv[eb][s] = k < TD_NG ? __expf(a.coeff * u * u) : (k <= TD_NG + 1 ? 1.f : 0.f);
+        }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        if (sl == 0 ? !has_a : !has_b) continue;
+        const float4 *Rp = Rt + (size_t)((cls * 2 + sl) * E16_STEPS) * 128 + lane * 2;
+#pragma unroll
+        for (int s = 0; s < E16_STEPS; ++s) {
+            const float4 r0 = Rp[s * 128], r1 = Rp[s * 128 + 1];
+            float av[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};     // A: R[k = 4s + g][hidden 16hb + lo]
+            if (s == 5 && g == 1) {
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb) av[hb] = pit[hb];
+            }
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                const float bv = (ed.valid[eb] && slot[eb] == sl) ? gv[eb][s] : 0.f;   // B: g_k(d_edge) for the edge's slot
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb) acc[eb][hb] = td_mfma16(av[hb], bv, acc[eb][hb]);
+            }
+        }
+    }
+    // ---- LayerNorm over the 128 hidden units of each edge + ReLU ---------------------------------------------------
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
+        const float mean = td_sum_groups(s1) * (1.0f / TD_H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dv = acc[eb][hb][r] - mean;
+                s2 = fmaf(dv, dv, s2);
+            }
+        const float rstd = __frsqrt_rn(td_sum_groups(s2) * (1.0f / TD_H) + 1e-5f);
+        const float nms = -mean * rstd;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            const float4 gm = *reinterpret_cast<const float4 *>(GAM + 16 * hb + 4 * g);
+            const float4 bm = *reinterpret_cast<const float4 *>(BET + 16 * hb + 4 * g);
+            acc[eb][hb][0] = fmaxf(fmaf(fmaf(acc[eb][hb][0], rstd, nms), gm.x, bm.x), 0.f);
+            acc[eb][hb][1] = fmaxf(fmaf(fmaf(acc[eb][hb][1], rstd, nms), gm.y, bm.y), 0.f);
+            acc[eb][hb][2] = fmaxf(fmaf(fmaf(acc[eb][hb][2], rstd, nms), gm.z, bm.z), 0.f);
+            acc[eb][hb][3] = fmaxf(fmaf(fmaf(acc[eb][hb][3], rstd, nms), gm.w, bm.w), 0.f);
+        }
+    }
+}
+
+// ================================================================================================ key pass
+constexpr int K16_WAVES = 12;
+constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
+
+__global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);       // [hb][r][jq][lane] x 4 j
+    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    {
+        const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R16);
+        float4 *rdst = reinterpret_cast<float4 *>(lds);
+        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += K16_WAVES * 64) rdst[idx] = rsrc[idx];
+        const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt16);
+        float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
+        for (int idx = tid; idx < E16_WQ_FLOATS / 4; idx += K16_WAVES * 64) wdst[idx] = wsrc[idx];
+        if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
+        else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
+    }
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+
+    for (int64_t it = begin + wid; it < end; it += K16_WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        floatx4_t acc[2][8];
+        Edge2 ed;
+        td_first_layer16<true>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+
+        // ---- logits^T[head][edge] = sum_k U_i[k][head] z[k][edge];  A = U_i built from q_i: lane (head lo, group g) ----
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+        floatx4_t lg[2];
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
+                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
+                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+            }
+
+        // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate -------------------------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+            const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+            float mx = td_max16(fmaxf(x0, x1));
+            if (mx == -INFINITY) mx = 0.f;
+            const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
+            const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
+            const float sm = td_sum16(p0 + p1);
+            const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
+            float *dst = a.alpha + ((size_t)i * TD_HEADS + 4 * g + r) * TD_K + lo;
+            dst[0] = p0 * inv * ed.ew[0];
+            dst[16] = p1 * inv * ed.ew[1];
+        }
+    }
+}
+
+// ================================================================================================ value pass (x2h)
+constexpr int V16_WAVES = 8;
+constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
+constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidden + 4]
+constexpr int V16_ZB_STRIDE = 132;
+constexpr int V16_WAVE_FLOATS = 8 * V16_ZB_STRIDE;        // 1056 >= 32 * 20: transpose tile, later the Zbar half
+constexpr size_t V16_LDS_BYTES =
+    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
+
+__global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float4 *Wv = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);          // [kq 32][n 128] x 4 k
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    float *TB = lds + E16_R_FLOATS + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
+    float *SB = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
+    float *B2 = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
+    const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
+    {
+        const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R16);
+        float4 *rdst = reinterpret_cast<float4 *>(lds);
+        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += V16_WAVES * 64) rdst[idx] = rsrc[idx];
+        const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt);
+        float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
+        for (int idx = tid; idx < V16_W_FLOATS / 4; idx += V16_WAVES * 64) wdst[idx] = wsrc[idx];
+        if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
+        else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
+        else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
+    }
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+
+    for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        floatx4_t acc[2][8];
+        Edge2 ed;
+        td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+
+        // ---- A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads) ----------
+        float al[8];
+        {
+            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+            al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
+        }
+        float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
+        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
+        if (lane < TD_HEADS) SB[lane] = ssum;
+
+        // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time: flip z^T (lane = edge) through
+        //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
+        floatx4_t zb[8];
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb)
+                *reinterpret_cast<float4 *>(TB + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                    make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+            zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s)                // B[edge 8g + s][hidden 16hb + lo]
+                zb[hb] = td_mfma16(al[s], TB[(8 * g + s) * V16_TB_STRIDE + lo], zb[hb]);
+        }
+
+        // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -------
+        // zb[hb][r] = Zbar[head 4g + r][hidden 16hb + lo]; heads 8ph .. 8ph+7 sit in lane groups g = 2ph, 2ph + 1
+        float *ZB = TB;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((g >> 1) == ph) {
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
+            }
+            const int n = 64 * ph + lane;
+            const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
+            float o = B2[n] * SB[8 * ph + (lane >> 3)];
+#pragma unroll 8
+            for (int kq = 0; kq < 32; ++kq) {
+                const float4 w = Wv[kq * TD_H + n];
+                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
+                o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
+            }
+            a.h[(size_t)i * TD_H + n] += o;
+        }
+    }
+}
+
+// ================================================================================================ launchers
+static int grid16(int64_t count, int waves) {
+    int64_t g = (count + waves - 1) / waves;
+    if (g > 256) g = 256;
+    if (g >= 8) g = (g / 8) * 8;
+    return (int)(g < 1 ? 1 : g);
+}
+
+int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
+                         const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
+                         float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
+        attr_set = true;
+    }
+    Args16 a;
+    a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
+    a.alpha = alpha; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    edge_key16_kernel<<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
+                           const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
+                           hipStream_t s) {
+    if (count == 0) return TD_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_value16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS_BYTES));
+        attr_set = true;
+    }
+    Args16 a;
+    a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
+    a.alpha = const_cast<float *>(alpha); a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff;
+    a.p_off = 2 * TD_H;
+    edge_value16_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

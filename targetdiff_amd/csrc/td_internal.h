@@ -38,6 +38,8 @@ struct TdEdgeMlp {
     const float *beta;     // [128] LayerNorm bias
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]
+    const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
+    const float *Walt16;   // key MLPs: Wq16[hb][r][jq][lane][4] = W2[8 lo + 4jq + jj][16hb + 4g + r]
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
 };
 
@@ -139,6 +141,13 @@ int td_launch_edge_key(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4,
 int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                          const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                          hipStream_t s);
+// edge16.hip (16x16x4 MFMA variants of the two passes; default)
+int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
+                         const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
+                         float *alpha, hipStream_t s);
+int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
+                           const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
+                           hipStream_t s);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);
