@@ -170,7 +170,7 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 }
 
 // ================================================================================================ key pass
-constexpr int K16_WAVES = 12;
+constexpr int K16_WAVES = 16;
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
 __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {

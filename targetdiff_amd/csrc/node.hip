@@ -9,42 +9,70 @@
 //
 // Work decomposition: workgroup = 4 waves, wave w owns 32 consecutive nodes (M = 32 rows of the MFMA
 // tile) and all 128 output columns (4 N-tiles -> 64 accumulator VGPRs).  A operands (the 32 x 128 h tile)
-// stay in registers for all six GEMMs; B operands stream from L2 in pre-packed fragment order
-// (one coalesced 1 KiB dwordx4 load feeds 4 MFMAs).
+// stay in registers for all six GEMMs; B operands (pre-packed fragment order) are staged through LDS in 16 KiB
+// chunks shared by the workgroup's 4 waves (gemm128_lds).
 #include "td_device.h"
 #include "td_internal.h"
 
-constexpr int ZSTRIDE = 132;     // 128 + 4: conflict-free ds_read_b128 of rows (stride/4 odd)
+constexpr int NP_CHUNK_STEPS = 16;                       // k-steps per staged B chunk
+constexpr int NP_CHUNK_F4 = NP_CHUNK_STEPS * 64;         // float4 per chunk (16 KiB)
+constexpr int NP_CHUNKS = TD_KSTEPS / NP_CHUNK_STEPS;    // 4 chunks per 128-deep GEMM
+constexpr int NP_TSTRIDE = 36;                           // transpose tile [32 rows][32 + 4]
+constexpr size_t NP_LDS_BYTES = (size_t)(2 * NP_CHUNK_F4 * 4 + 4 * 32 * NP_TSTRIDE) * sizeof(float);
 
-// 128-deep GEMM of one 32-row A tile against all 4 N tiles.  B fragments stream from L2 (~600-900 cycles); a
-// ring of PF 16-byte loads is kept in flight explicitly (hipcc on its own keeps 1-2, which left the kernel
-// latency-bound: 4 MFMAs = 256 cycles per k-step).
-constexpr int PF = 6;
-__device__ __forceinline__ void gemm128(const float4 (&a)[16], const float4 *__restrict__ B, int lane,
-                                        floatx16 (&acc)[4]) {
-    float4 ring[PF];
+// 16-byte-per-lane async global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane * 16.
+__device__ __forceinline__ void td_glds16(const float4 *gsrc_lane, float4 *lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// 128-deep GEMM of one 32-row A tile (registers) against all 4 N tiles.  The B fragments of the workgroup's current
+// weight matrix are staged through LDS in 16 KiB chunks shared by its 4 waves (one L2 read per workgroup instead of
+// one per wave; LDS latency instead of L2 latency in front of every 4 MFMAs): while chunk c is consumed from
+// buffer c & 1, every thread fetches its 64 bytes of chunk c + 1 into registers and stores them to the other
+// buffer afterwards.  One barrier per chunk.  `next` = first chunk of the matrix that follows (or nullptr).
+__device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 *__restrict__ B,
+                                            const float4 *__restrict__ next, float4 *__restrict__ bufs, int &cur,
+                                            int tid, int lane, floatx16 (&acc)[4]) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s) ring[s] = B[s * 64 + lane];
+    for (int ch = 0; ch < NP_CHUNKS; ++ch) {
+        const float4 *src = ch + 1 < NP_CHUNKS ? B + (size_t)(ch + 1) * NP_CHUNK_F4 : next;
+        if (src) {
+            // async global -> LDS copy of the next chunk (no staging registers): each wave-instruction moves
+            // 64 x 16 B to a wave-uniform LDS base + lane * 16; the barrier below waits for it (vmcnt(0)).
+            float4 *dst = bufs + (cur ^ 1) * NP_CHUNK_F4 + (tid & ~63);
 #pragma unroll
-    for (int s = 0; s < TD_KSTEPS; ++s) {
-        const float4 b = ring[s % PF];
-        if (s + PF < TD_KSTEPS) ring[s % PF] = B[(s + PF) * 64 + lane];
-        const float4 am = a[s >> 2];
-        const float av = (s & 3) == 0 ? am.x : (s & 3) == 1 ? am.y : (s & 3) == 2 ? am.z : am.w;
-        acc[0] = td_mfma(av, b.x, acc[0]);
-        acc[1] = td_mfma(av, b.y, acc[1]);
-        acc[2] = td_mfma(av, b.z, acc[2]);
-        acc[3] = td_mfma(av, b.w, acc[3]);
+            for (int u = 0; u < 4; ++u)
+                td_glds16(src + u * 256 + tid, dst + u * 256);
+        }
+        const float4 *bl = bufs + cur * NP_CHUNK_F4 + lane;
+#pragma unroll
+        for (int s = 0; s < NP_CHUNK_STEPS; ++s) {
+            const float4 b = bl[s * 64];
+            const float4 am = a[(ch * NP_CHUNK_STEPS + s) >> 2];
+            const float av = (s & 3) == 0 ? am.x : (s & 3) == 1 ? am.y : (s & 3) == 2 ? am.z : am.w;
+            acc[0] = td_mfma(av, b.x, acc[0]);
+            acc[1] = td_mfma(av, b.y, acc[1]);
+            acc[2] = td_mfma(av, b.z, acc[2]);
+            acc[3] = td_mfma(av, b.w, acc[3]);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 B fragments (16 VGPRs) in flight
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 }
 
 // mat_mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP.  rows != nullptr: process only
 // the listed node ids (h2x needs the dst-side projections and queries of ligand atoms only).
 __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
-                                                        const int32_t *__restrict__ rows, unsigned mat_mask,
-                                                        float *__restrict__ P, float *__restrict__ q) {
-    extern __shared__ __attribute__((aligned(16))) float zbuf[];     // [4 waves][32 rows][ZSTRIDE]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                           const int32_t *__restrict__ rows, unsigned mat_mask,
+                                                           float *__restrict__ P, float *__restrict__ q) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;          // wave-private transpose tile
     const int c = lane & 31, hi = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
     const int64_t aslot = row0 + c;
@@ -55,80 +83,83 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
     for (int m = 0; m < 16; ++m)
         a[m] = (arow >= 0) ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
-    // output row of each C-layout register row
-    int64_t orow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    // output row of C-layout register row r (recomputed at store time: 16 fewer live VGPRs)
+    auto out_row = [&](int r) -> int {
         const int64_t slot = row0 + td_erow(r, hi);
-        orow[r] = slot < N ? (rows ? (int64_t)rows[slot] : slot) : -1;
-    }
+        return slot < N ? (rows ? rows[slot] : (int)slot) : -1;
+    };
 
+    // the matrices this launch walks through, in order: selected projections, then q.net.0, then q.net.3
     const float4 *Bp = reinterpret_cast<const float4 *>(st.projB);
+    const float4 *seq[6];
+    int mats[6], nseq = 0;
+    for (int mat = 0; mat < 5; ++mat)
+        if ((mat_mask >> mat) & 1u) { seq[nseq] = Bp + (size_t)mat * TD_KSTEPS * 64; mats[nseq++] = mat; }
+    if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(st.q3B); mats[nseq++] = 5; }
+    // prologue: first chunk of the first matrix
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bufs[u * 256 + tid] = seq[0][u * 256 + tid];
+    __syncthreads();
+    int cur = 0;
+
     floatx16 acc[4];
-    for (int mat = 0; mat < 4; ++mat) {
-        if (!((mat_mask >> mat) & 1u)) continue;
+    for (int si = 0; si < nseq; ++si) {
+        const int mat = mats[si];
+        const float *bias = mat < 5 ? st.projBias + mat * TD_H : st.q3Bias;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float bias = st.projBias[mat * TD_H + 32 * t + c];
+            const float bv = bias[32 * t + c];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = bias;
+            for (int r = 0; r < 16; ++r) acc[t][r] = bv;
         }
-        gemm128(a, Bp + (size_t)mat * TD_KSTEPS * 64, lane, acc);
+        const float4 *next = si + 1 < nseq ? seq[si + 1] : nullptr;
+        gemm128_lds(a, seq[si], next, bufs, cur, tid, lane, acc);     // for q.net.3 `a` holds the normalised hidden tile
+        if (mat < 4) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (orow[r] >= 0) {
+            for (int r = 0; r < 16; ++r) {
+                const int orow = out_row(r);
+                if (orow >= 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) P[orow[r] * (4 * TD_H) + mat * TD_H + 32 * t + c] = acc[t][r];
+                    for (int t = 0; t < 4; ++t) P[(size_t)orow * (4 * TD_H) + mat * TD_H + 32 * t + c] = acc[t][r];
+                }
             }
-        }
-    }
-    if (!((mat_mask >> 4) & 1u)) return;      // uniform over the workgroup: no barrier is skipped by a subset
-
-    // ---- query MLP: Linear -> LayerNorm -> ReLU -> Linear (models/common.py:60-80) -------------------
+        } else if (mat == 4) {
+            // ---- query MLP: LayerNorm -> ReLU on the first Linear's output, then C layout -> A layout (into a) ---------
+            float gam[4], bet[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float bias = st.projBias[4 * TD_H + 32 * t + c];
+            for (int t = 0; t < 4; ++t) {
+                gam[t] = st.qGamma[32 * t + c];
+                bet[t] = st.qBeta[32 * t + c];
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = bias;
-    }
-    gemm128(a, Bp + (size_t)4 * TD_KSTEPS * 64, lane, acc);
-    float gam[4], bet[4];
+            for (int r = 0; r < 16; ++r) {
+                const float s1 = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+                const float mean = td_sum32(s1) * (1.0f / TD_H);
+                const float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
+                const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H);
+                const float rstd = __frsqrt_rn(var + 1e-5f);
+                acc[0][r] = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f);
+                acc[1][r] = fmaxf(d1 * rstd * gam[1] + bet[1], 0.f);
+                acc[2][r] = fmaxf(d2 * rstd * gam[2] + bet[2], 0.f);
+                acc[3][r] = fmaxf(d3 * rstd * gam[3] + bet[3], 0.f);
+            }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        gam[t] = st.qGamma[32 * t + c];
-        bet[t] = st.qBeta[32 * t + c];
-    }
-    float *zw = zbuf + wave * 32 * ZSTRIDE;
+            for (int t = 0; t < 4; ++t) {          // one 32-column tile at a time through the wave-private tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s1 = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-        const float mean = td_sum32(s1) * (1.0f / TD_H);
-        float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
-        float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        const float var = td_sum32(s2) * (1.0f / TD_H);
-        const float rstd = __frsqrt_rn(var + 1e-5f);
-        const int row = td_erow(r, hi);
-        zw[row * ZSTRIDE + c] = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f);
-        zw[row * ZSTRIDE + 32 + c] = fmaxf(d1 * rstd * gam[1] + bet[1], 0.f);
-        zw[row * ZSTRIDE + 64 + c] = fmaxf(d2 * rstd * gam[2] + bet[2], 0.f);
-        zw[row * ZSTRIDE + 96 + c] = fmaxf(d3 * rstd * gam[3] + bet[3], 0.f);
-    }
-    __syncthreads();
-    float4 a2[16];
+                for (int r = 0; r < 16; ++r) tb[td_erow(r, hi) * NP_TSTRIDE + c] = acc[t][r];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) a2[m] = *reinterpret_cast<const float4 *>(zw + c * ZSTRIDE + 8 * m + 4 * hi);
+                for (int mm = 0; mm < 4; ++mm)
+                    a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);   // h tile no longer needed
+            }
+        } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float bias = st.q3Bias[32 * t + c];
+            for (int r = 0; r < 16; ++r) {
+                const int orow = out_row(r);
+                if (orow >= 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = bias;
-    }
-    gemm128(a2, reinterpret_cast<const float4 *>(st.q3B), lane, acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (orow[r] >= 0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) q[orow[r] * TD_H + 32 * t + c] = acc[t][r];
+                    for (int t = 0; t < 4; ++t) q[(size_t)orow * TD_H + 32 * t + c] = acc[t][r];
+                }
+            }
         }
     }
 }
@@ -137,7 +168,7 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
                         float *P, float *q, hipStream_t s) {
     if (N == 0 || mat_mask == 0) return TD_OK;
     static bool attr_set = false;
-    const size_t lds = 4 * 32 * ZSTRIDE * sizeof(float);
+    const size_t lds = NP_LDS_BYTES;
     if (!attr_set) {
         TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
