@@ -198,6 +198,14 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
             }
         o.b2 = pack_vec(pk, m.b3, out_dim, TD_HEADS);
     }
+    if (alt == 0) {          // h2x value MLP: A operand of the 16x16x4 xv product, W2xv16[hb][r][lane]
+        o.Walt16 = pk.alloc((size_t)8 * 4 * 64);
+        float *q16 = pk.data.data() + o.Walt16;
+        for (int hb = 0; hb < 8; ++hb)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane)
+                    q16[((size_t)hb * 4 + r) * 64 + lane] = m.w3[(size_t)(lane & 15) * TD_H + 16 * hb + 4 * (lane >> 4) + r];
+    }
     if (alt == 1) {          // key MLP: per-head slices of W2 in the order the U_i build consumes them
         o.Walt = pk.alloc((size_t)4 * 16 * 2 * 2 * 16 * 4);
         float *q = pk.data.data() + o.Walt;
@@ -482,7 +490,12 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
                 ProfScope ps(PC_H2X_K, s);
                 if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc;
             }
-            { ProfScope ps(PC_H2X_V, s); if ((rc = td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc; }
+            {
+                ProfScope ps(PC_H2X_V, s);
+                if (edge_impl() == 2) rc = td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, w.P, w.lig_node, Nl, w.alpha, s);
+                else rc = td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s);
+                if (rc != TD_OK) return rc;
+            }
             float4 *t = xc; xc = xn; xn = t;
         }
     }

@@ -34,6 +34,7 @@ struct Args16 {
     const int32_t *count_ptr;
     float *h;
     float *alpha;
+    float4 *x4_out;            // XV mode: updated coordinates of the dst (ligand) nodes
     int64_t count;
     TdEdgeMlp mlp;
     const float *offsets;
@@ -74,6 +75,8 @@ __device__ __forceinline__ float td_max16(float v) {
 struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
     bool valid[2];
     float ew[2];
+    float rel[2][3];   // x_i - x_j
+    float4 xi;
 };
 
 template <bool LOAD_EW>
@@ -83,6 +86,7 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
                                                  floatx4_t (&acc)[2][8], Edge2 &ed) {
     const int lo = lane & 15, g = lane >> 4;
     const float4 xi = a.x4[i];
+    ed.xi = xi;
     const int cls = xi.w > 0.5f ? 0 : 1;
     float dist[2];
     int slot[2];
@@ -95,6 +99,7 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
         if (LOAD_EW) ed.ew[eb] = a.ew[i * TD_K + 16 * eb + lo];
         const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
         dist[eb] = sqrtf(rx * rx + ry * ry + rz * rz);
+        ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         any_a |= ed.valid[eb] && slot[eb] == 0;
         any_b |= ed.valid[eb] && slot[eb] == 1;
@@ -173,6 +178,11 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 constexpr int K16_WAVES = 16;
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
+// XV = false: key pass (logits -> softmax -> alpha).
+// XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
+//             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
+//             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
+template <bool XV>
 __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -186,7 +196,8 @@ __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
         for (int idx = tid; idx < E16_R_FLOATS / 4; idx += K16_WAVES * 64) rdst[idx] = rsrc[idx];
         const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt16);
         float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
-        for (int idx = tid; idx < E16_WQ_FLOATS / 4; idx += K16_WAVES * 64) wdst[idx] = wsrc[idx];
+        const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
+        for (int idx = tid; idx < nw4; idx += K16_WAVES * 64) wdst[idx] = wsrc[idx];
         if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
     }
@@ -201,7 +212,42 @@ __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
         floatx4_t acc[2][8];
         Edge2 ed;
-        td_first_layer16<true>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+        td_first_layer16<!XV>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+
+        if (XV) {
+            const float *Wx = lds + E16_R_FLOATS;                 // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
+            floatx4_t xv[2];
+            const float b2 = a.mlp.b2[lo];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = Wx[(hb * 4 + r) * 64 + lane];
+                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
+                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                }
+            // xv[eb][r] = xv of edge 16eb + lo, head 4g + r (bias: b2 of that head, fetched through the head's lane)
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bias = __shfl(b2, 4 * g + r);
+                const float *ap = a.alpha + ((size_t)i * TD_HEADS + 4 * g + r) * TD_K + lo;
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    const float wgt = ed.valid[eb] ? ap[16 * eb] * (xv[eb][r] + bias) : 0.f;
+                    sx = fmaf(wgt, ed.rel[eb][0], sx);
+                    sy = fmaf(wgt, ed.rel[eb][1], sy);
+                    sz = fmaf(wgt, ed.rel[eb][2], sz);
+                }
+            }
+            sx = td_sum64(sx) * (1.0f / TD_HEADS);
+            sy = td_sum64(sy) * (1.0f / TD_HEADS);
+            sz = td_sum64(sz) * (1.0f / TD_HEADS);
+            if (lane == 0) a.x4_out[i] = make_float4(ed.xi.x + sx, ed.xi.y + sy, ed.xi.z + sz, ed.xi.w);
+            continue;
+        }
 
         // ---- logits^T[head][edge] = sum_k U_i[k][head] z[k][edge];  A = U_i built from q_i: lane (head lo, group g) ----
         const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
@@ -348,14 +394,35 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
         attr_set = true;
     }
     Args16 a;
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
-    a.alpha = alpha; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    edge_key16_kernel<<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    edge_key16_kernel<false><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// h2x value pass (xv MLP + coordinate update) on the listed ligand rows; reads alpha written by the h2x key pass.
+int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
+                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
+        attr_set = true;
+    }
+    Args16 a;
+    a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
+    a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
+    a.coeff = L.coeff; a.p_off = 2 * TD_H;
+    edge_key16_kernel<true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -372,8 +439,8 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     }
     Args16 a;
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
-    a.alpha = const_cast<float *>(alpha); a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff;
-    a.p_off = 2 * TD_H;
+    a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
+    a.coeff = L.coeff; a.p_off = 2 * TD_H;
     edge_value16_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;

@@ -145,6 +145,8 @@ int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                          float *alpha, hipStream_t s);
+int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
+                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s);
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            hipStream_t s);
