@@ -175,15 +175,16 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 }
 
 // ================================================================================================ key pass
-constexpr int K16_WAVES = 16;
+constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, one LDS copy of the weights per CU
+constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
 //             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
 //             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
-template <bool XV>
-__global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
+template <bool XV, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
     const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);       // [hb][r][jq][lane] x 4 j
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
     {
         const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R16);
         float4 *rdst = reinterpret_cast<float4 *>(lds);
-        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += K16_WAVES * 64) rdst[idx] = rsrc[idx];
+        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += WAVES * 64) rdst[idx] = rsrc[idx];
         const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt16);
         float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
-        for (int idx = tid; idx < nw4; idx += K16_WAVES * 64) wdst[idx] = wsrc[idx];
+        for (int idx = tid; idx < nw4; idx += WAVES * 64) wdst[idx] = wsrc[idx];
         if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
     }
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(K16_WAVES * 64) void edge_key16_kernel(Args16 a) {
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
 
-    for (int64_t it = begin + wid; it < end; it += K16_WAVES) {
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
         floatx4_t acc[2][8];
         Edge2 ed;
@@ -291,7 +292,7 @@ constexpr int V16_WAVES = 8;
 constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
 constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidden + 4]
 constexpr int V16_ZB_STRIDE = 132;
-constexpr int V16_WAVE_FLOATS = 8 * V16_ZB_STRIDE;        // 1056 >= 32 * 20: transpose tile, later the Zbar half
+constexpr int V16_WAVE_FLOATS = 2 * 32 * V16_TB_STRIDE;   // 1280 >= 8 * 132: two transpose tiles, later the Zbar half
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
 
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 
     for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];   // residual, used last
         floatx4_t acc[2][8];
         Edge2 ed;
         td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
@@ -342,17 +344,26 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 
         // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time: flip z^T (lane = edge) through
         //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
+        // Two tiles ping-pong so that the flip of block hb + 1 is in flight while block hb feeds the MFMAs.
         floatx4_t zb[8];
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) {
+        auto flip_store = [&](int hb) {
+            float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb)
-                *reinterpret_cast<float4 *>(TB + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
                     make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+        };
+        flip_store(0);
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            if (hb + 1 < 8) flip_store(hb + 1);
+            const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+            float bv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];   // B[edge 8g + s][hidden 16hb + lo]
             zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 8; ++s)                // B[edge 8g + s][hidden 16hb + lo]
-                zb[hb] = td_mfma16(al[s], TB[(8 * g + s) * V16_TB_STRIDE + lo], zb[hb]);
+            for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
         }
 
         // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -------
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
                 o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
             }
-            a.h[(size_t)i * TD_H + n] += o;
+            a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
         }
     }
 }
@@ -394,16 +405,16 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
         attr_set = true;
     }
     Args16 a;
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    edge_key16_kernel<false><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    edge_key16_kernel<false, K16_WAVES><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -414,7 +425,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
         attr_set = true;
     }
@@ -422,7 +433,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
     a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
-    edge_key16_kernel<true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    edge_key16_kernel<true, XV16_WAVES><<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
