@@ -13,7 +13,7 @@ rank per GPU over RCCL) every rank samples its own pocket replica -- pockets sha
 collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = edge_key_kernel<false> (x2h key pass; the value pass is its twin);
+  roofline     dominant kernel = edge_key16_kernel<false,16> (x2h key pass; the value pass is its twin);
                achieved = executed algorithmic FLOPs per launch (327,680 per dst node) / mean
                launch time from HIP events recorded on the launch stream inside the timed region;
                peak = 157.3 TFLOP/s (fp32 MFMA = fp32 vector peak, dense).
@@ -38,7 +38,7 @@ from targetdiff_amd import capi, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
-# Dominant kernel: edge_key_kernel<x2h> (its value-pass twin edge_value_kernel costs the same).  FLOPs per dst node:
+# Dominant kernel: edge_key16_kernel (x2h key pass) (its value-pass twin edge_value_kernel costs the same).  FLOPs per dst node:
 #   executed  = 2 * (32*128*20 [radial/type first layer] + 128*128 [U_i = W2k^T q_i] + 32*128*16 [logits]) = 327,680
 #   canonical = 2 * (32*128*20 + 32*128*128 [per-edge second Linear] + 32*128 [q.k]) = 1,220,608  (SURVEY.md section 8d
 #               per-edge figures x 32 edges: what the reference formulation spends on the same stage)
@@ -188,8 +188,15 @@ def main():
 
     x2h = prof['x2h_k']
     x2h_ms = x2h['ms'] / max(1, x2h['launches'])
-    achieved = KEY_PASS_FLOP_EXECUTED * n_nodes / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
-    canonical = KEY_PASS_FLOP_CANONICAL * n_nodes / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
+    # dst rows per key-pass launch, averaged over the 9 layers of the last step: with the session the first layer only
+    # recomputes the rows a ligand atom touches and the last layer only the ligand atoms' 1-hop neighbourhood
+    n_layers = MODEL_CONFIG['num_layers']
+    rows_per_launch = float(n_nodes)
+    if sampler.session is not None:
+        n_all, n_dirty, n_hop = sampler.session.row_counts()
+        rows_per_launch = (n_dirty + (n_layers - 2) * n_all + n_hop) / n_layers
+    achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
+    canonical = KEY_PASS_FLOP_CANONICAL * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
     out = {
         'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -197,7 +204,7 @@ def main():
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
         'config': {'workload': desc, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
-        'roofline': {'bound': 'mfma', 'kernel': 'edge_key_kernel<false> (x2h key pass)', 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'edge_key16_kernel<false,16> (x2h key pass)', 'rows_per_launch': rows_per_launch, 'achieved': achieved,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': None,
                      'launch_ms': x2h_ms, 'launches': x2h['launches'], 'achieved_canonical_formulation': canonical,

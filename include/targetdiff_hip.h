@@ -139,8 +139,9 @@ int td_session_create(const td_model *m, const float *d_protein_pos, const float
 void td_session_destroy(td_session *s);
 int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *d_ligand_v, float *d_pred_ligand_pos,
                        float *d_pred_ligand_v, float *d_final_ligand_h, void *stream);
-/* number of rows (ligand + displaced protein rows) the last td_session_forward recomputed at layer 0; synchronises */
-int td_session_dirty_rows(td_session *s, int32_t *host_count, void *stream);
+/* rows processed by the last td_session_forward: counts[0] = N (layers 1 .. L-2), counts[1] = rows recomputed at layer 0
+ * (ligand + displaced protein rows), counts[2] = rows updated by the last layer (ligand + in-neighbours); synchronises */
+int td_session_row_counts(td_session *s, int32_t *host_counts3, void *stream);
 
 /* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
  *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;

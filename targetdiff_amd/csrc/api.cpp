@@ -457,7 +457,8 @@ int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const i
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
 // the buffer holding the final coordinates through *x_final.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
-                 float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false) {
+                 float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
+                 const int32_t *last_rows = nullptr, const int32_t *last_count = nullptr) {
     int rc;
     if (!graph_ready) {
     { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
@@ -470,8 +471,12 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         if (l == 0 && layer0_x2h_done) goto h2x_stage;
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
         if (fast_edges()) {
-            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, nullptr, nullptr, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, nullptr, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+            // last layer of a sampling step: only the ligand atoms' outputs are consumed, so only the ligand atoms and
+            // their in-neighbours need this layer's h (the final h2x reads the neighbours' projections)
+            const bool prune = last_rows && l == m->cfg.num_layers - 1 && l > 0;
+            const int32_t *rws = prune ? last_rows : nullptr, *cnt = prune ? last_count : nullptr;
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
         } else {
             { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
             { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
@@ -480,7 +485,10 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         if (!fix_x && Nl > 0) {
             {   // h2x: src-side projections (k_j, v_j) for every node; dst-side projections and queries for ligand atoms only
                 ProfScope ps(PC_NODE, s);
-                if ((rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.P, w.q, s)) != TD_OK) return rc;
+                const bool prune = last_rows && fast_edges() && l == m->cfg.num_layers - 1 && l > 0;
+                if (prune) rc = td_launch_node_proj(L.nodeH2x, h, N, last_rows, 0x0a, w.P, w.q, s, last_count);
+                else rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.P, w.q, s);
+                if (rc != TD_OK) return rc;
                 if ((rc = td_launch_node_proj(L.nodeH2x, h, Nl, w.lig_node, 0x15, w.P, w.q, s)) != TD_OK) return rc;
             }
             if (fast_edges()) {
@@ -668,7 +676,7 @@ struct td_session {
     int max_graph_nodes;
     char *block;
     Workspace w;                 // per-step buffers (x4a/x4b, gid, nbr, lig_node, node_ptr, ew, P, q, h, alpha)
-    int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count;
+    int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count, *hop_rows, *hop_count;
     unsigned long long *skeys;
     float *ews, *h0, *h1s, *P0, *q0;
     uint8_t *clean;
@@ -695,6 +703,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
                  o_snbr = reserve(n * TD_K * 4), o_skeys = reserve(n * TD_K * 8), o_ews = reserve(n * TD_K * 4),
                  o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_P0 = reserve(n * 4 * TD_H * 4),
                  o_q0 = reserve(n * TD_H * 4), o_clean = reserve(n), o_dirty = reserve(n * 4), o_dcnt = reserve(256),
+                 o_hop = reserve(n * 4), o_hcnt = reserve(256),
                  o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), off);
     if (e != hipSuccess) {
@@ -717,6 +726,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->clean = reinterpret_cast<uint8_t *>(b + o_clean);
     S->dirty_rows = reinterpret_cast<int32_t *>(b + o_dirty);
     S->dirty_count = reinterpret_cast<int32_t *>(b + o_dcnt);
+    S->hop_rows = reinterpret_cast<int32_t *>(b + o_hop);
+    S->hop_count = reinterpret_cast<int32_t *>(b + o_hcnt);
     float *tmp_lpos = reinterpret_cast<float *>(b + o_tmp_lpos);
     int64_t *tmp_lv = reinterpret_cast<int64_t *>(b + o_tmp_lv);
     Workspace &w = S->w;
@@ -786,17 +797,21 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
         { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
     }
+    // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
+    if ((rc = td_launch_ligand_hop_rows(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, s)) != TD_OK) return rc;
     float4 *xf = nullptr;
-    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true)) != TD_OK) return rc;
+    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
 }
 
-extern "C" int td_session_dirty_rows(td_session *S, int32_t *host_count, void *stream) {
-    if (!S || !host_count) { td_set_error("td_session_dirty_rows: null pointer"); return TD_EINVAL; }
+extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts3, void *stream) {
+    if (!S || !host_counts3) { td_set_error("td_session_row_counts: null pointer"); return TD_EINVAL; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    TD_CHECK_HIP(hipMemcpyAsync(host_count, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    host_counts3[0] = (int32_t)S->N;
+    TD_CHECK_HIP(hipMemcpyAsync(host_counts3 + 1, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipMemcpyAsync(host_counts3 + 2, S->hop_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }

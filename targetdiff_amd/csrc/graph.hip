@@ -325,6 +325,44 @@ int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, i
     return TD_OK;
 }
 
+// rows whose layer-L output is still needed when only ligand outputs are consumed: the ligand atoms and their
+// in-neighbours (the last h2x reads the neighbours' projections).  flags must be zeroed before the launch.
+__global__ void mark_ligand_hop_kernel(const int32_t *__restrict__ lig_node, int64_t Nl, const int32_t *__restrict__ nbr,
+                                       uint8_t *__restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t a = t >> 5;
+    if (a >= Nl) return;
+    const int i = lig_node[a];
+    const int e = (int)(t & 31);
+    if (e == 0) flags[i] = 1;
+    const int j = nbr[(int64_t)i * TD_K + e];
+    if (j >= 0) flags[j] = 1;
+}
+
+__global__ void compact_flags_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
+                                     int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = i < N && flags[i];
+    const unsigned long long m = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0);
+    if (on) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+int td_launch_ligand_hop_rows(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
+                              int32_t *rows, int32_t *count, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    TD_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)N, s));
+    TD_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (Nl > 0) mark_ligand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nbr, flags);
+    TD_CHECK_HIP(hipGetLastError());
+    compact_flags_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags, N, rows, count);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 // per-step refresh of the ligand rows: x4 = (pos, 1), h = Linear(one_hot(v)) ; 1
 __global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restrict__ lpos, const int64_t *__restrict__ lv,
                                                             const int32_t *__restrict__ lig_node, int64_t Nl, int C,

@@ -68,7 +68,12 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
 // the listed node ids (h2x needs the dst-side projections and queries of ligand atoms only).
 __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
                                                            const int32_t *__restrict__ rows, unsigned mat_mask,
+                                                           const int32_t *__restrict__ count_ptr,
                                                            float *__restrict__ P, float *__restrict__ q) {
+    if (count_ptr) {                     // device-side row count: workgroups beyond it exit before any barrier
+        N = *count_ptr;
+        if ((int64_t)blockIdx.x * 128 >= N) return;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
 }
 
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
-                        float *P, float *q, hipStream_t s) {
+                        float *P, float *q, hipStream_t s, const int32_t *count_ptr) {
     if (N == 0 || mat_mask == 0) return TD_OK;
     static bool attr_set = false;
     const size_t lds = NP_LDS_BYTES;
@@ -174,7 +179,7 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    node_proj_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), lds, s>>>(st, h, N, rows, mat_mask, P, q);
+    node_proj_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), lds, s>>>(st, h, N, rows, mat_mask, count_ptr, P, q);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

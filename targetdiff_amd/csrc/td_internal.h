@@ -118,13 +118,15 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
                         uint8_t *clean, hipStream_t s);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
+int td_launch_ligand_hop_rows(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
+                              int32_t *rows, int32_t *count, hipStream_t s);
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
                             float *h, float4 *x4, hipStream_t s);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
 // node.hip
 // rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
-                        float *P, float *q, hipStream_t s);
+                        float *P, float *q, hipStream_t s, const int32_t *count_ptr = nullptr);
 // edge.hip
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s);

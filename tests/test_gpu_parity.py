@@ -351,8 +351,8 @@ def test_session_forward_equals_stateless_forward(model, case):
         got = sess.forward(lpos, lv)
         for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
             assert torch.equal(got[k], want[k]), (case, step, k, _maxdiff(got[k], want[k]))
-        dirty = sess.dirty_rows()
-        assert lpos.shape[0] <= dirty <= N
+        n_all, dirty, hop = sess.row_counts()
+        assert n_all == N and lpos.shape[0] <= dirty <= N and lpos.shape[0] <= hop <= N
         if case == '1h36':
             assert dirty < 0.5 * N, (dirty, N)
         # move the ligand like a sampling step would (and shuffle the types) before the next comparison
