@@ -197,6 +197,14 @@ def main():
         rows_per_launch = (n_dirty + (n_layers - 2) * n_all + n_hop) / n_layers
     achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
     canonical = KEY_PASS_FLOP_CANONICAL * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
+    # HBM traffic of the same kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, tools/pmc_collect.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- cannot be read in-process
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_x2h_key.json')
+    if os.path.exists(tpath) and args.workload == 'c2':
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
     out = {
         'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -204,9 +212,9 @@ def main():
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
         'config': {'workload': desc, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
-        'roofline': {'bound': 'mfma', 'kernel': 'edge_key16_kernel<false,16> (x2h key pass)', 'rows_per_launch': rows_per_launch, 'achieved': achieved,
+        'roofline': {'bound': 'mfma', 'kernel': 'edge_key16_kernel<false, 16, 0> (x2h key pass)', 'rows_per_launch': rows_per_launch, 'achieved': achieved,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': None,
+                     'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': traffic,
                      'launch_ms': x2h_ms, 'launches': x2h['launches'], 'achieved_canonical_formulation': canonical,
                      'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
                      'share_of_step': (x2h['ms'] / args.steps) / (sec_per_step * 1e3)},

@@ -183,7 +183,8 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
 //             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
 //             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
-template <bool XV, int WAVES>
+// STAGE only tags the instantiation (0 = x2h, 1 = h2x) so that profilers report the two stages separately.
+template <bool XV, int WAVES, int STAGE>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -405,16 +406,21 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
         attr_set = true;
     }
     Args16 a;
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    edge_key16_kernel<false, K16_WAVES><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    if (rows && !count_ptr)      // h2x key pass (ligand row list of known length)
+        edge_key16_kernel<false, K16_WAVES, 1><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    else
+        edge_key16_kernel<false, K16_WAVES, 0><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -425,7 +431,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
     if (count == 0) return TD_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES>),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
         attr_set = true;
     }
@@ -433,7 +439,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
     a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
-    edge_key16_kernel<true, XV16_WAVES><<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    edge_key16_kernel<true, XV16_WAVES, 1><<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
