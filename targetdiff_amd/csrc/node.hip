@@ -43,9 +43,8 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
             // async global -> LDS copy of the next chunk (no staging registers): each wave-instruction moves
             // 64 x 16 B to a wave-uniform LDS base + lane * 16; the barrier below waits for it (vmcnt(0)).
             float4 *dst = bufs + (cur ^ 1) * NP_CHUNK_F4 + (tid & ~63);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                td_glds16(src + u * 256 + tid, dst + u * 256);
+            const int nthr = blockDim.x;             // 256 (4 waves) or 64 (1 wave, small launches)
+            for (int u = 0; u < NP_CHUNK_F4; u += nthr) td_glds16(src + u + tid, dst + u);
         }
         const float4 *bl = bufs + cur * NP_CHUNK_F4 + lane;
 #pragma unroll
@@ -72,14 +71,14 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
                                                            float *__restrict__ P, float *__restrict__ q) {
     if (count_ptr) {                     // device-side row count: workgroups beyond it exit before any barrier
         N = *count_ptr;
-        if ((int64_t)blockIdx.x * 128 >= N) return;
+        if ((int64_t)blockIdx.x * (blockDim.x >> 1) >= N) return;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;          // wave-private transpose tile
     const int c = lane & 31, hi = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+    const int64_t row0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
     const int64_t aslot = row0 + c;
     const int64_t arow = aslot < N ? (rows ? (int64_t)rows[aslot] : aslot) : -1;
 
@@ -94,6 +93,18 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
         return slot < N ? (rows ? rows[slot] : (int)slot) : -1;
     };
 
+    // Small launches (ligand rows only) are split over blockIdx.y: one independent unit (a projection, or the
+    // two-GEMM query MLP) per y, so that a 3 k-row launch fills the chip instead of 28 CUs.
+    if (gridDim.y > 1) {
+        int seen = 0;
+        unsigned sel = 0;
+        for (int b = 0; b < 5; ++b)
+            if ((mat_mask >> b) & 1u) {
+                if (seen == (int)blockIdx.y) sel = 1u << b;
+                ++seen;
+            }
+        mat_mask = sel;
+    }
     // the matrices this launch walks through, in order: selected projections, then q.net.0, then q.net.3
     const float4 *Bp = reinterpret_cast<const float4 *>(st.projB);
     const float4 *seq[6];
@@ -102,8 +113,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
         if ((mat_mask >> mat) & 1u) { seq[nseq] = Bp + (size_t)mat * TD_KSTEPS * 64; mats[nseq++] = mat; }
     if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(st.q3B); mats[nseq++] = 5; }
     // prologue: first chunk of the first matrix
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bufs[u * 256 + tid] = seq[0][u * 256 + tid];
+    for (int u = tid; u < NP_CHUNK_F4; u += blockDim.x) bufs[u] = seq[0][u];
     __syncthreads();
     int cur = 0;
 
@@ -179,7 +189,14 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    node_proj_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), lds, s>>>(st, h, N, rows, mat_mask, count_ptr, P, q);
+    // few rows (ligand atoms only): one wave per workgroup and one independent unit per blockIdx.y, so that the launch
+    // spreads over the whole chip; many rows: 4 waves share each staged B chunk and keep the A tile for all matrices
+    const bool small = N <= 16384;
+    const unsigned units = small ? (unsigned)__builtin_popcount(mat_mask & 0x1fu) : 1u;
+    const unsigned threads = small ? 64u : 256u;
+    const int64_t rows_per_wg = threads / 2;
+    node_proj_kernel<<<dim3((unsigned)((N + rows_per_wg - 1) / rows_per_wg), units), dim3(threads), lds, s>>>(
+        st, h, N, rows, mat_mask, count_ptr, P, q);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
