@@ -454,58 +454,81 @@ int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const i
                             : td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s);
 }
 
+bool h2x_fused() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TD_H2X_FUSED");
+        v = (edge_impl() == 2 && !(e && e[0] == '0')) ? 1 : 0;
+    }
+    return v == 1;
+}
+
+// h2x stage, projections in one launch: src-side (k_j, v_j) of every node (or of the pruned row list on the last layer)
+// plus, as a second segment, the dst-side projections and queries of the ligand atoms
+int h2x_project(const td_model *m, const TdLayer &L, int l, Workspace &w, float *h, int64_t N, int64_t Nl, float *P, float *q,
+                const int32_t *last_rows, const int32_t *last_count, hipStream_t s) {
+    ProfScope ps(PC_NODE, s);
+    const bool prune = last_rows && fast_edges() && l == m->cfg.num_layers - 1 && l > 0;
+    if (prune) return td_launch_node_proj(L.nodeH2x, h, N, last_rows, 0x0a, P, q, s, last_count, w.lig_node, Nl, 0x15);
+    return td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, P, q, s, nullptr, w.lig_node, Nl, 0x15);
+}
+
+// attention over the ligand atoms' edges and the coordinate update xc -> xn
+int h2x_attend(const TdLayer &L, Workspace &w, float *h, int64_t Nl, float4 *xc, float4 *xn, float *P, float *q,
+               float *alpha, hipStream_t s) {
+    int rc;
+    if (h2x_fused()) {
+        ProfScope ps(PC_H2X_K, s);
+        return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, s);
+    }
+    {
+        ProfScope ps(PC_H2X_K, s);
+        if (fast_edges()) rc = key_pass(L.xk, L, xc, w.nbr, w.ew, P, q, w.lig_node, nullptr, Nl, alpha, s);
+        else rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, h, alpha, s);
+        if (rc != TD_OK) return rc;
+    }
+    ProfScope ps(PC_H2X_V, s);
+    if (edge_impl() == 2) return td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, P, w.lig_node, Nl, alpha, s);
+    return td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, h, alpha, s);
+}
+
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
 // the buffer holding the final coordinates through *x_final.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
                  float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
                  const int32_t *last_rows = nullptr, const int32_t *last_count = nullptr) {
     int rc;
+    const int Lc = m->cfg.num_layers;
     if (!graph_ready) {
-    { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
-    { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
     }
     float4 *xc = w.x4a, *xn = w.x4b;
-    if (!fix_x && Nl > 0 && !graph_ready) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    for (int l = 0; l < m->cfg.num_layers; ++l) {
+    const bool do_h2x = !fix_x && Nl > 0;
+    if (do_h2x && !graph_ready) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < Lc; ++l) {
         const TdLayer &L = m->layers[l];
-        if (l == 0 && layer0_x2h_done) goto h2x_stage;
-        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
-        if (fast_edges()) {
-            // last layer of a sampling step: only the ligand atoms' outputs are consumed, so only the ligand atoms and
-            // their in-neighbours need this layer's h (the final h2x reads the neighbours' projections)
-            const bool prune = last_rows && l == m->cfg.num_layers - 1 && l > 0;
-            const int32_t *rws = prune ? last_rows : nullptr, *cnt = prune ? last_count : nullptr;
-            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
-        } else {
-            { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
-        }
-    h2x_stage:
-        if (!fix_x && Nl > 0) {
-            {   // h2x: src-side projections (k_j, v_j) for every node; dst-side projections and queries for ligand atoms only
+        if (!(l == 0 && layer0_x2h_done)) {
+            {
                 ProfScope ps(PC_NODE, s);
-                const bool prune = last_rows && fast_edges() && l == m->cfg.num_layers - 1 && l > 0;
-                if (prune) rc = td_launch_node_proj(L.nodeH2x, h, N, last_rows, 0x0a, w.P, w.q, s, last_count);
-                else rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.P, w.q, s);
-                if (rc != TD_OK) return rc;
-                if ((rc = td_launch_node_proj(L.nodeH2x, h, Nl, w.lig_node, 0x15, w.P, w.q, s)) != TD_OK) return rc;
+                if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc;
             }
             if (fast_edges()) {
-                ProfScope ps(PC_H2X_K, s);
-                if ((rc = key_pass(L.xk, L, xc, w.nbr, w.ew, w.P, w.q, w.lig_node, nullptr, Nl, w.alpha, s)) != TD_OK) return rc;
+                // last layer of a sampling step: only the ligand atoms' outputs are consumed, so only the ligand atoms and
+                // their in-neighbours need this layer's h (the final h2x reads the neighbours' projections)
+                const bool prune = last_rows && l == Lc - 1 && l > 0;
+                const int32_t *rws = prune ? last_rows : nullptr, *cnt = prune ? last_count : nullptr;
+                { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
+                { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
             } else {
-                ProfScope ps(PC_H2X_K, s);
-                if ((rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s)) != TD_OK) return rc;
+                { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
+                { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
             }
-            {
-                ProfScope ps(PC_H2X_V, s);
-                if (edge_impl() == 2) rc = td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, w.P, w.lig_node, Nl, w.alpha, s);
-                else rc = td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, w.P, w.q, w.lig_node, Nl, h, w.alpha, s);
-                if (rc != TD_OK) return rc;
-            }
-            float4 *t = xc; xc = xn; xn = t;
         }
+        if (!do_h2x) continue;
+        if ((rc = h2x_project(m, L, l, w, h, N, Nl, w.P, w.q, last_rows, last_count, s)) != TD_OK) return rc;
+        if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.P, w.q, w.alpha, s)) != TD_OK) return rc;
+        float4 *t = xc; xc = xn; xn = t;
     }
     *x_final = xc;
     return TD_OK;

@@ -288,6 +288,131 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     }
 }
 
+// ================================================================================================ fused h2x stage
+// Key pass + value pass of the h2x stage for the listed ligand rows in one launch: the attention weights never leave
+// registers (alpha[eb][r] and xv[eb][r] share the (edge 16eb + lo, head 4g + r) layout).  The two edge MLPs' tables do
+// not fit in LDS together, so a workgroup alternates: xk tables -> logits / softmax for one row per wave -> barrier ->
+// xv tables -> coordinate update.  The ligand rows of a sampling batch are fewer than the resident waves, so this is one
+// round per workgroup.  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
+constexpr int H2X16_WAVES = 8;
+
+struct ArgsH2x {
+    Args16 a;              // a.mlp = xk MLP (keys), a.p_off = 0
+    TdEdgeMlp mlp_v;       // xv MLP
+};
+
+template <int WAVES>
+__device__ __forceinline__ void td_stage_tables16(float *lds, const TdEdgeMlp &mlp, int nw4, int tid) {
+    const float4 *rsrc = reinterpret_cast<const float4 *>(mlp.R16);
+    float4 *rdst = reinterpret_cast<float4 *>(lds);
+    for (int idx = tid; idx < E16_R_FLOATS / 4; idx += WAVES * 64) rdst[idx] = rsrc[idx];
+    const float4 *wsrc = reinterpret_cast<const float4 *>(mlp.Walt16);
+    float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
+    for (int idx = tid; idx < nw4; idx += WAVES * 64) wdst[idx] = wsrc[idx];
+    if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.gamma[tid];
+    else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.beta[tid - TD_H];
+}
+
+__global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar) {
+    constexpr int WAVES = H2X16_WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Args16 &a = ar.a;
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
+    const float *Wx = lds + E16_R_FLOATS;
+    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+    Args16 av = a;
+    av.p_off = 2 * TD_H;
+    const float b2 = ar.mlp_v.b2[lo];
+
+    for (int64_t base = begin; base < end; base += WAVES) {      // uniform trip count: every wave reaches the barriers
+        const int64_t it = base + wid;
+        const bool active = it < end;
+        const int64_t i = active ? (a.rows ? (int64_t)a.rows[it] : it) : 0;
+        if (base != begin) __syncthreads();
+        td_stage_tables16<WAVES>(lds, a.mlp, E16_WQ_FLOATS / 4, tid);
+        __syncthreads();
+        floatx4_t al[2];
+        Edge2 ed;
+        if (active) {
+            floatx4_t acc[2][8];
+            td_first_layer16<true>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+            const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+            const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+            floatx4_t lg[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
+                    const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+                    float u = w0.x * q0.x;
+                    u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                    u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                    lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
+                    lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+                float mx = td_max16(fmaxf(x0, x1));
+                if (mx == -INFINITY) mx = 0.f;
+                const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
+                const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
+                const float sm = td_sum16(p0 + p1);
+                const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
+                al[0][r] = p0 * inv * ed.ew[0];
+                al[1][r] = p1 * inv * ed.ew[1];
+            }
+        }
+        __syncthreads();
+        td_stage_tables16<WAVES>(lds, ar.mlp_v, 8 * 4 * 64 / 4, tid);
+        __syncthreads();
+        if (active) {
+            floatx4_t acc[2][8];
+            Edge2 ev;
+            td_first_layer16<false>(av, Rt, GAM, BET, offk, i, lane, acc, ev);
+            floatx4_t xv[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = Wx[(hb * 4 + r) * 64 + lane];
+                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
+                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                }
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bias = __shfl(b2, 4 * g + r);
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    const float wgt = ev.valid[eb] ? al[eb][r] * (xv[eb][r] + bias) : 0.f;
+                    sx = fmaf(wgt, ev.rel[eb][0], sx);
+                    sy = fmaf(wgt, ev.rel[eb][1], sy);
+                    sz = fmaf(wgt, ev.rel[eb][2], sz);
+                }
+            }
+            sx = td_sum64(sx) * (1.0f / TD_HEADS);
+            sy = td_sum64(sy) * (1.0f / TD_HEADS);
+            sz = td_sum64(sz) * (1.0f / TD_HEADS);
+            if (lane == 0) a.x4_out[i] = make_float4(ev.xi.x + sx, ev.xi.y + sy, ev.xi.z + sz, ev.xi.w);
+        }
+    }
+}
+
 // ================================================================================================ value pass (x2h)
 constexpr int V16_WAVES = 8;
 constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
@@ -459,6 +584,27 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
     edge_value16_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// Fused h2x stage (keys + softmax + xv + coordinate update) on the listed ligand rows.
+int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
+                         const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
+                         int64_t count, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_h2x16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
+        attr_set = true;
+    }
+    ArgsH2x ar;
+    Args16 &a = ar.a;
+    a.x4 = x4_in; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
+    a.alpha = nullptr; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    ar.mlp_v = mlp_v;
+    edge_h2x16_kernel<<<dim3(grid16(count, H2X16_WAVES)), dim3(H2X16_WAVES * 64), K16_LDS_BYTES, s>>>(ar);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -65,20 +65,35 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
 
 // mat_mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP.  rows != nullptr: process only
 // the listed node ids (h2x needs the dst-side projections and queries of ligand atoms only).
+//
+// Second segment (blocks2 > 0): workgroups blockIdx.x < blocks2 process the row list rows2[0..N2) with mask2, one
+// unit per workgroup -- the h2x stage's ligand-row projections ride along with the all-row launch instead of paying a
+// separate latency-bound launch.
 __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
                                                            const int32_t *__restrict__ rows, unsigned mat_mask,
                                                            const int32_t *__restrict__ count_ptr,
-                                                           float *__restrict__ P, float *__restrict__ q) {
-    if (count_ptr) {                     // device-side row count: workgroups beyond it exit before any barrier
+                                                           float *__restrict__ P, float *__restrict__ q, int blocks2,
+                                                           const int32_t *__restrict__ rows2, int64_t N2, unsigned mask2) {
+    int bx = blockIdx.x;
+    int unit = gridDim.y > 1 ? (int)blockIdx.y : -1;
+    if (bx < blocks2) {
+        const int units2 = __builtin_popcount(mask2 & 0x1fu);
+        unit = bx % units2;
+        bx /= units2;
+        rows = rows2; N = N2; mat_mask = mask2;
+    } else {
+        bx -= blocks2;
+    }
+    if (count_ptr && blockIdx.x >= blocks2) {   // device-side row count: workgroups beyond it exit before any barrier
         N = *count_ptr;
-        if ((int64_t)blockIdx.x * (blockDim.x >> 1) >= N) return;
+        if ((int64_t)bx * (blockDim.x >> 1) >= N) return;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;          // wave-private transpose tile
     const int c = lane & 31, hi = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 32;
+    const int64_t row0 = ((int64_t)bx * (blockDim.x >> 6) + wave) * 32;
     const int64_t aslot = row0 + c;
     const int64_t arow = aslot < N ? (rows ? (int64_t)rows[aslot] : aslot) : -1;
 
@@ -95,12 +110,12 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
 
     // Small launches (ligand rows only) are split over blockIdx.y: one independent unit (a projection, or the
     // two-GEMM query MLP) per y, so that a 3 k-row launch fills the chip instead of 28 CUs.
-    if (gridDim.y > 1) {
+    if (unit >= 0) {
         int seen = 0;
         unsigned sel = 0;
         for (int b = 0; b < 5; ++b)
             if ((mat_mask >> b) & 1u) {
-                if (seen == (int)blockIdx.y) sel = 1u << b;
+                if (seen == unit) sel = 1u << b;
                 ++seen;
             }
         mat_mask = sel;
@@ -180,8 +195,10 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
 }
 
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
-                        float *P, float *q, hipStream_t s, const int32_t *count_ptr) {
+                        float *P, float *q, hipStream_t s, const int32_t *count_ptr, const int32_t *rows2, int64_t N2,
+                        unsigned mask2) {
     if (N == 0 || mat_mask == 0) return TD_OK;
+    if (!rows2 || N2 == 0 || (mask2 & 0x1fu) == 0) { rows2 = nullptr; N2 = 0; mask2 = 0; }
     static bool attr_set = false;
     const size_t lds = NP_LDS_BYTES;
     if (!attr_set) {
@@ -191,12 +208,14 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
     }
     // few rows (ligand atoms only): one wave per workgroup and one independent unit per blockIdx.y, so that the launch
     // spreads over the whole chip; many rows: 4 waves share each staged B chunk and keep the A tile for all matrices
-    const bool small = N <= 16384;
+    const bool small = N <= 16384 && !rows2;
     const unsigned units = small ? (unsigned)__builtin_popcount(mat_mask & 0x1fu) : 1u;
     const unsigned threads = small ? 64u : 256u;
     const int64_t rows_per_wg = threads / 2;
-    node_proj_kernel<<<dim3((unsigned)((N + rows_per_wg - 1) / rows_per_wg), units), dim3(threads), lds, s>>>(
-        st, h, N, rows, mat_mask, count_ptr, P, q);
+    const unsigned blocks1 = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
+    const unsigned blocks2 = rows2 ? (unsigned)((N2 + rows_per_wg - 1) / rows_per_wg) * (unsigned)__builtin_popcount(mask2 & 0x1fu) : 0u;
+    node_proj_kernel<<<dim3(blocks1 + blocks2, units), dim3(threads), lds, s>>>(st, h, N, rows, mat_mask, count_ptr, P, q,
+                                                                                (int)blocks2, rows2, N2, mask2);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -126,7 +126,8 @@ int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int
 // node.hip
 // rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
-                        float *P, float *q, hipStream_t s, const int32_t *count_ptr = nullptr);
+                        float *P, float *q, hipStream_t s, const int32_t *count_ptr = nullptr,
+                        const int32_t *rows2 = nullptr, int64_t N2 = 0, unsigned mask2 = 0);
 // edge.hip
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s);
@@ -147,6 +148,9 @@ int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                          float *alpha, hipStream_t s);
+int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
+                         const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
+                         int64_t count, hipStream_t s);
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
                         const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s);
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
