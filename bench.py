@@ -13,7 +13,8 @@ rank per GPU over RCCL) every rank samples its own pocket replica -- pockets sha
 collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = edge_key16_kernel<false,16> (x2h key pass; the value pass is its twin);
+  roofline     dominant kernel = edge_value16_kernel (x2h value pass; the key pass edge_key16_kernel<false,16,0> is its
+               twin and is reported under roofline.key_pass);
                achieved = executed algorithmic FLOPs per launch (327,680 per dst node) / mean
                launch time from HIP events recorded on the launch stream inside the timed region;
                peak = 157.3 TFLOP/s (fp32 MFMA = fp32 vector peak, dense).
@@ -38,10 +39,12 @@ from targetdiff_amd import capi, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
-# Dominant kernel: edge_key16_kernel (x2h key pass) (its value-pass twin edge_value_kernel costs the same).  FLOPs per dst node:
-#   executed  = 2 * (32*128*20 [radial/type first layer] + 128*128 [U_i = W2k^T q_i] + 32*128*16 [logits]) = 327,680
-#   canonical = 2 * (32*128*20 + 32*128*128 [per-edge second Linear] + 32*128 [q.k]) = 1,220,608  (SURVEY.md section 8d
-#               per-edge figures x 32 edges: what the reference formulation spends on the same stage)
+# Dominant kernels: edge_value16_kernel (x2h value pass) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
+# identical for the two passes:
+#   executed  = 2 * (32*128*20 [radial/type first layer] + 128*128 [out = W2v Zbar | U_i = W2k^T q_i]
+#                    + 32*128*16 [Zbar = alpha^T z | logits = z U_i]) = 327,680
+#   canonical = 2 * (32*128*20 + 32*128*128 [per-edge second Linear] + 32*128 [alpha.v | q.k]) = 1,220,608  (SURVEY.md
+#               section 8d per-edge figures x 32 edges: what the reference formulation spends on the same stage)
 # `roofline.achieved` uses the executed count (so frac <= 1 is meaningful for this kernel); the canonical figure is
 # reported next to it.  DESIGN.md section 4 derives both.
 KEY_PASS_FLOP_EXECUTED = 2 * (32 * 128 * 20 + 128 * 128 + 32 * 128 * 16)
@@ -169,7 +172,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k',)
+    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k', 'x2h_v')
     fence()
     capi.profile_begin(classes)
     t0 = time.perf_counter()
@@ -186,25 +189,39 @@ def main():
     graphs = len(pockets) * spp
     value = world * graphs / (1000.0 * sec_per_step)
 
-    x2h = prof['x2h_k']
-    x2h_ms = x2h['ms'] / max(1, x2h['launches'])
-    # dst rows per key-pass launch, averaged over the 9 layers of the last step: with the session the first layer only
+    # dst rows per key / value launch, averaged over the 9 layers of the last step: with the session the first layer only
     # recomputes the rows a ligand atom touches and the last layer only the ligand atoms' 1-hop neighbourhood
     n_layers = MODEL_CONFIG['num_layers']
     rows_per_launch = float(n_nodes)
     if sampler.session is not None:
         n_all, n_dirty, n_hop = sampler.session.row_counts()
         rows_per_launch = (n_dirty + (n_layers - 2) * n_all + n_hop) / n_layers
-    achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
-    canonical = KEY_PASS_FLOP_CANONICAL * rows_per_launch / (x2h_ms * 1e-3) / 1e12 if x2h['launches'] else None
-    # HBM traffic of the same kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, tools/pmc_collect.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- cannot be read in-process
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_x2h_key.json')
-    if os.path.exists(tpath) and args.workload == 'c2':
-        with open(tpath) as f:
-            tj = json.load(f)
-        traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
+
+    def pass_roofline(cls, kernel, traffic_file):
+        p = prof[cls]
+        if not p['launches']:
+            return None
+        ms = p['ms'] / p['launches']
+        achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate passes, tools/pmc_collect.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- PMC counters
+        # cannot be read in-process
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', traffic_file)
+        if os.path.exists(tpath) and args.workload == 'c2' and sampler.session is not None:
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
+        return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'achieved': achieved,
+                'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'traffic': traffic, 'launch_ms': ms, 'launches': p['launches'],
+                'achieved_canonical_formulation': KEY_PASS_FLOP_CANONICAL * rows_per_launch / (ms * 1e-3) / 1e12,
+                'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
+                'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}
+
+    roofline = pass_roofline('x2h_v', 'edge_value16_kernel (x2h value pass)', 'traffic_x2h_value.json')
+    if roofline is not None:
+        roofline['key_pass'] = pass_roofline('x2h_k', 'edge_key16_kernel<false, 16, 0> (x2h key pass)', 'traffic_x2h_key.json')
     out = {
         'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -212,12 +229,7 @@ def main():
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
         'config': {'workload': desc, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
-        'roofline': {'bound': 'mfma', 'kernel': 'edge_key16_kernel<false, 16, 0> (x2h key pass)', 'rows_per_launch': rows_per_launch, 'achieved': achieved,
-                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, 'traffic': traffic,
-                     'launch_ms': x2h_ms, 'launches': x2h['launches'], 'achieved_canonical_formulation': canonical,
-                     'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
-                     'share_of_step': (x2h['ms'] / args.steps) / (sec_per_step * 1e3)},
+        'roofline': roofline,
     }
     if rank == 0:
         if args.profile_all:

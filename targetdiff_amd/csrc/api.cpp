@@ -463,13 +463,13 @@ bool h2x_fused() {
     return v == 1;
 }
 
-// h2x stage, projections in one launch: src-side (k_j, v_j) of every node (or of the pruned row list on the last layer)
-// plus, as a second segment, the dst-side projections and queries of the ligand atoms
-int h2x_project(const td_model *m, const TdLayer &L, int l, Workspace &w, float *h, int64_t N, int64_t Nl, float *P, float *q,
-                const int32_t *last_rows, const int32_t *last_count, hipStream_t s) {
+// h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
+// ligand atoms and their neighbours, fixed for the step) when the caller has the list, every node otherwise -- plus, as
+// a second segment, the dst-side projections and queries of the ligand atoms
+int h2x_project(const TdLayer &L, Workspace &w, float *h, int64_t N, int64_t Nl, float *P, float *q,
+                const int32_t *hop_rows, const int32_t *hop_count, hipStream_t s) {
     ProfScope ps(PC_NODE, s);
-    const bool prune = last_rows && fast_edges() && l == m->cfg.num_layers - 1 && l > 0;
-    if (prune) return td_launch_node_proj(L.nodeH2x, h, N, last_rows, 0x0a, P, q, s, last_count, w.lig_node, Nl, 0x15);
+    if (hop_rows) return td_launch_node_proj(L.nodeH2x, h, N, hop_rows, 0x0a, P, q, s, hop_count, w.lig_node, Nl, 0x15);
     return td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, P, q, s, nullptr, w.lig_node, Nl, 0x15);
 }
 
@@ -493,10 +493,12 @@ int h2x_attend(const TdLayer &L, Workspace &w, float *h, int64_t Nl, float4 *xc,
 }
 
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
-// the buffer holding the final coordinates through *x_final.
+// the buffer holding the final coordinates through *x_final.  hop_rows (optional, sampling session): the ligand atoms
+// and their neighbours -- the only rows whose h2x-stage projections and last-layer features are ever read when just the
+// ligand outputs are consumed.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
                  float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
-                 const int32_t *last_rows = nullptr, const int32_t *last_count = nullptr) {
+                 const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr) {
     int rc;
     const int Lc = m->cfg.num_layers;
     if (!graph_ready) {
@@ -516,8 +518,8 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             if (fast_edges()) {
                 // last layer of a sampling step: only the ligand atoms' outputs are consumed, so only the ligand atoms and
                 // their in-neighbours need this layer's h (the final h2x reads the neighbours' projections)
-                const bool prune = last_rows && l == Lc - 1 && l > 0;
-                const int32_t *rws = prune ? last_rows : nullptr, *cnt = prune ? last_count : nullptr;
+                const bool prune = hop_rows && l == Lc - 1 && l > 0;
+                const int32_t *rws = prune ? hop_rows : nullptr, *cnt = prune ? hop_count : nullptr;
                 { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
                 { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
             } else {
@@ -526,7 +528,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
         }
         if (!do_h2x) continue;
-        if ((rc = h2x_project(m, L, l, w, h, N, Nl, w.P, w.q, last_rows, last_count, s)) != TD_OK) return rc;
+        if ((rc = h2x_project(L, w, h, N, Nl, w.P, w.q, hop_rows, hop_count, s)) != TD_OK) return rc;
         if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.P, w.q, w.alpha, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
     }

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 // Key pass + value pass of the h2x stage for the listed ligand rows in one launch: the attention weights never leave
 // registers (alpha[eb][r] and xv[eb][r] share the (edge 16eb + lo, head 4g + r) layout).  The two edge MLPs' tables do
 // not fit in LDS together, so a workgroup alternates: xk tables -> logits / softmax for one row per wave -> barrier ->
-// xv tables -> coordinate update.  The ligand rows of a sampling batch are fewer than the resident waves, so this is one
-// round per workgroup.  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
+// xv tables -> coordinate update, with up to two rows per wave per table residency (one round per workgroup for the
+// ligand rows of a sampling batch).  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
 constexpr int H2X16_WAVES = 8;
 
 struct ArgsH2x {
@@ -332,17 +332,19 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     av.p_off = 2 * TD_H;
     const float b2 = ar.mlp_v.b2[lo];
 
-    for (int64_t base = begin; base < end; base += WAVES) {      // uniform trip count: every wave reaches the barriers
-        const int64_t it = base + wid;
-        const bool active = it < end;
-        const int64_t i = active ? (a.rows ? (int64_t)a.rows[it] : it) : 0;
+    constexpr int RPW = 2;      // rows per wave and table residency: the ligand rows of a batch are ~1.1x the resident waves
+    for (int64_t base = begin; base < end; base += WAVES * RPW) {      // uniform trip count: every wave reaches the barriers
         if (base != begin) __syncthreads();
         td_stage_tables16<WAVES>(lds, a.mlp, E16_WQ_FLOATS / 4, tid);
         __syncthreads();
-        floatx4_t al[2];
-        Edge2 ed;
-        if (active) {
+        floatx4_t al[RPW][2];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int64_t it = base + rr * WAVES + wid;
+            if (it >= end) continue;
+            const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
             floatx4_t acc[2][8];
+            Edge2 ed;
             td_first_layer16<true>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
             const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
             const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
@@ -371,14 +373,18 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
                 const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
                 const float sm = td_sum16(p0 + p1);
                 const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
-                al[0][r] = p0 * inv * ed.ew[0];
-                al[1][r] = p1 * inv * ed.ew[1];
+                al[rr][0][r] = p0 * inv * ed.ew[0];
+                al[rr][1][r] = p1 * inv * ed.ew[1];
             }
         }
         __syncthreads();
         td_stage_tables16<WAVES>(lds, ar.mlp_v, 8 * 4 * 64 / 4, tid);
         __syncthreads();
-        if (active) {
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int64_t it = base + rr * WAVES + wid;
+            if (it >= end) continue;
+            const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
             floatx4_t acc[2][8];
             Edge2 ev;
             td_first_layer16<false>(av, Rt, GAM, BET, offk, i, lane, acc, ev);
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
                 const float bias = __shfl(b2, 4 * g + r);
 #pragma unroll
                 for (int eb = 0; eb < 2; ++eb) {
-                    const float wgt = ev.valid[eb] ? al[eb][r] * (xv[eb][r] + bias) : 0.f;
+                    const float wgt = ev.valid[eb] ? al[rr][eb][r] * (xv[eb][r] + bias) : 0.f;
                     sx = fmaf(wgt, ev.rel[eb][0], sx);
                     sy = fmaf(wgt, ev.rel[eb][1], sy);
                     sz = fmaf(wgt, ev.rel[eb][2], sz);
