@@ -139,9 +139,11 @@ int td_session_create(const td_model *m, const float *d_protein_pos, const float
 void td_session_destroy(td_session *s);
 int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *d_ligand_v, float *d_pred_ligand_pos,
                        float *d_pred_ligand_v, float *d_final_ligand_h, void *stream);
-/* rows processed by the last td_session_forward: counts[0] = N (layers 1 .. L-2), counts[1] = rows recomputed at layer 0
- * (ligand + displaced protein rows), counts[2] = rows updated by the last layer (ligand + in-neighbours); synchronises */
-int td_session_row_counts(td_session *s, int32_t *host_counts3, void *stream);
+/* rows processed by the last td_session_forward: counts[0] = N, counts[1] = rows recomputed at layer 0 (ligand +
+ * displaced protein rows), counts[2 + k] = size of receptive-field level k + 1 of the ligand outputs (level 1 = ligand
+ * atoms + their neighbours, level k + 1 = level k + its neighbours; the layer e from the end updates level e + 1 only),
+ * -1 for levels the session does not track; synchronises */
+int td_session_row_counts(td_session *s, int32_t *host_counts, int32_t n_counts, void *stream);
 
 /* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
  *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;

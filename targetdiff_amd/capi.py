@@ -49,7 +49,7 @@ SIGNATURES = {
     'td_session_create': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, POINTER(c_void_p)]),
     'td_session_destroy': (None, [_P]),
     'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
-    'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), _P]),
+    'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
     'td_debug_edge_timing': (c_int32, [_P, c_int32]),
@@ -317,10 +317,12 @@ class NativeSession:
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': None, 'final_ligand_h': lig_h}
 
     def row_counts(self):
-        """(N, rows recomputed at layer 0, rows updated by the last layer) of the last forward; synchronises."""
-        n = (c_int32 * 3)()
-        _check(self.lib.td_session_row_counts(self.handle, n, _stream()), 'td_session_row_counts')
-        return int(n[0]), int(n[1]), int(n[2])
+        """(N, rows recomputed at layer 0, [receptive-field level sizes ...]) of the last forward; synchronises.
+
+        Level k (1-based) is what the layer k - 1 from the end has to update when only ligand outputs are read."""
+        n = (c_int32 * 10)()
+        _check(self.lib.td_session_row_counts(self.handle, n, 10, _stream()), 'td_session_row_counts')
+        return int(n[0]), int(n[1]), [int(v) for v in n[2:] if v >= 0]
 
     def dirty_rows(self) -> int:
         return self.row_counts()[1]

@@ -498,9 +498,13 @@ int h2x_attend(const TdLayer &L, Workspace &w, float *h, int64_t Nl, float4 *xc,
 // ligand outputs are consumed.
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
                  float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
-                 const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr) {
+                 const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr, int hop_levels = 0) {
     int rc;
     const int Lc = m->cfg.num_layers;
+    if (!fast_edges()) hop_levels = 0;
+    // row list of receptive-field level k (1-based); nullptr = every row
+    auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
+    auto level_count = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_count + (k - 1) : nullptr; };
     if (!graph_ready) {
         { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
         { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
@@ -511,15 +515,16 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     for (int l = 0; l < Lc; ++l) {
         const TdLayer &L = m->layers[l];
         if (!(l == 0 && layer0_x2h_done)) {
+            // Sampling session: only ligand outputs are consumed, so the layer e from the end updates receptive-field
+            // level e + 1 only, and its projections are needed on level e + 2 (those rows and their neighbours).
+            const int e = Lc - 1 - l;
+            const int32_t *prow = l > 0 ? level_rows(e + 2) : nullptr, *pcnt = l > 0 ? level_count(e + 2) : nullptr;
+            const int32_t *rws = l > 0 ? level_rows(e + 1) : nullptr, *cnt = l > 0 ? level_count(e + 1) : nullptr;
             {
                 ProfScope ps(PC_NODE, s);
-                if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc;
+                if ((rc = td_launch_node_proj(L.nodeX2h, h, N, prow, 0x1f, w.P, w.q, s, pcnt)) != TD_OK) return rc;
             }
             if (fast_edges()) {
-                // last layer of a sampling step: only the ligand atoms' outputs are consumed, so only the ligand atoms and
-                // their in-neighbours need this layer's h (the final h2x reads the neighbours' projections)
-                const bool prune = hop_rows && l == Lc - 1 && l > 0;
-                const int32_t *rws = prune ? hop_rows : nullptr, *cnt = prune ? hop_count : nullptr;
                 { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
                 { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
             } else {
@@ -528,7 +533,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
         }
         if (!do_h2x) continue;
-        if ((rc = h2x_project(L, w, h, N, Nl, w.P, w.q, hop_rows, hop_count, s)) != TD_OK) return rc;
+        if ((rc = h2x_project(L, w, h, N, Nl, w.P, w.q, level_rows(1), level_count(1), s)) != TD_OK) return rc;
         if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.P, w.q, w.alpha, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
     }
@@ -702,6 +707,7 @@ struct td_session {
     char *block;
     Workspace w;                 // per-step buffers (x4a/x4b, gid, nbr, lig_node, node_ptr, ew, P, q, h, alpha)
     int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count, *hop_rows, *hop_count;
+    int hop_levels;
     unsigned long long *skeys;
     float *ews, *h0, *h1s, *P0, *q0;
     uint8_t *clean;
@@ -728,7 +734,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
                  o_snbr = reserve(n * TD_K * 4), o_skeys = reserve(n * TD_K * 8), o_ews = reserve(n * TD_K * 4),
                  o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_P0 = reserve(n * 4 * TD_H * 4),
                  o_q0 = reserve(n * TD_H * 4), o_clean = reserve(n), o_dirty = reserve(n * 4), o_dcnt = reserve(256),
-                 o_hop = reserve(n * 4), o_hcnt = reserve(256),
+                 o_hop = reserve(n * 4 * TD_HOP_LEVELS), o_hcnt = reserve(256),
                  o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), off);
     if (e != hipSuccess) {
@@ -753,6 +759,15 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->dirty_count = reinterpret_cast<int32_t *>(b + o_dcnt);
     S->hop_rows = reinterpret_cast<int32_t *>(b + o_hop);
     S->hop_count = reinterpret_cast<int32_t *>(b + o_hcnt);
+    {
+        // receptive-field levels tracked per step (each prunes one more layer from the end); TD_HOP_LEVELS caps it
+        const char *e = getenv("TD_SESSION_HOP_LEVELS");
+        int lv = e ? atoi(e) : TD_HOP_LEVELS;
+        if (lv < 1) lv = 1;
+        if (lv > TD_HOP_LEVELS) lv = TD_HOP_LEVELS;
+        if (lv > m->cfg.num_layers) lv = m->cfg.num_layers;
+        S->hop_levels = lv;
+    }
     float *tmp_lpos = reinterpret_cast<float *>(b + o_tmp_lpos);
     int64_t *tmp_lv = reinterpret_cast<int64_t *>(b + o_tmp_lv);
     Workspace &w = S->w;
@@ -823,20 +838,22 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
-    if ((rc = td_launch_ligand_hop_rows(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, s)) != TD_OK) return rc;
+    if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s)) != TD_OK) return rc;
     float4 *xf = nullptr;
-    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count)) != TD_OK) return rc;
+    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
 }
 
-extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts3, void *stream) {
-    if (!S || !host_counts3) { td_set_error("td_session_row_counts: null pointer"); return TD_EINVAL; }
+extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_t n_counts, void *stream) {
+    if (!S || !host_counts || n_counts < 2) { td_set_error("td_session_row_counts: bad argument"); return TD_EINVAL; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    host_counts3[0] = (int32_t)S->N;
-    TD_CHECK_HIP(hipMemcpyAsync(host_counts3 + 1, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    TD_CHECK_HIP(hipMemcpyAsync(host_counts3 + 2, S->hop_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    host_counts[0] = (int32_t)S->N;
+    TD_CHECK_HIP(hipMemcpyAsync(host_counts + 1, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    for (int k = 0; k + 2 < n_counts; ++k) host_counts[k + 2] = -1;
+    const int lv = S->hop_levels < n_counts - 2 ? S->hop_levels : n_counts - 2;
+    if (lv > 0) TD_CHECK_HIP(hipMemcpyAsync(host_counts + 2, S->hop_count, sizeof(int32_t) * (size_t)lv, hipMemcpyDeviceToHost, s));
     TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }

@@ -325,18 +325,21 @@ int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, i
     return TD_OK;
 }
 
-// rows whose layer-L output is still needed when only ligand outputs are consumed: the ligand atoms and their
-// in-neighbours (the last h2x reads the neighbours' projections).  flags must be zeroed before the launch.
-__global__ void mark_ligand_hop_kernel(const int32_t *__restrict__ lig_node, int64_t Nl, const int32_t *__restrict__ nbr,
-                                       uint8_t *__restrict__ flags) {
+// Receptive field of the ligand outputs, one level per layer counted from the last: level 1 = the ligand atoms and
+// their neighbours (the last h2x reads the neighbours' projections), level k + 1 = level k plus its neighbours.  When
+// only ligand outputs are consumed, the layer e from the end needs new features for level e + 1 only.
+// flags[i] = first level that reaches node i (0 = not reached yet).
+__global__ void expand_hop_kernel(const int32_t *__restrict__ rows, int64_t count, const int32_t *__restrict__ count_ptr,
+                                  const int32_t *__restrict__ nbr, int level, uint8_t *__restrict__ flags) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t a = t >> 5;
-    if (a >= Nl) return;
-    const int i = lig_node[a];
+    if (count_ptr) count = *count_ptr;
+    if (a >= count) return;
+    const int i = rows[a];
     const int e = (int)(t & 31);
-    if (e == 0) flags[i] = 1;
+    if (e == 0 && flags[i] == 0) flags[i] = (uint8_t)level;
     const int j = nbr[(int64_t)i * TD_K + e];
-    if (j >= 0) flags[j] = 1;
+    if (j >= 0 && flags[j] == 0) flags[j] = (uint8_t)level;     // racing writers store the same value
 }
 
 __global__ void compact_flags_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
@@ -351,15 +354,23 @@ __global__ void compact_flags_kernel(const uint8_t *__restrict__ flags, int64_t 
     if (on) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
 }
 
-int td_launch_ligand_hop_rows(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
-                              int32_t *rows, int32_t *count, hipStream_t s) {
-    if (N == 0) return TD_OK;
+// rows: [levels][N] row lists, counts: [levels] device-side lengths
+int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
+                         int32_t *rows, int32_t *counts, int levels, hipStream_t s) {
+    if (N == 0 || levels <= 0) return TD_OK;
     TD_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)N, s));
-    TD_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
-    if (Nl > 0) mark_ligand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nbr, flags);
-    TD_CHECK_HIP(hipGetLastError());
-    compact_flags_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags, N, rows, count);
-    TD_CHECK_HIP(hipGetLastError());
+    TD_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)levels, s));
+    for (int k = 0; k < levels; ++k) {
+        if (k == 0) {
+            if (Nl > 0) expand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nullptr, nbr, 1, flags);
+        } else {
+            expand_hop_kernel<<<dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, s>>>(rows + (size_t)(k - 1) * N, N, counts + k - 1,
+                                                                                         nbr, k + 1, flags);
+        }
+        TD_CHECK_HIP(hipGetLastError());
+        compact_flags_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags, N, rows + (size_t)k * N, counts + k);
+        TD_CHECK_HIP(hipGetLastError());
+    }
     return TD_OK;
 }
 

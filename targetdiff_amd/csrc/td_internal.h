@@ -118,8 +118,9 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
                         uint8_t *clean, hipStream_t s);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
-int td_launch_ligand_hop_rows(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
-                              int32_t *rows, int32_t *count, hipStream_t s);
+constexpr int TD_HOP_LEVELS = 4;
+int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
+                         int32_t *rows, int32_t *counts, int levels, hipStream_t s);
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
                             float *h, float4 *x4, hipStream_t s);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);

@@ -135,16 +135,17 @@ def pack_samples(pockets, samples_per_pocket, ligand_num_atoms) -> PackedBatch:
     return PackedBatch(torch.cat(pos), torch.cat(feat), torch.cat(bp), bl, ligand_num_atoms, g)
 
 
-def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, generator=None):
+def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, generator=None, spread: float = 1.0):
     """scripts/sample_diffusion.py:60-70: positions = protein centroid + N(0, I); types = arg-max of Gumbel
-    noise over uniform logits (models/molopt_score_model.py:160-166)."""
+    noise over uniform logits (models/molopt_score_model.py:160-166).  `spread` != 1 scales the noise (benchmarks use
+    it to emulate the geometry of a later, spread-out ligand; the reference's initial state is spread = 1)."""
     dev = batch.protein_pos.device
     B = batch.num_graphs
     s = torch.zeros(B, 3, device=dev).index_add_(0, batch.protein_element_batch, batch.protein_pos)
     c = torch.bincount(batch.protein_element_batch, minlength=B).clamp(min=1).unsqueeze(-1).float()
     center = (s / c)[batch.ligand_element_batch]
     n = center.shape[0]
-    pos = center + torch.randn(n, 3, generator=generator, device=dev)
+    pos = center + spread * torch.randn(n, 3, generator=generator, device=dev)
     u = torch.rand(n, num_classes, generator=generator, device=dev)
     v = (-torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)
     return pos, v

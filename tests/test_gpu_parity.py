@@ -351,8 +351,10 @@ def test_session_forward_equals_stateless_forward(model, case):
         got = sess.forward(lpos, lv)
         for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
             assert torch.equal(got[k], want[k]), (case, step, k, _maxdiff(got[k], want[k]))
-        n_all, dirty, hop = sess.row_counts()
-        assert n_all == N and lpos.shape[0] <= dirty <= N and lpos.shape[0] <= hop <= N
+        n_all, dirty, levels = sess.row_counts()
+        assert n_all == N and lpos.shape[0] <= dirty <= N
+        # receptive-field levels of the ligand outputs: nested, each at least the ligand atoms, at most every node
+        assert len(levels) >= 1 and all(lpos.shape[0] <= a <= b <= N for a, b in zip(levels, levels[1:] + [N]))
         if case == '1h36':
             assert dirty < 0.5 * N, (dirty, N)
         # move the ligand like a sampling step would (and shuffle the types) before the next comparison
