@@ -42,6 +42,7 @@ from targetdiff_amd import capi, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
+PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E ~ 8 TB/s
 # Dominant kernels: edge_value16_kernel (x2h value pass) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
 # identical for the two passes:
 #   executed  = 2 * (32*128*20 [radial/type first layer] + 128*128 [out = W2v Zbar | U_i = W2k^T q_i]
@@ -230,6 +231,9 @@ def main():
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'traffic': traffic, 'launch_ms': ms, 'launches': p['launches'],
+                # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
+                'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
+                'hbm_frac': (traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                 'achieved_canonical_formulation': KEY_PASS_FLOP_CANONICAL * rows_per_launch / (ms * 1e-3) / 1e12,
                 'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
                 'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}

@@ -23,6 +23,18 @@ from targetdiff_amd import workloads
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 SEED = 2021
+KEEP_EXISTING = '--keep-existing' in sys.argv      # only write fixtures that are not in tests/golden yet
+
+
+def _save(path, **arrays):
+    """np.savez_compressed, except that --keep-existing leaves committed fixtures byte-identical (zip timestamps)."""
+    if KEEP_EXISTING and os.path.exists(path):
+        with np.load(path) as z:
+            for k, v in arrays.items():
+                assert np.array_equal(z[k], np.asarray(v)), (path, k, 'regenerated fixture differs from the committed one')
+        print('kept', os.path.basename(path), '(regenerated values identical)')
+        return
+    np.savez_compressed(path, **arrays)
 
 
 def build_reference_model(ref, seed=SEED):
@@ -108,7 +120,7 @@ def main():
     # ---------------------------------------------------------------- schedules (molopt_score_model.py:221-267)
     names = ['betas', 'alphas_cumprod', 'posterior_mean_c0_coef', 'posterior_mean_ct_coef', 'posterior_logvar',
              'log_alphas_v', 'log_one_minus_alphas_v', 'log_alphas_cumprod_v', 'log_one_minus_alphas_cumprod_v']
-    np.savez_compressed(os.path.join(GOLDEN_DIR, 'schedules.npz'),
+    _save(os.path.join(GOLDEN_DIR, 'schedules.npz'),
                         **{n: getattr(model, n).detach().numpy() for n in names})
 
     # ---------------------------------------------------------------- 1h36 pocket (examples/, real geometry)
@@ -120,7 +132,7 @@ def main():
     space = atom_num.get_space_size(pocket.pos)
     np.random.seed(SEED)
     sizes100 = np.array([atom_num.sample_atom_num(space).astype(int) for _ in range(100)])
-    np.savez_compressed(os.path.join(GOLDEN_DIR, 'pocket_1h36.npz'), pos=pocket.pos,
+    _save(os.path.join(GOLDEN_DIR, 'pocket_1h36.npz'), pos=pocket.pos,
                         feat=pocket.feat.astype(np.int8), prior_sizes_seed2021=sizes100, space_size=space)
     print('1h36:', pocket.num_atoms, 'atoms; space size', space, 'sizes[:8]', sizes100[:8], 'mean', sizes100.mean())
 
@@ -136,7 +148,7 @@ def main():
     for e, d in enumerate(dst.tolist()):
         ew_tab[d, slot[d]] = e_w[e]
         slot[d] += 1
-    np.savez_compressed(
+    _save(
         os.path.join(GOLDEN_DIR, 'forward_small.npz'),
         protein_pos=ppos.numpy(), protein_feat=b.protein_atom_feature.numpy().astype(np.int8),
         batch_protein=b.protein_element_batch.numpy(), ligand_pos=lpos_c.numpy(), ligand_v=lv.numpy(),
@@ -151,7 +163,7 @@ def main():
     with torch.no_grad():
         pe = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lpos_c, lv,
                    b.ligand_element_batch, fix_x=True)
-    np.savez_compressed(os.path.join(GOLDEN_DIR, 'forward_small_fixx.npz'),
+    _save(os.path.join(GOLDEN_DIR, 'forward_small_fixx.npz'),
                         pred_ligand_pos=pe['pred_ligand_pos'].numpy(), pred_ligand_v=pe['pred_ligand_v'].numpy(),
                         final_ligand_h=pe['final_ligand_h'].numpy())
 
@@ -162,7 +174,7 @@ def main():
     ppos2, lpos2c, preds2, inter2 = ref_forward_with_intermediates(ref, model, b2, lpos2, lv2)
     N2 = ppos2.shape[0] + lpos2c.shape[0]
     nbr2 = edge_index_to_table(inter2['edge_index'], N2, k)
-    np.savez_compressed(
+    _save(
         os.path.join(GOLDEN_DIR, 'forward_1h36x2.npz'),
         ligand_pos=lpos2c.numpy(), ligand_v=lv2.numpy(), sizes=sizes100[:2],
         nbr=nbr2.numpy().astype(np.int32),
@@ -192,7 +204,7 @@ def main():
                                        lpos, lv, b.ligand_element_batch, num_steps=6, center_pos_mode='protein')
     finally:
         torch.randn_like, torch.rand_like = o_randn, o_rand
-    np.savez_compressed(
+    _save(
         os.path.join(GOLDEN_DIR, 'sample_small.npz'),
         init_ligand_pos=lpos.numpy(), init_ligand_v=lv.numpy(),
         noises=torch.stack(rec['randn']).numpy(), uniforms=torch.stack(rec['rand']).numpy(),
@@ -224,10 +236,54 @@ def main():
         log_post = model.q_v_posterior(log_v0, log_vt, t, bl)
         gumbel = -torch.log(-torch.log(uni + 1e-30) + 1e-30)
         v_next = (gumbel + log_post).argmax(dim=-1)
-    np.savez_compressed(os.path.join(GOLDEN_DIR, 'posterior_kat.npz'), t=t.numpy(), batch_ligand=bl.numpy(),
+    _save(os.path.join(GOLDEN_DIR, 'posterior_kat.npz'), t=t.numpy(), batch_ligand=bl.numpy(),
                         x_t=x_t.numpy(), x0=x0.numpy(), v_t=v_t.numpy(), v0_logits=v0_logits.numpy(),
                         noise=noise.numpy(), uniform=uni.numpy(), pos_next=pos_next.numpy(),
                         v_next=v_next.numpy(), log_v0=log_v0.numpy(), log_post=log_post.numpy())
+    # ---------------------------------------------------------------- return_all (num_blocks = 1: block input + output)
+    ppos_c, lpos_c, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    with torch.no_grad():
+        pa = model(ppos_c, b.protein_atom_feature.float(), b.protein_element_batch, lpos_c, lv,
+                   b.ligand_element_batch, return_all=True)
+    _save(os.path.join(GOLDEN_DIR, 'forward_small_return_all.npz'),
+                        layer_pred_ligand_pos=torch.stack(pa['layer_pred_ligand_pos']).numpy(),
+                        layer_pred_ligand_v=torch.stack(pa['layer_pred_ligand_v']).numpy())
+    print('return_all: layers', len(pa['layer_pred_ligand_pos']))
+
+    # ---------------------------------------------------------------- likelihood_estimation, recorded RNG
+    # (scripts/likelihood_est_diffusion.py:30,48): mixed time steps incl. the t == 0 decoder branch, and the prior
+    rec = {'normal': [], 'rand': []}
+    o_normal, o_rand = torch.Tensor.normal_, torch.rand_like
+
+    def normal_(self, *a, **kw):
+        out = o_normal(self, *a, **kw)
+        rec['normal'].append(out.clone())
+        return out
+
+    def rand_like2(x, *a, **kw):
+        out = o_rand(x, *a, **kw)
+        rec['rand'].append(out.clone())
+        return out
+    torch.Tensor.normal_, torch.rand_like = normal_, rand_like2
+    try:
+        torch.manual_seed(SEED + 1)
+        tl = torch.tensor([0, 1, 537], dtype=torch.long)
+        kl_pos, kl_v = model.likelihood_estimation(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                                                   lpos, lv, b.ligand_element_batch, tl)
+        tT = torch.full((3,), 1000, dtype=torch.long)
+        klp_prior, klv_prior = model.likelihood_estimation(b.protein_pos, b.protein_atom_feature.float(),
+                                                           b.protein_element_batch, lpos, lv, b.ligand_element_batch, tT)
+    finally:
+        torch.Tensor.normal_, torch.rand_like = o_normal, o_rand
+    assert len(rec['normal']) == 1 and len(rec['rand']) == 1
+    _save(os.path.join(GOLDEN_DIR, 'likelihood_small.npz'), time_step=tl.numpy(),
+                        protein_pos=b.protein_pos.numpy(), protein_feat=b.protein_atom_feature.numpy().astype(np.int8),
+                        batch_protein=b.protein_element_batch.numpy(), batch_ligand=b.ligand_element_batch.numpy(),
+                        ligand_pos=lpos.numpy(), ligand_v=lv.numpy(), noise=rec['normal'][0].numpy(),
+                        uniform=rec['rand'][0].numpy(), kl_pos=kl_pos.numpy(), kl_v=kl_v.numpy(),
+                        kl_pos_prior=klp_prior.numpy(), kl_v_prior=klv_prior.numpy())
+    print('likelihood_small:', kl_pos.numpy(), kl_v.numpy(), klp_prior.numpy(), klv_prior.numpy())
+
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)) // 1024, 'KiB')
 

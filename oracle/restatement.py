@@ -199,7 +199,7 @@ def compose_context(h_p, h_l, pos_p, pos_l, batch_p, batch_l):
 
 
 def model_forward(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand,
-                  fix_x=False, dtype=torch.float32, collect=None):
+                  fix_x=False, dtype=torch.float32, collect=None, return_all=False):
     """ScorePosNet3D.forward (models/molopt_score_model.py:313-368), time_emb_dim == 0, node_indicator."""
     cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
     C = sd['ligand_atom_emb.weight'].shape[1]
@@ -216,7 +216,14 @@ def model_forward(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, li
     y = F.linear(fh, sd['v_inference.0.weight'].to(dtype), sd['v_inference.0.bias'].to(dtype))
     y = F.softplus(y) - math.log(2.0)                                                           # common.py:156-162
     v = F.linear(y, sd['v_inference.2.weight'].to(dtype), sd['v_inference.2.bias'].to(dtype))   # :352
-    return {'pred_ligand_pos': out['x'][mask], 'pred_ligand_v': v, 'final_h': out['h'], 'final_ligand_h': fh}
+    preds = {'pred_ligand_pos': out['x'][mask], 'pred_ligand_v': v, 'final_h': out['h'], 'final_ligand_h': fh}
+    if return_all:                 # :360-367 with num_blocks == 1: the block input and the block output
+        def v_inf(hh):
+            yy = F.softplus(F.linear(hh, sd['v_inference.0.weight'].to(dtype), sd['v_inference.0.bias'].to(dtype)))
+            return F.linear(yy - math.log(2.0), sd['v_inference.2.weight'].to(dtype), sd['v_inference.2.bias'].to(dtype))
+        preds['layer_pred_ligand_pos'] = [pos[mask], out['x'][mask]]
+        preds['layer_pred_ligand_v'] = [v_inf(h[mask]), v]
+    return preds
 
 
 # ----------------------------------------------------------------------------------------- posterior
@@ -285,3 +292,96 @@ def sample_diffusion(sd, cfg, protein_pos, protein_v, batch_protein, init_ligand
             traj['v0_traj'].append(log_v0.clone())
             traj['vt_traj'].append(log_post.clone())
     return dict(pos=lpos + off[batch_ligand], v=lv, **traj)
+
+
+# ------------------------------------------------------------------------------------------ likelihood estimation
+def _q_v_pred(sched, log_v0, tb, lnK):                                                           # :383-392
+    return _log_add_exp(log_v0 + sched['log_alphas_cumprod_v'][tb].unsqueeze(-1),
+                        sched['log_one_minus_alphas_cumprod_v'][tb].unsqueeze(-1) - lnK)
+
+
+def _q_v_posterior(sched, log_v0, log_vt, t, batch, lnK):                                        # :401-409
+    tm1 = torch.where(t - 1 < 0, torch.zeros_like(t), t - 1)[batch]
+    tb = t[batch]
+    un = _q_v_pred(sched, log_v0, tm1, lnK) + _log_add_exp(
+        log_vt + sched['log_alphas_v'][tb].unsqueeze(-1), sched['log_one_minus_alphas_v'][tb].unsqueeze(-1) - lnK)
+    return un - torch.logsumexp(un, dim=-1, keepdim=True)
+
+
+def _scatter_mean(v, batch, B):
+    s = torch.zeros(B, dtype=v.dtype).index_add_(0, batch, v)
+    return s / torch.bincount(batch, minlength=B).clamp(min=1).to(v.dtype)
+
+
+def perturb(sched, t, ligand_pos, ligand_v, batch_ligand, noise, uniform, num_classes):
+    """Forward-process sample used by likelihood_estimation (models/molopt_score_model.py:577-588):
+    x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps;  v_t ~ q(v_t | v_0) by Gumbel-max with injected uniforms."""
+    a = sched['alphas_cumprod'][t][batch_ligand].unsqueeze(-1)
+    xt = a.sqrt() * ligand_pos + (1.0 - a).sqrt() * noise
+    log_v0 = torch.log(F.one_hot(ligand_v, num_classes).float().clamp(min=1e-30))
+    log_q = _q_v_pred(sched, log_v0, t[batch_ligand], np.log(num_classes))
+    gumbel = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
+    return xt, (gumbel + log_q).argmax(dim=-1)
+
+
+def likelihood_terms(sched, t, x0, xt, v0, vt, pred_pos, pred_v, batch_ligand, num_classes):
+    """kl_pos, kl_v per graph (models/molopt_score_model.py:594-613 with compute_pos_Lt :463-474 and compute_v_Lt
+    :476-483): KL between the true and the model posterior for t > 0, decoder NLL for t == 0, mean over the atoms."""
+    B = int(t.numel())
+    tb = t[batch_ligand]
+    lnK = np.log(num_classes)
+    c0 = sched['posterior_mean_c0_coef'][tb].unsqueeze(-1)
+    ct = sched['posterior_mean_ct_coef'][tb].unsqueeze(-1)
+    logvar = sched['posterior_logvar'][tb].unsqueeze(-1)
+    model_mean = c0 * pred_pos + ct * xt
+    true_mean = c0 * x0 + ct * xt
+    kl_pos = (0.5 * (-1.0 + logvar - logvar + torch.exp(logvar - logvar)
+                     + (true_mean - model_mean) ** 2 * torch.exp(-logvar))).sum(-1) / np.log(2.)
+    log_scales = 0.5 * logvar
+    nll_pos = -(-((x0 - model_mean) ** 2) / (2 * torch.exp(log_scales * 2)) - log_scales
+                - np.log(np.sqrt(2 * np.pi))).sum(-1)
+    mask = (t == 0).float()[batch_ligand]
+    out_pos = _scatter_mean(mask * nll_pos + (1. - mask) * kl_pos, batch_ligand, B)
+    log_v0 = torch.log(F.one_hot(v0, num_classes).float().clamp(min=1e-30))
+    log_vt = torch.log(F.one_hot(vt, num_classes).float().clamp(min=1e-30))
+    log_model = _q_v_posterior(sched, F.log_softmax(pred_v, dim=-1), log_vt, t, batch_ligand, lnK)
+    log_true = _q_v_posterior(sched, log_v0, log_vt, t, batch_ligand, lnK)
+    kl_v = (log_true.exp() * (log_true - log_model)).sum(dim=1)
+    nll_v = -(log_v0.exp() * log_model).sum(dim=1)
+    out_v = _scatter_mean(mask * nll_v + (1. - mask) * kl_v, batch_ligand, B)
+    return out_pos, out_v
+
+
+def likelihood_prior(sched, x0, v_index, batch_ligand, num_classes):
+    """kl_pos_prior, kl_v_prior (models/molopt_score_model.py:572-576, :410-416, :430-438).  NB the reference passes
+    ``batch_ligand`` where the atom types are meant (:574); callers reproduce that through ``v_index``."""
+    B = int(batch_ligand.max()) + 1
+    T = sched['alphas_cumprod'].numel()
+    a = sched['alphas_cumprod'][T - 1]
+    mean2 = a.sqrt() * x0
+    logvar2 = torch.log((1.0 - a).sqrt())
+    kl = (0.5 * (-1.0 + logvar2 - 0.0 + torch.exp(0.0 - logvar2) + (0.0 - mean2) ** 2 * torch.exp(-logvar2))).sum(-1)
+    kl_pos = _scatter_mean(kl, batch_ligand, B)
+    log_x = torch.log(F.one_hot(v_index, num_classes).float().clamp(min=1e-30))
+    tb = torch.full_like(batch_ligand, T - 1)
+    log_q = _q_v_pred(sched, log_x, tb, np.log(num_classes))
+    log_half = -torch.log(num_classes * torch.ones_like(log_q))
+    kl_v = _scatter_mean((log_q.exp() * (log_q - log_half)).sum(dim=1), batch_ligand, B)
+    return kl_pos, kl_v
+
+
+def likelihood_estimation(sd, cfg, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand,
+                          time_step, noise=None, uniform=None):
+    """ScorePosNet3D.likelihood_estimation (models/molopt_score_model.py:565-613) with the Gaussian / uniform draws
+    injected."""
+    cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
+    sched = diffusion_schedules(cfg)
+    T = cfg['num_diffusion_timesteps']
+    K = sd['ligand_atom_emb.weight'].shape[1]
+    ppos, lpos, _ = center_positions(protein_pos, ligand_pos, batch_protein, batch_ligand)
+    if bool((time_step == T).all()):
+        return likelihood_prior(sched, lpos, batch_ligand, batch_ligand, K)
+    xt, vt = perturb(sched, time_step, lpos, ligand_v, batch_ligand, noise, uniform, K)
+    preds = model_forward(sd, cfg, ppos, protein_v, batch_protein, xt, vt, batch_ligand)
+    return likelihood_terms(sched, time_step, lpos, xt, ligand_v, vt, preds['pred_ligand_pos'],
+                            preds['pred_ligand_v'], batch_ligand, K)

@@ -108,3 +108,34 @@ def test_weight_spec_is_complete():
     n = sum(int(np.prod(s)) for k, s, kind, _ in spec if kind != 'offset')
     assert n == 2824692           # trainable parameters of the default model
     assert len(spec) == 384 - 17  # state-dict entries minus 15 schedule constants and 2 buffers
+
+
+def test_return_all_matches_reference(state_dict, golden_small):
+    g = load_golden('forward_small_return_all.npz')
+    inp = small_inputs(golden_small)
+    out = R.model_forward(state_dict, None, inp['protein_pos'], inp['protein_v'], inp['batch_protein'],
+                          inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'], return_all=True)
+    assert len(out['layer_pred_ligand_pos']) == g['layer_pred_ligand_pos'].shape[0] == 2
+    for l in range(2):
+        assert _maxdiff(out['layer_pred_ligand_pos'][l], g['layer_pred_ligand_pos'][l]) < 2e-5
+        assert _maxdiff(out['layer_pred_ligand_v'][l], g['layer_pred_ligand_v'][l]) < 2e-5
+
+
+def _likelihood_inputs(g):
+    return dict(protein_pos=torch.from_numpy(g['protein_pos']), protein_v=torch.from_numpy(g['protein_feat'].astype(np.float32)),
+                batch_protein=torch.from_numpy(g['batch_protein']), ligand_pos=torch.from_numpy(g['ligand_pos']),
+                ligand_v=torch.from_numpy(g['ligand_v']), batch_ligand=torch.from_numpy(g['batch_ligand']))
+
+
+def test_likelihood_estimation_matches_reference(state_dict):
+    """scripts/likelihood_est_diffusion.py:30,48 -- KL terms at t = (0, 1, 537) with the reference's recorded draws, and
+    the prior term.  Relative tolerance 1e-4 (the t = 0 decoder NLL is O(1e3)), absolute 1e-6 for the near-zero KLs."""
+    g = load_golden('likelihood_small.npz')
+    inp = _likelihood_inputs(g)
+    kl_pos, kl_v = R.likelihood_estimation(state_dict, None, **inp, time_step=torch.from_numpy(g['time_step']),
+                                           noise=torch.from_numpy(g['noise']), uniform=torch.from_numpy(g['uniform']))
+    np.testing.assert_allclose(kl_pos.numpy(), g['kl_pos'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(kl_v.numpy(), g['kl_v'], rtol=1e-4, atol=1e-6)
+    klp, klv = R.likelihood_estimation(state_dict, None, **inp, time_step=torch.full((3,), 1000, dtype=torch.long))
+    np.testing.assert_allclose(klp.numpy(), g['kl_pos_prior'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(klv.numpy(), g['kl_v_prior'], rtol=1e-4, atol=1e-7)
