@@ -116,6 +116,29 @@ int td_posterior_step(const td_model *m, const int32_t *d_t, const int32_t *d_li
                       const float *d_uniform, float *d_pos_next, int64_t *d_v_next, float *d_log_v0,
                       float *d_log_post, void *stream);
 
+/* ---- other consumers of the denoiser (scripts/likelihood_est_diffusion.py; ScorePosNet3D.forward(return_all=True)).
+ * They need the 8th schedule array (alphas_cumprod of the position schedule) at td_model_create.
+ *
+ * td_perturb: the forward-process sample inside ScorePosNet3D.likelihood_estimation (models/molopt_score_model.py:577-588;
+ *   q_v_sample :394-398): pos_t = sqrt(abar_t) pos_0 + sqrt(1 - abar_t) noise; v_t = argmax(gumbel(uniform) + log q(v_t|v_0)).
+ * td_likelihood_terms: per-graph kl_pos, kl_v of the same function (:594-613 = q_pos_posterior :424-428, q_v_posterior
+ *   :401-409, compute_pos_Lt :463-474, compute_v_Lt :476-483): posterior KL for t > 0, decoder NLL for t == 0, mean over
+ *   the graph's ligand atoms.  kl_*: [B].
+ * td_likelihood_prior: the time_step == T branch (:569-576 = kl_pos_prior :430-438, kl_v_prior :410-416).  v_index is
+ *   what the reference feeds index_to_log_onehot there (it passes batch_ligand, :574).
+ * td_embed_ligand / td_v_inference: ligand_atom_emb (+ node indicator, :317,334,338) and v_inference (:307-311) on
+ *   free-standing rows -- the block-input entries of layer_pred_ligand_v (:360-367). */
+int td_perturb(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+               const float *d_ligand_pos, const int64_t *d_ligand_v, const float *d_noise, const float *d_uniform,
+               float *d_pos_t, int64_t *d_v_t, void *stream);
+int td_likelihood_terms(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                        const float *d_pos_0, const float *d_pos_t, const int64_t *d_v_0, const int64_t *d_v_t,
+                        const float *d_pred_pos, const float *d_pred_v, float *d_kl_pos, float *d_kl_v, void *stream);
+int td_likelihood_prior(const td_model *m, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B, const float *d_pos_0,
+                        const int64_t *d_v_index, float *d_kl_pos, float *d_kl_v, void *stream);
+int td_embed_ligand(const td_model *m, const int64_t *d_ligand_v, int64_t N_l, float *d_h, void *stream);
+int td_v_inference(const td_model *m, const float *d_h, int64_t n, float *d_logits, void *stream);
+
 /* ---- centring (replaces: center_pos(mode='protein'), models/molopt_score_model.py:110-120).
  *      offset [B,3] = per-graph protein centroid; positions are shifted in place by -offset (sign = -1)
  *      or +offset (sign = +1, models/molopt_score_model.py:691,695).  d_protein_pos may be NULL to

@@ -46,6 +46,11 @@ SIGNATURES = {
                                    _P, _P, _P, c_size_t, _P]),
     'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
+    'td_perturb': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    'td_likelihood_terms': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'td_likelihood_prior': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
+    'td_embed_ligand': (c_int32, [_P, _P, c_int64, _P, _P]),
+    'td_v_inference': (c_int32, [_P, _P, c_int64, _P, _P]),
     'td_session_create': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, POINTER(c_void_p)]),
     'td_session_destroy': (None, [_P]),
     'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
@@ -144,6 +149,8 @@ def flatten_state_dict(sd, num_layers: int) -> np.ndarray:
 
 SCHEDULE_ORDER = ('posterior_mean_c0_coef', 'posterior_mean_ct_coef', 'posterior_logvar', 'log_alphas_v',
                   'log_one_minus_alphas_v', 'log_alphas_cumprod_v', 'log_one_minus_alphas_cumprod_v')
+# optional 8th array: needed by td_perturb / td_likelihood_prior (likelihood estimation), not by sampling
+SCHEDULE_OPTIONAL = ('alphas_cumprod',)
 
 
 class NativeModel:
@@ -166,7 +173,8 @@ class NativeModel:
         sched_ptr, sched_n = None, 0
         if schedules is not None:
             sch = np.ascontiguousarray(np.concatenate(
-                [np.asarray(schedules[k], dtype=np.float32).reshape(-1) for k in SCHEDULE_ORDER]))
+                [np.asarray(schedules[k], dtype=np.float32).reshape(-1)
+                 for k in SCHEDULE_ORDER + tuple(o for o in SCHEDULE_OPTIONAL if o in schedules)]))
             sched_ptr, sched_n = sch.ctypes.data_as(POINTER(c_float)), sch.size
         handle = c_void_p()
         with torch.cuda.device(self.device):
@@ -254,6 +262,48 @@ class NativeModel:
             _ptr(noise, torch.float32, 'noise'), _ptr(uniform, torch.float32, 'uniform'), _ptr(pos_next),
             _ptr(v_next, torch.int64, 'v_next'), _ptr(log_v0), _ptr(log_post), _stream()), 'td_posterior_step')
         return pos_next, v_next
+
+    # ---- likelihood estimation / return_all (the other consumers of the denoiser)
+    def perturb(self, t, ligand_ptr, ligand_pos, ligand_v, noise, uniform):
+        Nl, B = ligand_pos.shape[0], ligand_ptr.numel() - 1
+        pos_t, v_t = torch.empty_like(ligand_pos), torch.empty_like(ligand_v)
+        _check(self.lib.td_perturb(self.handle, _ptr(t, torch.int32, 't'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
+                                   _ptr(ligand_pos, torch.float32, 'ligand_pos'), _ptr(ligand_v, torch.int64, 'ligand_v'),
+                                   _ptr(noise, torch.float32, 'noise'), _ptr(uniform, torch.float32, 'uniform'),
+                                   _ptr(pos_t), _ptr(v_t), _stream()), 'td_perturb')
+        return pos_t, v_t
+
+    def likelihood_terms(self, t, ligand_ptr, pos_0, pos_t, v_0, v_t, pred_pos, pred_v):
+        Nl, B = pos_0.shape[0], ligand_ptr.numel() - 1
+        kl_pos = torch.empty(B, dtype=torch.float32, device=pos_0.device)
+        kl_v = torch.empty(B, dtype=torch.float32, device=pos_0.device)
+        _check(self.lib.td_likelihood_terms(
+            self.handle, _ptr(t, torch.int32, 't'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
+            _ptr(pos_0, torch.float32, 'pos_0'), _ptr(pos_t, torch.float32, 'pos_t'), _ptr(v_0, torch.int64, 'v_0'),
+            _ptr(v_t, torch.int64, 'v_t'), _ptr(pred_pos, torch.float32, 'pred_pos'), _ptr(pred_v, torch.float32, 'pred_v'),
+            _ptr(kl_pos), _ptr(kl_v), _stream()), 'td_likelihood_terms')
+        return kl_pos, kl_v
+
+    def likelihood_prior(self, ligand_ptr, pos_0, v_index):
+        Nl, B = pos_0.shape[0], ligand_ptr.numel() - 1
+        kl_pos = torch.empty(B, dtype=torch.float32, device=pos_0.device)
+        kl_v = torch.empty(B, dtype=torch.float32, device=pos_0.device)
+        _check(self.lib.td_likelihood_prior(self.handle, _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
+                                            _ptr(pos_0, torch.float32, 'pos_0'), _ptr(v_index, torch.int64, 'v_index'),
+                                            _ptr(kl_pos), _ptr(kl_v), _stream()), 'td_likelihood_prior')
+        return kl_pos, kl_v
+
+    def embed_ligand(self, ligand_v):
+        h = torch.empty(ligand_v.shape[0], HIDDEN, dtype=torch.float32, device=ligand_v.device)
+        _check(self.lib.td_embed_ligand(self.handle, _ptr(ligand_v, torch.int64, 'ligand_v'), ligand_v.shape[0], _ptr(h),
+                                        _stream()), 'td_embed_ligand')
+        return h
+
+    def v_inference(self, h):
+        out = torch.empty(h.shape[0], self.num_classes, dtype=torch.float32, device=h.device)
+        _check(self.lib.td_v_inference(self.handle, _ptr(h, torch.float32, 'h'), h.shape[0], _ptr(out), _stream()),
+               'td_v_inference')
+        return out
 
     def center_pos(self, protein_pos, protein_ptr, ligand_pos, ligand_ptr, offset=None, sign=-1):
         """In place.  offset=None: compute the protein centroids and subtract them (sign=-1)."""

@@ -296,11 +296,13 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         td_set_error("td_model_create: weight blob has %zu floats, expected %zu", num_weights, td_model_num_weights(cfg));
         return TD_EINVAL;
     }
-    if (host_schedules && num_schedule_floats != (size_t)7 * c.num_timesteps) {
-        td_set_error("td_model_create: schedule blob has %zu floats, expected %zu", num_schedule_floats,
-                     (size_t)7 * c.num_timesteps);
+    if (host_schedules && num_schedule_floats != (size_t)7 * c.num_timesteps &&
+        num_schedule_floats != (size_t)8 * c.num_timesteps) {
+        td_set_error("td_model_create: schedule blob has %zu floats, expected %zu (sampling) or %zu (+ alphas_cumprod)",
+                     num_schedule_floats, (size_t)7 * c.num_timesteps, (size_t)8 * c.num_timesteps);
         return TD_EINVAL;
     }
+    const bool has_abar = host_schedules && num_schedule_floats == (size_t)8 * c.num_timesteps;
     const int H = TD_H, E = H - 1, F = c.protein_feat_dim, C = c.ligand_num_classes, KV = kv_in(c), L = c.num_layers;
     Cursor cur{host_weights, num_weights};
     const float *Wp = cur.take((size_t)E * F), *bp = cur.take(E);
@@ -357,8 +359,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     // ---- schedules
     const int T = c.num_timesteps;
-    size_t oS = pk.alloc((size_t)7 * T);
-    if (host_schedules) memcpy(pk.data.data() + oS, host_schedules, (size_t)7 * T * sizeof(float));
+    size_t oS = pk.alloc((size_t)8 * T);
+    if (host_schedules) memcpy(pk.data.data() + oS, host_schedules, (size_t)(has_abar ? 8 : 7) * T * sizeof(float));
 
     td_model *m = new (std::nothrow) td_model();
     if (!m) { td_set_error("td_model_create: out of host memory"); return TD_ENOMEM; }
@@ -389,7 +391,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
     const float *S = D + oS;
-    m->sched = TdSchedules{S, S + T, S + 2 * T, S + 3 * T, S + 4 * T, S + 5 * T, S + 6 * T};
+    m->sched = TdSchedules{S, S + T, S + 2 * T, S + 3 * T, S + 4 * T, S + 5 * T, S + 6 * T, has_abar ? S + 7 * T : nullptr};
     *out = m;
     return TD_OK;
 }
@@ -662,6 +664,62 @@ extern "C" int td_posterior_step(const td_model *m, const int32_t *d_t, const in
     return td_launch_posterior(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, N_l, B, m->cfg.ligand_num_classes,
                                d_ligand_pos, d_ligand_v, d_pred_pos, d_pred_v, d_noise, d_uniform, d_pos_next,
                                d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream));
+}
+
+// ---- the other forward consumers: likelihood estimation (scripts/likelihood_est_diffusion.py) and return_all
+extern "C" int td_perturb(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                          const float *d_ligand_pos, const int64_t *d_ligand_v, const float *d_noise, const float *d_uniform,
+                          float *d_pos_t, int64_t *d_v_t, void *stream) {
+    if (!m || N_l < 0 || B < 0) { td_set_error("td_perturb: bad argument"); return TD_EINVAL; }
+    if (!m->sched.abar) { td_set_error("td_perturb: the model was created without alphas_cumprod (8 schedule arrays)"); return TD_EINVAL; }
+    if (N_l == 0) return TD_OK;
+    if (!d_t || !d_ligand_ptr || !d_ligand_pos || !d_ligand_v || !d_noise || !d_uniform || !d_pos_t || !d_v_t) {
+        td_set_error("td_perturb: null pointer");
+        return TD_EINVAL;
+    }
+    return td_launch_perturb(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, N_l, B, m->cfg.ligand_num_classes, d_ligand_pos,
+                             d_ligand_v, d_noise, d_uniform, d_pos_t, d_v_t, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_likelihood_terms(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                                   const float *d_pos_0, const float *d_pos_t, const int64_t *d_v_0, const int64_t *d_v_t,
+                                   const float *d_pred_pos, const float *d_pred_v, float *d_kl_pos, float *d_kl_v,
+                                   void *stream) {
+    if (!m || N_l < 0 || B < 0) { td_set_error("td_likelihood_terms: bad argument"); return TD_EINVAL; }
+    if (B == 0) return TD_OK;
+    if (!d_t || !d_ligand_ptr || !d_kl_pos || !d_kl_v ||
+        (N_l > 0 && (!d_pos_0 || !d_pos_t || !d_v_0 || !d_v_t || !d_pred_pos || !d_pred_v))) {
+        td_set_error("td_likelihood_terms: null pointer");
+        return TD_EINVAL;
+    }
+    return td_launch_likelihood_terms(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, B, m->cfg.ligand_num_classes, d_pos_0,
+                                      d_pos_t, d_v_0, d_v_t, d_pred_pos, d_pred_v, d_kl_pos, d_kl_v,
+                                      static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_likelihood_prior(const td_model *m, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
+                                   const float *d_pos_0, const int64_t *d_v_index, float *d_kl_pos, float *d_kl_v,
+                                   void *stream) {
+    if (!m || N_l < 0 || B < 0) { td_set_error("td_likelihood_prior: bad argument"); return TD_EINVAL; }
+    if (!m->sched.abar) { td_set_error("td_likelihood_prior: the model was created without alphas_cumprod (8 schedule arrays)"); return TD_EINVAL; }
+    if (B == 0) return TD_OK;
+    if (!d_ligand_ptr || !d_kl_pos || !d_kl_v || (N_l > 0 && (!d_pos_0 || !d_v_index))) {
+        td_set_error("td_likelihood_prior: null pointer");
+        return TD_EINVAL;
+    }
+    return td_launch_likelihood_prior(m->sched, m->cfg.num_timesteps, d_ligand_ptr, B, m->cfg.ligand_num_classes, d_pos_0,
+                                      d_v_index, d_kl_pos, d_kl_v, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_embed_ligand(const td_model *m, const int64_t *d_ligand_v, int64_t N_l, float *d_h, void *stream) {
+    if (!m || N_l < 0 || (N_l > 0 && (!d_ligand_v || !d_h))) { td_set_error("td_embed_ligand: bad argument"); return TD_EINVAL; }
+    return td_launch_embed_ligand(m->emb, m->cfg.ligand_num_classes, d_ligand_v, N_l, d_h, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_v_inference(const td_model *m, const float *d_h, int64_t n, float *d_logits, void *stream) {
+    if (!m || n < 0 || (n > 0 && (!d_h || !d_logits))) { td_set_error("td_v_inference: bad argument"); return TD_EINVAL; }
+    return td_launch_head(m->head, d_h, nullptr, nullptr, n, m->cfg.ligand_num_classes, nullptr, d_logits, nullptr,
+                          static_cast<hipStream_t>(stream));
 }
 
 extern "C" int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_ligand_pos,

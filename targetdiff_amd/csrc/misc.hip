@@ -23,10 +23,10 @@ __global__ __launch_bounds__(128) void head_kernel(TdHead hd, const float *__res
         const int64_t at = a0 + a;
         float v = 0.f;
         if (at < Nl) {
-            const int64_t p = lig_node[at];
+            const int64_t p = lig_node ? (int64_t)lig_node[at] : at;     // nullptr: free-standing rows (return_all)
             v = h[p * TD_H + n];
             if (lig_h) lig_h[at * TD_H + n] = v;
-            if (n < 3) {
+            if (n < 3 && x4) {
                 const float4 xp = x4[p];
                 pred_pos[at * 3 + n] = n == 0 ? xp.x : (n == 1 ? xp.y : xp.z);
             }

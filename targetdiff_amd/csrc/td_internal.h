@@ -83,6 +83,7 @@ struct TdHead {            // v_inference (models/molopt_score_model.py:307-311)
 
 struct TdSchedules {       // [T] each
     const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_ca, *log_1mca;
+    const float *abar;     // alphas_cumprod of the position schedule; nullptr when the model was created without it
 };
 
 struct td_model {
@@ -164,6 +165,16 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
                         const float *pred_v, const float *noise, const float *uni, float *pos_next,
                         int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
+// likelihood.hip
+int td_launch_perturb(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B, int classes,
+                      const float *pos, const int64_t *v, const float *noise, const float *uni, float *pos_t, int64_t *v_t,
+                      hipStream_t s);
+int td_launch_likelihood_terms(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t B, int classes,
+                               const float *x0, const float *xt, const int64_t *v0, const int64_t *vt, const float *pred_pos,
+                               const float *pred_v, float *kl_pos, float *kl_v, hipStream_t s);
+int td_launch_likelihood_prior(const TdSchedules &sc, int T, const int32_t *lptr, int64_t B, int classes, const float *x0,
+                               const int64_t *vidx, float *kl_pos, float *kl_v, hipStream_t s);
+int td_launch_embed_ligand(const TdEmbed &emb, int classes, const int64_t *lv, int64_t Nl, float *h, hipStream_t s);
 int td_launch_center(float *ppos, const int32_t *pptr, float *lpos, const int32_t *lptr, int64_t B, float *offset,
                      int compute, int sign, hipStream_t s);
 int td_launch_reductions(const float *in, float *out, hipStream_t s);

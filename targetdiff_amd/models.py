@@ -262,7 +262,7 @@ class ScorePosNet3D(nn.Module):
                        num_r_gaussian=rn.num_r_gaussian, edge_feat_dim=rn.edge_feat_dim,
                        protein_feat_dim=self.protein_atom_feature_dim, ligand_num_classes=self.num_classes,
                        num_timesteps=self.num_timesteps)
-            sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER}
+            sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             self._native_model = capi.NativeModel(cfg, self.state_dict(), sched, device=device)
             self._native_key = key
         return self._native_model
@@ -272,15 +272,50 @@ class ScorePosNet3D(nn.Module):
                 time_step=None, return_all=False, fix_x=False):
         """One denoiser evaluation (models/molopt_score_model.py:313-368).  ``time_step`` is unused by the
         network when time_emb_dim == 0, as in the reference."""
-        if return_all:
-            raise NotImplementedError('return_all=True is not built yet')
         native = self._native(protein_pos.device)
         B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
         pptr = native.graph_ptr(batch_protein.contiguous(), B)
         lptr = native.graph_ptr(batch_ligand.contiguous(), B)
-        return native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr,
-                                    init_ligand_pos.contiguous().float(), init_ligand_v.contiguous(), lptr,
-                                    fix_x=fix_x)
+        lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
+        preds = native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr, lpos, lv, lptr,
+                                     fix_x=fix_x)
+        if return_all:
+            # :360-367 -- the refine net records the state before and after each block; num_blocks == 1 here, so the
+            # lists hold the block input (the embedded ligand atoms at their input positions) and the block output
+            preds['layer_pred_ligand_pos'] = [lpos.clone(), preds['pred_ligand_pos']]
+            preds['layer_pred_ligand_v'] = [native.v_inference(native.embed_ligand(lv)), preds['pred_ligand_v']]
+        return preds
+
+    @torch.no_grad()
+    def likelihood_estimation(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand, time_step,
+                              noise_source=None):
+        """models/molopt_score_model.py:565-613 (scripts/likelihood_est_diffusion.py:30,48): per-graph ``(kl_pos, kl_v)``
+        at ``time_step`` [B], or the prior terms when every entry equals ``num_timesteps``.  ``noise_source(0, name,
+        like)`` may inject the Gaussian / uniform draws (parity tests); default: torch RNG in the reference's order."""
+        native = self._native(protein_pos.device)
+        T = self.num_timesteps
+        B = int(batch_protein.max().item()) + 1
+        pptr = native.graph_ptr(batch_protein.contiguous(), B)
+        lptr = native.graph_ptr(batch_ligand.contiguous(), B)
+        ppos = protein_pos.detach().clone().contiguous().float()
+        lpos = ligand_pos.detach().clone().contiguous().float()
+        lv = ligand_v.contiguous()
+        native.center_pos(ppos, pptr, lpos, lptr)                                          # :568 (mode='protein')
+        all_T, all_lt = bool((time_step == T).all()), bool((time_step < T).all())
+        assert all_T or all_lt                                                             # :570
+        if all_T:
+            assert int(batch_ligand.max().item()) < self.num_classes                       # index_to_log_onehot's check
+            return native.likelihood_prior(lptr, lpos, batch_ligand.contiguous())          # :571-575 (sic: batch_ligand)
+        t32 = time_step.to(torch.int32).contiguous()
+        if noise_source is None:
+            noise = torch.zeros_like(lpos).normal_()                                       # :579-580
+            uniform = torch.rand(lpos.shape[0], self.num_classes, dtype=torch.float32, device=lpos.device)   # :161
+        else:
+            noise = noise_source(0, 'noise', lpos)
+            uniform = noise_source(0, 'uniform', None)
+        pos_t, v_t = native.perturb(t32, lptr, lpos, lv, noise, uniform)                    # :582-586
+        preds = native.model_forward(ppos, protein_v.contiguous().float(), pptr, pos_t, v_t, lptr, want_final_h=False)
+        return native.likelihood_terms(t32, lptr, lpos, pos_t, lv, v_t, preds['pred_ligand_pos'], preds['pred_ligand_v'])
 
     @torch.no_grad()
     def fetch_embedding(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand):
@@ -289,11 +324,13 @@ class ScorePosNet3D(nn.Module):
 
     # ------------------------------------------------------------------------------------------ sampling
     def begin_sampling(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
-                       num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None, use_session=True):
+                       num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None, use_session=True,
+                       pos_only=False):
         """Set up the reverse-diffusion state on the device and return a :class:`ReverseSampler`
         (``.step()`` = one iteration of the loop at models/molopt_score_model.py:650-693)."""
         return ReverseSampler(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
-                              batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session)
+                              batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session,
+                              pos_only)
 
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
@@ -307,10 +344,9 @@ class ScorePosNet3D(nn.Module):
         tensors, positions de-centred).  ``noise_source(step, name, like)`` may inject the Gaussian /
         uniform draws (parity tests); by default torch.randn_like / rand_like are used in the reference's
         order."""
-        if pos_only:
-            raise NotImplementedError('pos_only=True is not built yet')
         sampler = self.begin_sampling(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
-                                      batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source)
+                                      batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source,
+                                      pos_only=pos_only)
         while not sampler.done:
             sampler.step()
         return sampler.finish()
@@ -321,7 +357,8 @@ class ReverseSampler:
 
     @torch.no_grad()
     def __init__(self, model, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
-                 num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True):
+                 num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True, pos_only=False):
+        self.pos_only = bool(pos_only)
         if center_pos_mode not in ('protein', 'none', None):
             raise NotImplementedError(center_pos_mode)
         dev = protein_pos.device
@@ -345,8 +382,12 @@ class ReverseSampler:
         Nl, C = self.Nl, self.C
         self.pos_traj = torch.empty(S, Nl, 3, dtype=torch.float32, device=dev)
         self.v_traj = torch.empty(S, Nl, dtype=torch.int64, device=dev)
-        self.v0_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
-        self.vt_traj = torch.empty(S, Nl, C, dtype=torch.float32, device=dev)
+        # pos_only (:681): the types are frozen, no uniforms are drawn and v0 / vt are not recorded
+        SV = 0 if self.pos_only else S
+        self.v0_traj = torch.empty(SV, Nl, C, dtype=torch.float32, device=dev)
+        self.vt_traj = torch.empty(SV, Nl, C, dtype=torch.float32, device=dev)
+        self._half = torch.full((Nl, C), 0.5, dtype=torch.float32, device=dev) if self.pos_only else None
+        self._v_scratch = torch.empty(Nl, dtype=torch.int64, device=dev) if self.pos_only else None
         self.t_all = torch.tensor(steps, dtype=torch.int32, device=dev).view(S, 1).expand(S, B).contiguous()
         self.max_graph_nodes = max_graph_nodes
         self.noise_source = noise_source
@@ -370,11 +411,18 @@ class ReverseSampler:
             preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
                                          max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
         self.bufs = preds
+        noise = torch.randn_like(self.lpos) if self.noise_source is None else self.noise_source(s, 'noise', self.lpos)   # :677
+        if self.pos_only:
+            native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
+                                  preds['pred_ligand_v'], noise, self._half, pos_next=self.pos_traj[s],
+                                  v_next=self._v_scratch)
+            self.v_traj[s].copy_(self.lv)                                                  # :689
+            self.lpos = self.pos_traj[s]
+            self.s += 1
+            return
         if self.noise_source is None:
-            noise = torch.randn_like(self.lpos)                                            # :677
             uniform = torch.rand(self.Nl, self.C, dtype=torch.float32, device=self.lpos.device)   # :161
         else:
-            noise = self.noise_source(s, 'noise', self.lpos)
             uniform = self.noise_source(s, 'uniform', self.v0_traj[s])
         native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
                               preds['pred_ligand_v'], noise, uniform, pos_next=self.pos_traj[s],
@@ -385,7 +433,8 @@ class ReverseSampler:
     @torch.no_grad()
     def finish(self):
         S = self.s
-        pos_traj, v_traj, v0_traj, vt_traj = self.pos_traj[:S], self.v_traj[:S], self.v0_traj[:S], self.vt_traj[:S]
+        SV = 0 if self.pos_only else S
+        pos_traj, v_traj, v0_traj, vt_traj = self.pos_traj[:S], self.v_traj[:S], self.v0_traj[:SV], self.vt_traj[:SV]
         shift = self.offset[self.batch_ligand] if self.offset is not None else None
         if shift is not None:
             pos_traj = pos_traj + shift.unsqueeze(0)                                       # :691

@@ -51,8 +51,6 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
                             pos_only=False, center_pos_mode='protein', sample_num_atoms='prior',
                             atom_num_sampler=None, ligand_num_atoms=None, generator=None):
     """Returns (pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj, time_list)."""
-    if pos_only:
-        raise NotImplementedError('pos_only=True is not built yet')
     pocket = _as_pocket(data)
     all_pos, all_v, all_pos_traj, all_v_traj, all_v0_traj, all_vt_traj, time_list = [], [], [], [], [], [], []
     num_batch = int(np.ceil(num_samples / batch_size))

@@ -485,3 +485,65 @@ def test_alternative_kernel_paths_agree(model, golden_small, tmp_path, env, bitw
             assert np.array_equal(a, b), k
         else:
             assert np.max(np.abs(a - b)) < (TOL_X if k == 'pred_ligand_pos' else TOL_H), k
+
+
+# ------------------------------------------------------------------------------------------ other forward consumers
+def test_return_all_vs_reference_golden(model, golden_small):
+    """forward(return_all=True) (models/molopt_score_model.py:360-367): block input and block output predictions."""
+    dev = _dev()
+    g = load_golden('forward_small_return_all.npz')
+    out = _forward(model, small_inputs(golden_small), dev, return_all=True)
+    assert len(out['layer_pred_ligand_pos']) == len(out['layer_pred_ligand_v']) == 2
+    for l in range(2):
+        assert _maxdiff(out['layer_pred_ligand_pos'][l], g['layer_pred_ligand_pos'][l]) < TOL_X
+        assert _maxdiff(out['layer_pred_ligand_v'][l], g['layer_pred_ligand_v'][l]) < TOL_H
+
+
+def test_likelihood_estimation_vs_reference_golden(model):
+    """ScorePosNet3D.likelihood_estimation (scripts/likelihood_est_diffusion.py:30,48) with the reference's recorded
+    draws: KL terms at t = (0, 1, 537) -- rtol 1e-4 (the t = 0 decoder NLL is O(1e3)), atol 1e-6 -- and the prior terms.
+    Also checked against the oracle restatement on the same inputs."""
+    from oracle import restatement as R
+    from oracle import weights
+    dev = _dev()
+    g = load_golden('likelihood_small.npz')
+    T = lambda k, dt=None: torch.from_numpy(g[k].astype(dt) if dt else g[k])
+    args = (T('protein_pos').to(dev), T('protein_feat', np.float32).to(dev), T('batch_protein').to(dev),
+            T('ligand_pos').to(dev), T('ligand_v').to(dev), T('batch_ligand').to(dev))
+    noise, uni = T('noise').to(dev), T('uniform').to(dev)
+    src = lambda step, name, like: noise if name == 'noise' else uni
+    kl_pos, kl_v = model.likelihood_estimation(*args, T('time_step').to(dev), noise_source=src)
+    np.testing.assert_allclose(kl_pos.cpu().numpy(), g['kl_pos'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(kl_v.cpu().numpy(), g['kl_v'], rtol=1e-4, atol=1e-6)
+    klp, klv = model.likelihood_estimation(*args, torch.full((3,), 1000, dtype=torch.long, device=dev))
+    np.testing.assert_allclose(klp.cpu().numpy(), g['kl_pos_prior'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(klv.cpu().numpy(), g['kl_v_prior'], rtol=1e-4, atol=1e-7)
+    # oracle on a different set of time steps
+    ts = torch.tensor([999, 0, 3], dtype=torch.long)
+    sd = weights.make_state_dict(2021)
+    want_pos, want_v = R.likelihood_estimation(sd, None, *[a.cpu() for a in args], time_step=ts, noise=noise.cpu(),
+                                               uniform=uni.cpu())
+    got_pos, got_v = model.likelihood_estimation(*args, ts.to(dev), noise_source=src)
+    np.testing.assert_allclose(got_pos.cpu().numpy(), want_pos.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got_v.cpu().numpy(), want_v.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_sample_diffusion_pos_only(model):
+    """pos_only=True (models/molopt_score_model.py:681): atom types frozen, no type trajectories, positions of the first
+    step identical to the regular sampler's (same Gaussian draw)."""
+    from oracle.make_golden import small_batch
+    dev = _dev()
+    g = load_golden('sample_small.npz')
+    b, lpos, lv = small_batch()
+    noises = torch.from_numpy(g['noises']).to(dev)
+    unis = torch.from_numpy(g['uniforms']).to(dev)
+    src = lambda step, name, like: (noises if name == 'noise' else unis)[step].contiguous()
+    args = (b.protein_pos.to(dev), b.protein_atom_feature.float().to(dev), b.protein_element_batch.to(dev), lpos.to(dev),
+            lv.to(dev), b.ligand_element_batch.to(dev))
+    r = model.sample_diffusion(*args, num_steps=4, center_pos_mode='protein', noise_source=src, pos_only=True)
+    assert len(r['pos_traj']) == 4 and len(r['v_traj']) == 4 and r['v0_traj'] == [] and r['vt_traj'] == []
+    assert torch.equal(r['v'].cpu(), lv) and all(torch.equal(v, lv) for v in r['v_traj'])
+    # step 0 of the T-4 .. T-1 schedule differs from the golden's T-6 schedule, so compare with a regular 4-step run
+    r2 = model.sample_diffusion(*args, num_steps=4, center_pos_mode='protein', noise_source=src)
+    assert torch.equal(r['pos_traj'][0], r2['pos_traj'][0])
+    assert all(torch.isfinite(p).all() for p in r['pos_traj'])
