@@ -409,6 +409,7 @@ struct Workspace {
     float4 *x4a, *x4b;
     int32_t *gid, *nbr, *lig_node, *node_ptr;
     float *ew, *P, *q, *h, *alpha;
+    float *Px, *qx;          // h2x-stage projections / queries (separate from P / q: both stages project in one launch)
     size_t bytes;
 };
 
@@ -428,6 +429,8 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     w.q = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
     w.h = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
     w.alpha = reinterpret_cast<float *>(take(n * TD_HEADS * TD_K * sizeof(float)));
+    w.Px = reinterpret_cast<float *>(take(n * 4 * TD_H * sizeof(float)));
+    w.qx = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
     w.bytes = off;
     return w;
 }
@@ -514,18 +517,21 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     float4 *xc = w.x4a, *xn = w.x4b;
     const bool do_h2x = !fix_x && Nl > 0;
     if (do_h2x && !graph_ready) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    // Sampling session: only ligand outputs are consumed, so the layer e from the end updates receptive-field level e + 1
+    // only, and its projections are needed on level e + 2 (those rows and their neighbours).
+    auto proj_rows = [&](int l) -> const int32_t * { return l > 0 ? level_rows(Lc - 1 - l + 2) : nullptr; };
+    auto proj_count = [&](int l) -> const int32_t * { return l > 0 ? level_count(Lc - 1 - l + 2) : nullptr; };
+    bool proj_done = false;        // this layer's x2h-stage projections rode in the previous layer's paired launch
     for (int l = 0; l < Lc; ++l) {
         const TdLayer &L = m->layers[l];
         if (!(l == 0 && layer0_x2h_done)) {
-            // Sampling session: only ligand outputs are consumed, so the layer e from the end updates receptive-field
-            // level e + 1 only, and its projections are needed on level e + 2 (those rows and their neighbours).
             const int e = Lc - 1 - l;
-            const int32_t *prow = l > 0 ? level_rows(e + 2) : nullptr, *pcnt = l > 0 ? level_count(e + 2) : nullptr;
             const int32_t *rws = l > 0 ? level_rows(e + 1) : nullptr, *cnt = l > 0 ? level_count(e + 1) : nullptr;
-            {
+            if (!proj_done) {
                 ProfScope ps(PC_NODE, s);
-                if ((rc = td_launch_node_proj(L.nodeX2h, h, N, prow, 0x1f, w.P, w.q, s, pcnt)) != TD_OK) return rc;
+                if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
+            proj_done = false;
             if (fast_edges()) {
                 { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
                 { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
@@ -535,8 +541,17 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
         }
         if (!do_h2x) continue;
-        if ((rc = h2x_project(L, w, h, N, Nl, w.P, w.q, level_rows(1), level_count(1), s)) != TD_OK) return rc;
-        if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.P, w.q, w.alpha, s)) != TD_OK) return rc;
+        if (l + 1 < Lc) {
+            // the h2x stage of this layer and the x2h stage of the next project the same h: one launch
+            ProfScope ps(PC_NODE, s);
+            if ((rc = td_launch_node_proj_pair(L.nodeH2x, level_rows(1), level_count(1), w.lig_node, Nl, w.Px, w.qx,
+                                               m->layers[l + 1].nodeX2h, proj_rows(l + 1), proj_count(l + 1), w.P, w.q, h, N,
+                                               s)) != TD_OK) return rc;
+            proj_done = true;
+        } else {
+            if ((rc = h2x_project(L, w, h, N, Nl, w.Px, w.qx, level_rows(1), level_count(1), s)) != TD_OK) return rc;
+        }
+        if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.Px, w.qx, w.alpha, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
     }
     *x_final = xc;

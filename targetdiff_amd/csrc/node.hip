@@ -63,29 +63,46 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
     }
 }
 
-// mat_mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP.  rows != nullptr: process only
-// the listed node ids (h2x needs the dst-side projections and queries of ligand atoms only).
-//
-// Second segment (blocks2 > 0): workgroups blockIdx.x < blocks2 process the row list rows2[0..N2) with mask2, one
-// unit per workgroup -- the h2x stage's ligand-row projections ride along with the all-row launch instead of paying a
-// separate latency-bound launch.
-__global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const float *__restrict__ h, int64_t N,
-                                                           const int32_t *__restrict__ rows, unsigned mat_mask,
-                                                           const int32_t *__restrict__ count_ptr,
-                                                           float *__restrict__ P, float *__restrict__ q, int blocks2,
-                                                           const int32_t *__restrict__ rows2, int64_t N2, unsigned mask2) {
-    int bx = blockIdx.x;
+// One launch processes up to three row segments, each with its own stage weights, row list and outputs:
+//   mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP
+//   rows != nullptr: only the listed node ids; count_ptr != nullptr: device-side list length (N is then the bound the
+//   grid was sized for, workgroups beyond the count exit before any barrier)
+//   units > 1: one unit (a projection, or the two-GEMM query MLP) per workgroup, so that a 2 k-row segment spreads over
+//   many CUs instead of walking five matrices on a few
+// Segments are laid out along blockIdx.x in the order given (small segments first so that they start early).  This is
+// how the h2x stage's projections (neighbourhood rows + ligand rows, h2x weights) ride in the same launch as the next
+// layer's x2h-stage projections: all of them read the same h.
+struct NpSeg {
+    TdNodeStage st;
+    const int32_t *rows;
+    const int32_t *count_ptr;
+    int64_t N;
+    float *P, *q;
+    unsigned mask;
+    int units;         // 1, or popcount(mask & 0x1f) for per-unit workgroups
+    int blocks;        // workgroups of this segment
+};
+struct NpArgs {
+    NpSeg seg[3];
+    int nseg;
+};
+
+__global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const float *__restrict__ h) {
+    int bx = blockIdx.x, si = 0;
+    while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
+    const NpSeg &sg = args.seg[si];
+    const TdNodeStage st = sg.st;
+    const int32_t *__restrict__ rows = sg.rows;
+    float *__restrict__ P = sg.P, *__restrict__ q = sg.q;
+    unsigned mat_mask = sg.mask;
+    int64_t N = sg.N;
     int unit = gridDim.y > 1 ? (int)blockIdx.y : -1;
-    if (bx < blocks2) {
-        const int units2 = __builtin_popcount(mask2 & 0x1fu);
-        unit = bx % units2;
-        bx /= units2;
-        rows = rows2; N = N2; mat_mask = mask2;
-    } else {
-        bx -= blocks2;
+    if (sg.units > 1) {
+        unit = bx % sg.units;
+        bx /= sg.units;
     }
-    if (count_ptr && blockIdx.x >= blocks2) {   // device-side row count: workgroups beyond it exit before any barrier
-        N = *count_ptr;
+    if (sg.count_ptr) {
+        N = *sg.count_ptr;
         if ((int64_t)bx * (blockDim.x >> 1) >= N) return;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -104,8 +121,9 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
                            : make_float4(0.f, 0.f, 0.f, 0.f);
     // output row of C-layout register row r (recomputed at store time: 16 fewer live VGPRs)
     auto out_row = [&](int r) -> int {
-        const int64_t slot = row0 + td_erow(r, hi);
-        return slot < N ? (rows ? rows[slot] : (int)slot) : -1;
+        int slot = (int)row0 + td_erow(r, hi);
+        asm volatile("" : "+v"(slot));      // keep the row-list address out of the loop-invariant set (it would be spilled)
+        return slot < N ? (rows ? rows[slot] : slot) : -1;
     };
 
     // Small launches (ligand rows only) are split over blockIdx.y: one independent unit (a projection, or the
@@ -194,28 +212,60 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(TdNodeStage st, const
     }
 }
 
+static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const int32_t *count_ptr, int64_t N, unsigned mask,
+                   float *P, float *q, bool split_units, int rows_per_wg) {
+    g.st = st; g.rows = rows; g.count_ptr = count_ptr; g.N = N; g.P = P; g.q = q; g.mask = mask;
+    g.units = split_units ? __builtin_popcount(mask & 0x1fu) : 1;
+    g.blocks = (int)((N + rows_per_wg - 1) / rows_per_wg) * g.units;
+    return g.blocks;
+}
+
+static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, unsigned y, unsigned threads, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_LDS_BYTES));
+        attr_set = true;
+    }
+    node_proj_kernel<<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
                         float *P, float *q, hipStream_t s, const int32_t *count_ptr, const int32_t *rows2, int64_t N2,
                         unsigned mask2) {
     if (N == 0 || mat_mask == 0) return TD_OK;
     if (!rows2 || N2 == 0 || (mask2 & 0x1fu) == 0) { rows2 = nullptr; N2 = 0; mask2 = 0; }
-    static bool attr_set = false;
-    const size_t lds = NP_LDS_BYTES;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     // few rows (ligand atoms only): one wave per workgroup and one independent unit per blockIdx.y, so that the launch
     // spreads over the whole chip; many rows: 4 waves share each staged B chunk and keep the A tile for all matrices
-    const bool small = N <= 16384 && !rows2;
-    const unsigned units = small ? (unsigned)__builtin_popcount(mat_mask & 0x1fu) : 1u;
-    const unsigned threads = small ? 64u : 256u;
-    const int64_t rows_per_wg = threads / 2;
-    const unsigned blocks1 = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
-    const unsigned blocks2 = rows2 ? (unsigned)((N2 + rows_per_wg - 1) / rows_per_wg) * (unsigned)__builtin_popcount(mask2 & 0x1fu) : 0u;
-    node_proj_kernel<<<dim3(blocks1 + blocks2, units), dim3(threads), lds, s>>>(st, h, N, rows, mat_mask, count_ptr, P, q,
-                                                                                (int)blocks2, rows2, N2, mask2);
-    TD_CHECK_HIP(hipGetLastError());
-    return TD_OK;
+    const bool small = N <= 16384 && !rows2 && !count_ptr;
+    NpArgs a;
+    a.nseg = 0;
+    unsigned total = 0;
+    if (small) {
+        const unsigned units = (unsigned)__builtin_popcount(mat_mask & 0x1fu);
+        total += np_fill(a.seg[a.nseg++], st, rows, nullptr, N, mat_mask, P, q, false, 32);
+        return np_launch(a, h, total, units, 64u, s);
+    }
+    if (rows2) total += np_fill(a.seg[a.nseg++], st, rows2, nullptr, N2, mask2, P, q, true, 128);
+    total += np_fill(a.seg[a.nseg++], st, rows, count_ptr, N, mat_mask, P, q, false, 128);
+    return np_launch(a, h, total, 1u, 256u, s);
+}
+
+// The h2x-stage projections of layer l (stage `hx`: src-side units on `hop_rows`, dst-side units + queries on the ligand
+// rows, into Px / qx) and the x2h-stage projections of layer l + 1 (stage `nx`, all units on `rows` or every node, into
+// P / q) in one launch: both read the features the value pass of layer l just wrote.
+int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, const int32_t *hop_count,
+                             const int32_t *lig_rows, int64_t Nl, float *Px, float *qx, const TdNodeStage &nx,
+                             const int32_t *rows, const int32_t *count_ptr, float *P, float *q, const float *h, int64_t N,
+                             hipStream_t s) {
+    if (N == 0) return TD_OK;
+    NpArgs a;
+    a.nseg = 0;
+    unsigned total = 0;
+    if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
+    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, false, 128);
+    total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, false, 128);
+    return np_launch(a, h, total, 1u, 256u, s);
 }

@@ -130,6 +130,10 @@ int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int
 int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const int32_t *rows, unsigned mat_mask,
                         float *P, float *q, hipStream_t s, const int32_t *count_ptr = nullptr,
                         const int32_t *rows2 = nullptr, int64_t N2 = 0, unsigned mask2 = 0);
+int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, const int32_t *hop_count,
+                             const int32_t *lig_rows, int64_t Nl, float *Px, float *qx, const TdNodeStage &nx,
+                             const int32_t *rows, const int32_t *count_ptr, float *P, float *q, const float *h, int64_t N,
+                             hipStream_t s);
 // edge.hip
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s);
