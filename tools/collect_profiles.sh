@@ -14,4 +14,5 @@ python tools/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.txt" 2>> "$OUT/pmc.lo
 find "$OUT/pmc" -name "*.csv" -size +2M -delete
 python bench.py --no-cpu-baseline --profile-all > "$OUT/bench_profile_all.json" 2> "$OUT/bench_breakdown.txt"
 python bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+python bench.py --no-cpu-baseline --initial-state > "$OUT/bench_c2_initial_state.json" 2>> "$OUT/bench_c2.err"
 tail -c 600 "$OUT/bench_c2.json"
