@@ -110,8 +110,12 @@ def seeded_state_dict(model, seed=2021):
     return sd
 
 
-def cpu_baseline(pocket, sizes, samples=4, steps=2):
-    """Oracle restatement on the host cores; bounded sample of the same workload."""
+CPU_THREADS = 16       # fastest of 8 / 16 / 32 / 64 / 128 torch threads on the 128-core MI355X host (1.2 / 1.6 / 3.5 / 7.5 s per
+                       # step at 32 / 64 / 128: the small per-layer ops do not scale past one socket's worth of cores)
+
+
+def cpu_baseline(pocket, sizes, samples=4, steps=8):
+    """Oracle restatement on the host cores; bounded sample of the same workload (about 10 s of CPU work)."""
     from oracle import restatement as R
     from oracle import weights
     sd = weights.make_state_dict(2021)
@@ -121,16 +125,22 @@ def cpu_baseline(pocket, sizes, samples=4, steps=2):
     nl = lpos.shape[0]
     noises = torch.randn(steps + 1, nl, 3, generator=g)
     unis = torch.rand(steps + 1, nl, 13, generator=g)
-    cores = torch.get_num_threads()
-    args = (sd, None, b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
-            b.ligand_element_batch)
-    R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)            # warm-up
-    t0 = time.time()
-    R.sample_diffusion(*args, num_steps=steps, noises=noises, uniforms=unis)
-    sec_per_step = (time.time() - t0) / steps
+    prev = torch.get_num_threads()
+    cores = max(1, min(CPU_THREADS, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    try:
+        args = (sd, None, b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
+                b.ligand_element_batch)
+        R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)            # warm-up
+        t0 = time.time()
+        R.sample_diffusion(*args, num_steps=steps, noises=noises, uniforms=unis)
+        sec_per_step = (time.time() - t0) / steps
+    finally:
+        torch.set_num_threads(prev)
     return {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/restatement.py (torch CPU fp32), same pocket, {samples} samples x {steps} steps '
-                      f'({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, extrapolated to 1000 steps'}
+            'sample': f'oracle/restatement.py (torch CPU fp32, {cores} threads = the fastest setting on this host), same pocket, '
+                      f'{samples} samples x {steps} steps ({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, '
+                      f'extrapolated to 1000 steps'}
 
 
 def main():

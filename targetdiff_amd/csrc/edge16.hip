@@ -193,13 +193,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
-        const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R16);
-        float4 *rdst = reinterpret_cast<float4 *>(lds);
-        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += WAVES * 64) rdst[idx] = rsrc[idx];
-        const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt16);
-        float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, WAVES * 64);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
-        for (int idx = tid; idx < nw4; idx += WAVES * 64) wdst[idx] = wsrc[idx];
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), nw4, tid,
+                       WAVES * 64);
         if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
     }
@@ -303,12 +300,8 @@ struct ArgsH2x {
 
 template <int WAVES>
 __device__ __forceinline__ void td_stage_tables16(float *lds, const TdEdgeMlp &mlp, int nw4, int tid) {
-    const float4 *rsrc = reinterpret_cast<const float4 *>(mlp.R16);
-    float4 *rdst = reinterpret_cast<float4 *>(lds);
-    for (int idx = tid; idx < E16_R_FLOATS / 4; idx += WAVES * 64) rdst[idx] = rsrc[idx];
-    const float4 *wsrc = reinterpret_cast<const float4 *>(mlp.Walt16);
-    float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
-    for (int idx = tid; idx < nw4; idx += WAVES * 64) wdst[idx] = wsrc[idx];
+    td_stage_lds16(reinterpret_cast<const float4 *>(mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, WAVES * 64);
+    td_stage_lds16(reinterpret_cast<const float4 *>(mlp.Walt16), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), nw4, tid, WAVES * 64);
     if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.gamma[tid];
     else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.beta[tid - TD_H];
 }
@@ -439,12 +432,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     float *B2 = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
     const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
     {
-        const float4 *rsrc = reinterpret_cast<const float4 *>(a.mlp.R16);
-        float4 *rdst = reinterpret_cast<float4 *>(lds);
-        for (int idx = tid; idx < E16_R_FLOATS / 4; idx += V16_WAVES * 64) rdst[idx] = rsrc[idx];
-        const float4 *wsrc = reinterpret_cast<const float4 *>(a.mlp.Walt);
-        float4 *wdst = reinterpret_cast<float4 *>(lds + E16_R_FLOATS);
-        for (int idx = tid; idx < V16_W_FLOATS / 4; idx += V16_WAVES * 64) wdst[idx] = wsrc[idx];
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, V16_WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), V16_W_FLOATS / 4, tid,
+                       V16_WAVES * 64);
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
         else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
         else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];

@@ -20,14 +20,6 @@ constexpr int NP_CHUNKS = TD_KSTEPS / NP_CHUNK_STEPS;    // 4 chunks per 128-dee
 constexpr int NP_TSTRIDE = 36;                           // transpose tile [32 rows][32 + 4]
 constexpr size_t NP_LDS_BYTES = (size_t)(2 * NP_CHUNK_F4 * 4 + 4 * 32 * NP_TSTRIDE) * sizeof(float);
 
-// 16-byte-per-lane async global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane * 16.
-__device__ __forceinline__ void td_glds16(const float4 *gsrc_lane, float4 *lds_wave_base) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-#endif
-}
-
 // 128-deep GEMM of one 32-row A tile (registers) against all 4 N tiles.  The B fragments of the workgroup's current
 // weight matrix are staged through LDS in 16 KiB chunks shared by its 4 waves (one L2 read per workgroup instead of
 // one per wave; LDS latency instead of L2 latency in front of every 4 MFMAs): while chunk c is consumed from

@@ -91,3 +91,20 @@ __device__ __forceinline__ float td_sum64(float v) {
 __device__ __forceinline__ float td_dist2(float dx, float dy, float dz) {
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
+
+// 16-byte-per-lane async global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane * 16.
+__device__ __forceinline__ void td_glds16(const float4 *gsrc_lane, float4 *lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc_lane,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+
+// Stage `n4` float4 (a multiple of 64) from global memory into LDS with the async copy, all waves of the workgroup
+// cooperating; the caller's next __syncthreads() waits for the copies (vmcnt(0)) and publishes them.
+__device__ __forceinline__ void td_stage_lds16(const float4 *__restrict__ src, float4 *__restrict__ dst, int n4, int tid,
+                                               int nthreads) {
+    const int lane = tid & 63;
+    for (int idx = tid; idx < n4; idx += nthreads) td_glds16(src + idx, dst + (idx - lane));
+}
