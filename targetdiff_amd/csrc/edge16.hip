@@ -79,13 +79,52 @@ struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
     float4 xi;
 };
 
+// Raw operands of one dst row, as loaded: the gathered positions / projections of its 32 neighbours (two per lane).  Kept
+// separate from the arithmetic so that a kernel can issue the next row's gathers while it finishes the current row.
+struct RowIn16 {
+    float4 xi, xj[2];
+    int j[2];
+    float ew[2];
+    float pit[8];          // dst-side projection P_i: hidden 16hb + lo
+};
+
+// neighbour indices of row i (the only load the gathers depend on)
+__device__ __forceinline__ void td_row_index16(const Args16 &a, int64_t i, int lane, RowIn16 &r) {
+    const int lo = lane & 15;
+    r.xi = a.x4[i];
+    r.j[0] = a.nbr[i * TD_K + lo];
+    r.j[1] = a.nbr[i * TD_K + 16 + lo];
+}
+
+// gathers: neighbour positions, neighbour-side projections straight into the accumulators, dst-side projection
 template <bool LOAD_EW>
-__device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
-                                                 const float *__restrict__ GAM, const float *__restrict__ BET,
-                                                 const float (&offk)[E16_STEPS], int64_t i, int lane,
-                                                 floatx4_t (&acc)[2][8], Edge2 &ed) {
+__device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int lane, RowIn16 &r, floatx4_t (&acc)[2][8]) {
     const int lo = lane & 15, g = lane >> 4;
-    const float4 xi = a.x4[i];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        const int jj = r.j[eb] >= 0 ? r.j[eb] : (int)i;
+        r.xj[eb] = a.x4[jj];
+        if (LOAD_EW) r.ew[eb] = a.ew[i * TD_K + 16 * eb + lo];
+        // neighbour-side projection P_j, 16 bytes per hidden block: hidden 16hb + 4g .. + 3
+        const float *pj = a.P + (size_t)jj * (4 * TD_H) + a.p_off + TD_H + 4 * g;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            const float4 v = *reinterpret_cast<const float4 *>(pj + 16 * hb);
+            acc[eb][hb][0] = v.x; acc[eb][hb][1] = v.y; acc[eb][hb][2] = v.z; acc[eb][hb][3] = v.w;
+        }
+    }
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) r.pit[hb] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 16 * hb + lo];
+}
+
+// radial / type first layer on the gathered operands + LayerNorm + ReLU: z^T in acc[eb][hb]
+template <bool LOAD_EW>
+__device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const float4 *__restrict__ Rt,
+                                                         const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                         const float (&offk)[E16_STEPS], const RowIn16 &r, int lane,
+                                                         floatx4_t (&acc)[2][8], Edge2 &ed) {
+    const int g = lane >> 4;
+    const float4 xi = r.xi;
     ed.xi = xi;
     const int cls = xi.w > 0.5f ? 0 : 1;
     float dist[2];
@@ -93,29 +132,18 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
     bool any_a = false, any_b = false;
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
-        const int j = a.nbr[i * TD_K + 16 * eb + lo];
-        ed.valid[eb] = j >= 0;
-        const float4 xj = a.x4[ed.valid[eb] ? j : i];
-        if (LOAD_EW) ed.ew[eb] = a.ew[i * TD_K + 16 * eb + lo];
+        ed.valid[eb] = r.j[eb] >= 0;
+        const float4 xj = r.xj[eb];
+        if (LOAD_EW) ed.ew[eb] = r.ew[eb];
         const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
         dist[eb] = sqrtf(rx * rx + ry * ry + rz * rz);
         ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         any_a |= ed.valid[eb] && slot[eb] == 0;
         any_b |= ed.valid[eb] && slot[eb] == 1;
-        // neighbour-side projection P_j, 16 bytes per hidden block: hidden 16hb + 4g .. + 3
-        const float *pj = a.P + (size_t)(ed.valid[eb] ? j : (int)i) * (4 * TD_H) + a.p_off + TD_H + 4 * g;
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) {
-            const float4 v = *reinterpret_cast<const float4 *>(pj + 16 * hb);
-            acc[eb][hb][0] = v.x; acc[eb][hb][1] = v.y; acc[eb][hb][2] = v.z; acc[eb][hb][3] = v.w;
-        }
     }
     const bool has_a = __ballot(any_a) != 0ull, has_b = __ballot(any_b) != 0ull;
     // dst-side projection P_i rides in the table's padding column k = 21 (k-step 5, lane group 1)
-    float pit[8];
-#pragma unroll
-    for (int hb = 0; hb < 8; ++hb) pit[hb] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 16 * hb + lo];
     float gv[2][E16_STEPS];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
@@ -135,7 +163,7 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
             float av[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};     // A: R[k = 4s + g][hidden 16hb + lo]
             if (s == 5 && g == 1) {
 #pragma unroll
-                for (int hb = 0; hb < 8; ++hb) av[hb] = pit[hb];
+                for (int hb = 0; hb < 8; ++hb) av[hb] = r.pit[hb];
             }
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) {
@@ -172,6 +200,17 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
             acc[eb][hb][3] = fmaxf(fmaf(fmaf(acc[eb][hb][3], rstd, nms), gm.w, bm.w), 0.f);
         }
     }
+}
+
+template <bool LOAD_EW>
+__device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
+                                                 const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                 const float (&offk)[E16_STEPS], int64_t i, int lane,
+                                                 floatx4_t (&acc)[2][8], Edge2 &ed) {
+    RowIn16 r;
+    td_row_index16(a, i, lane, r);
+    td_row_gather16<LOAD_EW>(a, i, lane, r, acc);
+    td_first_layer_compute16<LOAD_EW>(a, Rt, GAM, BET, offk, r, lane, acc, ed);
 }
 
 // ================================================================================================ key pass
@@ -446,20 +485,40 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
 
-    for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
-        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];   // residual, used last
-        floatx4_t acc[2][8];
-        Edge2 ed;
-        td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
-
-        // ---- A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads) ----------
-        float al[8];
-        {
-            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
-            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
-            al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
+    // Software pipeline over the wave's rows: the neighbour indices of row n + 1 are fetched at the top of row n, and its
+    // gathers (32 neighbour projections straight into the accumulator registers, which are free once Zbar is done) are
+    // issued before row n's output GEMV, so that they land while it runs.
+    auto row_id = [&](int64_t itx) -> int64_t { return a.rows ? (int64_t)a.rows[itx] : itx; };
+    auto load_side = [&](int64_t ix, float (&alx)[8], float &h0, float &h1) {
+        // A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads); residual row
+        const float *ap = a.alpha + ((size_t)ix * TD_HEADS + lo) * TD_K + 8 * g;
+        const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+        alx[0] = v0.x; alx[1] = v0.y; alx[2] = v0.z; alx[3] = v0.w; alx[4] = v1.x; alx[5] = v1.y; alx[6] = v1.z; alx[7] = v1.w;
+        h0 = a.h[(size_t)ix * TD_H + lane];
+        h1 = a.h[(size_t)ix * TD_H + 64 + lane];
+    };
+    int64_t it = begin + wid;
+    int64_t i = 0;
+    RowIn16 rin;
+    floatx4_t acc[2][8];
+    float al[8], hres0 = 0.f, hres1 = 0.f;
+    if (it < end) {
+        i = row_id(it);
+        td_row_index16(a, i, lane, rin);
+        td_row_gather16<false>(a, i, lane, rin, acc);
+        load_side(i, al, hres0, hres1);
+    }
+    for (; it < end; it += V16_WAVES) {
+        const bool more = it + V16_WAVES < end;
+        int64_t inext = 0;
+        RowIn16 rnext;
+        if (more) {
+            inext = row_id(it + V16_WAVES);
+            td_row_index16(a, inext, lane, rnext);
         }
+        Edge2 ed;
+        td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
         if (lane < TD_HEADS) SB[lane] = ssum;
@@ -488,6 +547,16 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
         }
 
+        // ---- next row: gathers into the (now free) accumulators, its alpha fragment and residual ---------------------
+        const int64_t icur = i;
+        const float hcur0 = hres0, hcur1 = hres1;
+        if (more) {
+            td_row_gather16<false>(a, inext, lane, rnext, acc);
+            load_side(inext, al, hres0, hres1);
+            rin = rnext;
+            i = inext;
+        }
+
         // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -------
         // zb[hb][r] = Zbar[head 4g + r][hidden 16hb + lo]; heads 8ph .. 8ph+7 sit in lane groups g = 2ph, 2ph + 1
         float *ZB = TB;
@@ -508,7 +577,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
                 o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
             }
-            a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+            a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
     }
 }
