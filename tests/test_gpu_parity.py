@@ -547,3 +547,52 @@ def test_sample_diffusion_pos_only(model):
     r2 = model.sample_diffusion(*args, num_steps=4, center_pos_mode='protein', noise_source=src)
     assert torch.equal(r['pos_traj'][0], r2['pos_traj'][0])
     assert all(torch.isfinite(p).all() for p in r['pos_traj'])
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 2, full size
+def test_full_size_c2_pack_reproduces_reference_golden(model):
+    """The benchmark's full-size batch (1h36 x 100 samples, N = 60,708 nodes): the two graphs whose ligands are the
+    reference golden's ligands must reproduce the reference outputs wherever they sit in the ragged pack (graphs are
+    independent), through the stateless forward AND through the sampling session (row skipping, receptive-field pruning),
+    and the two paths must agree bit for bit on every ligand atom of the batch."""
+    from oracle import restatement as R
+    from targetdiff_amd import capi, workloads
+    dev = _dev()
+    g = load_golden('forward_1h36x2.npz')
+    pocket, sizes = pocket_1h36()
+    sizes = [int(v) for v in sizes[:100]]
+    assert sizes[:2] == [int(v) for v in g['sizes']]
+    n2 = sizes[0] + sizes[1]
+    # put the golden ligands (already centred) into graphs 37 and 81 instead of 0 and 1: swap the sizes accordingly
+    order = list(range(100))
+    order[0], order[37] = order[37], order[0]
+    order[1], order[81] = order[81], order[1]
+    sizes_p = [sizes[k] for k in order]
+    b = workloads.pack_samples(pocket, 100, sizes_p)
+    cum = np.cumsum([0] + sizes_p)
+    lpos_p = torch.randn(int(cum[-1]), 3, generator=torch.Generator().manual_seed(12)) * 2.0
+    lv_p = torch.randint(0, 13, (int(cum[-1]),), generator=torch.Generator().manual_seed(13))
+    gp, gv = torch.from_numpy(g['ligand_pos']), torch.from_numpy(g['ligand_v'])
+    lpos_p[cum[37]:cum[38]], lv_p[cum[37]:cum[38]] = gp[:sizes[0]], gv[:sizes[0]]
+    lpos_p[cum[81]:cum[82]], lv_p[cum[81]:cum[82]] = gp[sizes[0]:n2], gv[sizes[0]:n2]
+    ppos_c, _, _ = R.center_positions(b.protein_pos, torch.zeros(int(cum[-1]), 3), b.protein_element_batch,
+                                      b.ligand_element_batch)
+    b = b.to(dev)
+    ppos_c, lpos_p, lv_p = ppos_c.to(dev), lpos_p.to(dev).contiguous(), lv_p.to(dev)
+    assert ppos_c.shape[0] + lpos_p.shape[0] > 60000
+    pv = b.protein_atom_feature.float()
+    out = model(ppos_c, pv, b.protein_element_batch, lpos_p, lv_p, b.ligand_element_batch)
+    nat = model._native(dev)
+    pptr = nat.graph_ptr(b.protein_element_batch, 100)
+    lptr = nat.graph_ptr(b.ligand_element_batch, 100)
+    sess = capi.NativeSession(nat, ppos_c, pv, pptr, lptr, lpos_p.shape[0])
+    got = sess.forward(lpos_p, lv_p)
+    sel = torch.cat([torch.arange(cum[37], cum[38]), torch.arange(cum[81], cum[82])]).to(dev)
+    for name, res in (('stateless', out), ('session', got)):
+        d = {k: _maxdiff(res[k][sel], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h')}
+        print(name, d)
+        assert d['pred_ligand_pos'] < TOL_X and d['pred_ligand_v'] < TOL_H and d['final_ligand_h'] < TOL_H, (name, d)
+    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+        assert torch.equal(out[k], got[k]), k
+    n_all, dirty, levels = sess.row_counts()
+    assert n_all == ppos_c.shape[0] + lpos_p.shape[0] and dirty < n_all and levels[0] < n_all
