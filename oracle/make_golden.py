@@ -284,6 +284,29 @@ def main():
                         kl_pos_prior=klp_prior.numpy(), kl_v_prior=klv_prior.numpy())
     print('likelihood_small:', kl_pos.numpy(), kl_v.numpy(), klp_prior.numpy(), klv_prior.numpy())
 
+    # ---------------------------------------------------------------- standalone EGNN refine net (models/egnn.py)
+    # built exactly as get_refine_net('egnn', config) does (models/molopt_score_model.py:34-42); seeded features on the
+    # small batch's composed geometry
+    import importlib
+    egnn_mod = importlib.import_module('models.egnn')
+    L_e = weights.DEFAULT_MODEL_CONFIG['num_layers']
+    enet = egnn_mod.EGNN(num_layers=L_e, hidden_dim=128, edge_feat_dim=4, num_r_gaussian=1, k=k, cutoff_mode='knn').eval()
+    esd = weights.make_egnn_state_dict(SEED, num_layers=L_e)
+    assert set(esd) == set(enet.state_dict()), set(esd) ^ set(enet.state_dict())
+    enet.load_state_dict(esd, strict=True)
+    from . import restatement as Rst
+    ppos_e, lpos_e, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    ge = torch.Generator().manual_seed(SEED + 2)
+    n_p, n_l = ppos_e.shape[0], lpos_e.shape[0]
+    h_ctx, x_ctx, batch_ctx, mask_ctx = Rst.compose_context(torch.randn(n_p, 128, generator=ge), torch.randn(n_l, 128, generator=ge),
+                                                            ppos_e, lpos_e, b.protein_element_batch, b.ligand_element_batch)
+    with torch.no_grad():
+        oe = enet(h_ctx, x_ctx, mask_ctx, batch_ctx, return_all=True)
+    _save(os.path.join(GOLDEN_DIR, 'egnn_small.npz'), h=h_ctx.numpy(), x=x_ctx.numpy(), batch=batch_ctx.numpy(),
+          mask_ligand=mask_ctx.numpy(), num_layers=np.int64(L_e), all_x=torch.stack(oe['all_x']).numpy(),
+          h_layer1=oe['all_h'][1].numpy(), h_layer5=oe['all_h'][5].numpy(), h_final=oe['h'].numpy())
+    print('egnn_small: N =', h_ctx.shape[0], 'max |dx| =', float((oe['x'] - x_ctx).abs().max()))
+
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)) // 1024, 'KiB')
 

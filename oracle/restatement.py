@@ -385,3 +385,35 @@ def likelihood_estimation(sd, cfg, protein_pos, protein_v, batch_protein, ligand
     preds = model_forward(sd, cfg, ppos, protein_v, batch_protein, xt, vt, batch_ligand)
     return likelihood_terms(sched, time_step, lpos, xt, ligand_v, vt, preds['pred_ligand_pos'],
                             preds['pred_ligand_v'], batch_ligand, K)
+
+
+# ------------------------------------------------------------------------------------------ EGNN (models/egnn.py)
+def egnn_forward(sd, h, x, mask_ligand, batch, num_layers=9, k=32, dtype=torch.float32, collect=None):
+    """EGNN.forward (models/egnn.py:121-133) as get_refine_net configures it (num_r_gaussian = 1, knn, SiLU, no norm):
+    per layer a fresh kNN graph on the current coordinates, EnBaseLayer.forward (:36-64) on the dense neighbour table."""
+    h, x = h.to(dtype), x.to(dtype)
+    lin = lambda key, v: F.linear(v, sd[f'{key}.weight'].to(dtype), sd[f'{key}.bias'].to(dtype) if f'{key}.bias' in sd else None)
+    for l in range(num_layers):
+        p = f'net.{l}'
+        nbr = knn_neighbours(x.float(), k, batch)                                   # :123 -> :99
+        valid = nbr >= 0
+        nb = nbr.clamp(min=0)
+        etype = F.one_hot(edge_types(nbr, mask_ligand).clamp(min=0), 4).to(dtype)  # :105-118
+        rel = x.unsqueeze(1) - x[nb]                                                # :40  x[dst] - x[src]
+        d_sq = (rel ** 2).sum(-1, keepdim=True)                                     # :41
+        hi = h.unsqueeze(1).expand(-1, nbr.shape[1], -1)
+        feat = torch.cat([hi, h[nb], d_sq, etype], -1)                              # :46-51 (num_r_gaussian == 1: d_feat = d_sq)
+        mij = F.silu(lin(f'{p}.edge_mlp.net.2', F.silu(lin(f'{p}.edge_mlp.net.0', feat))))   # :22-23 (act_last)
+        eij = torch.sigmoid(lin(f'{p}.edge_inf.0', mij))                            # :52
+        vmask = valid.unsqueeze(-1).to(dtype)
+        mi = (mij * eij * vmask).sum(dim=1)                                         # :53
+        h_new = h + lin(f'{p}.node_mlp.net.2', F.silu(lin(f'{p}.node_mlp.net.0', torch.cat([mi, h], -1))))   # :56
+        s = torch.tanh(lin(f'{p}.x_mlp.2', F.silu(lin(f'{p}.x_mlp.0', mij))))       # :27-33
+        delta = (rel / (torch.sqrt(d_sq + 1e-8) + 1) * s * vmask).sum(dim=1)        # :61
+        x = x + delta * mask_ligand.unsqueeze(-1).to(dtype)                         # :62
+        h = h_new
+        if collect is not None:
+            collect.setdefault('h_layers', []).append(h.clone())
+            collect.setdefault('x_layers', []).append(x.clone())
+            collect.setdefault('nbr', []).append(nbr.clone())
+    return {'x': x, 'h': h}

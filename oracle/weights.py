@@ -116,3 +116,38 @@ def make_state_dict(seed: int = 2021, cfg=None, protein_dim=PROTEIN_FEATURE_DIM,
             raise ValueError(kind)
         sd[key] = t
     return sd
+
+
+# ------------------------------------------------------------------------------------------ EGNN (models/egnn.py)
+def egnn_parameter_spec(num_layers=9, hidden=128, edge_feat_dim=4, num_r_gaussian=1):
+    """(key, shape, kind, fan_in) of the EGNN refine net as get_refine_net builds it (models/molopt_score_model.py:34-42:
+    num_r_gaussian = 1, so the edge MLP sees [h_i | h_j | d^2 | one_hot(type)] = 2 * hidden + 1 + edge_feat_dim inputs;
+    models/egnn.py:22-35)."""
+    spec = [('distance_expansion.offset', (len(GAUSSIAN_OFFSETS),), 'offset', 0)]
+    ein = 2 * hidden + edge_feat_dim + num_r_gaussian
+    for l in range(num_layers):
+        p = f'net.{l}'
+        spec += [(f'{p}.edge_mlp.net.0.weight', (hidden, ein), 'linear', ein), (f'{p}.edge_mlp.net.0.bias', (hidden,), 'bias', ein),
+                 (f'{p}.edge_mlp.net.2.weight', (hidden, hidden), 'linear', hidden), (f'{p}.edge_mlp.net.2.bias', (hidden,), 'bias', hidden),
+                 (f'{p}.edge_inf.0.weight', (1, hidden), 'linear', hidden), (f'{p}.edge_inf.0.bias', (1,), 'bias', hidden),
+                 (f'{p}.x_mlp.0.weight', (hidden, hidden), 'linear', hidden), (f'{p}.x_mlp.0.bias', (hidden,), 'bias', hidden),
+                 (f'{p}.x_mlp.2.weight', (1, hidden), 'linear', hidden),
+                 (f'{p}.node_mlp.net.0.weight', (hidden, 2 * hidden), 'linear', 2 * hidden),
+                 (f'{p}.node_mlp.net.0.bias', (hidden,), 'bias', 2 * hidden),
+                 (f'{p}.node_mlp.net.2.weight', (hidden, hidden), 'linear', hidden),
+                 (f'{p}.node_mlp.net.2.bias', (hidden,), 'bias', hidden)]
+    return spec
+
+
+def make_egnn_state_dict(seed: int = 2021, num_layers=9, hidden=128, edge_feat_dim=4):
+    """Seeded EGNN weights, U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like nn.Linear (x_mlp.2 too, instead of the reference's
+    xavier gain 0.001 initialisation, so that the coordinate update is exercised)."""
+    sd = OrderedDict()
+    for key, shape, kind, fan_in in egnn_parameter_spec(num_layers, hidden, edge_feat_dim):
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(('egnn.' + key).encode())) % (2 ** 63))
+        if kind == 'offset':
+            t = torch.tensor(GAUSSIAN_OFFSETS, dtype=torch.float32)
+        else:
+            t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / (fan_in ** 0.5)
+        sd[key] = t
+    return sd

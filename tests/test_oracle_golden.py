@@ -139,3 +139,20 @@ def test_likelihood_estimation_matches_reference(state_dict):
     klp, klv = R.likelihood_estimation(state_dict, None, **inp, time_step=torch.full((3,), 1000, dtype=torch.long))
     np.testing.assert_allclose(klp.numpy(), g['kl_pos_prior'], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(klv.numpy(), g['kl_v_prior'], rtol=1e-4, atol=1e-7)
+
+
+def test_egnn_matches_reference():
+    """Standalone EGNN refine net (models/egnn.py, built as get_refine_net('egnn') does): per-layer coordinates, selected
+    per-layer features and the per-layer kNN tables' effect, 9 layers."""
+    g = load_golden('egnn_small.npz')
+    L = int(g['num_layers'])
+    sd = weights.make_egnn_state_dict(2021, num_layers=L)
+    col = {}
+    out = R.egnn_forward(sd, torch.from_numpy(g['h']), torch.from_numpy(g['x']), torch.from_numpy(g['mask_ligand']),
+                         torch.from_numpy(g['batch']), num_layers=L, collect=col)
+    for l in range(L):
+        assert _maxdiff(col['x_layers'][l], g['all_x'][l + 1]) < 2e-5, l
+    assert _maxdiff(col['h_layers'][0], g['h_layer1']) < 2e-5
+    assert _maxdiff(col['h_layers'][4], g['h_layer5']) < 5e-5
+    assert _maxdiff(out['h'], g['h_final']) < 1e-4
+    assert float(np.abs(g['all_x'][-1] - g['all_x'][0]).max()) > 1e-2, 'fixture must move the ligand'
