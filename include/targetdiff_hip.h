@@ -116,6 +116,23 @@ int td_posterior_step(const td_model *m, const int32_t *d_t, const int32_t *d_li
                       const float *d_uniform, float *d_pos_next, int64_t *d_v_next, float *d_log_v0,
                       float *d_log_post, void *stream);
 
+/* ---- standalone EGNN refine net (replaces: models/egnn.py EGNN / EnBaseLayer as get_refine_net('egnn', config) builds
+ *      it, models/molopt_score_model.py:34-42: num_r_gaussian = 1, kNN rebuilt per layer, SiLU, no LayerNorm, hidden 128,
+ *      4 edge types, k = 32).  `host_weights`: per layer, in this order and as PyTorch stores them: edge_mlp.net.0.{weight
+ *      [128,261], bias}, edge_mlp.net.2.{weight, bias}, edge_inf.0.{weight [1,128], bias [1]}, x_mlp.0.{weight, bias},
+ *      x_mlp.2.weight [1,128], node_mlp.net.0.{weight [128,256], bias}, node_mlp.net.2.{weight, bias}.
+ *      td_egnn_forward = EGNN.forward(h, x, mask_ligand, batch, return_all) (models/egnn.py:121-133): d_all_h [L][N][128] /
+ *      d_all_x [L][N][3] (optional) receive the state after every layer (all_h[1:], all_x[1:]). */
+typedef struct td_egnn td_egnn;
+size_t td_egnn_num_weights(int32_t num_layers);
+int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t edge_feat_dim, int32_t knn, const float *host_weights,
+                   size_t num_weights, td_egnn **out);
+void td_egnn_destroy(td_egnn *m);
+size_t td_egnn_workspace_bytes(int64_t N);
+int td_egnn_forward(const td_egnn *m, const float *d_h, const float *d_x, const uint8_t *d_mask_ligand,
+                    const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t max_graph_nodes, float *d_out_h, float *d_out_x,
+                    float *d_all_h, float *d_all_x, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- other consumers of the denoiser (scripts/likelihood_est_diffusion.py; ScorePosNet3D.forward(return_all=True)).
  * They need the 8th schedule array (alphas_cumprod of the position schedule) at td_model_create.
  *

@@ -51,6 +51,11 @@ SIGNATURES = {
     'td_likelihood_prior': (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, _P]),
     'td_embed_ligand': (c_int32, [_P, _P, c_int64, _P, _P]),
     'td_v_inference': (c_int32, [_P, _P, c_int64, _P, _P]),
+    'td_egnn_num_weights': (ctypes.c_size_t, [c_int32]),
+    'td_egnn_create': (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_float), ctypes.c_size_t, POINTER(c_void_p)]),
+    'td_egnn_destroy': (None, [_P]),
+    'td_egnn_workspace_bytes': (ctypes.c_size_t, [c_int64]),
+    'td_egnn_forward': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     'td_session_create': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, POINTER(c_void_p)]),
     'td_session_destroy': (None, [_P]),
     'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
@@ -376,3 +381,59 @@ class NativeSession:
 
     def dirty_rows(self) -> int:
         return self.row_counts()[1]
+
+
+# ----------------------------------------------------------------------------------------- standalone EGNN refine net
+EGNN_LAYER_KEYS = ('edge_mlp.net.0.weight', 'edge_mlp.net.0.bias', 'edge_mlp.net.2.weight', 'edge_mlp.net.2.bias',
+                   'edge_inf.0.weight', 'edge_inf.0.bias', 'x_mlp.0.weight', 'x_mlp.0.bias', 'x_mlp.2.weight',
+                   'node_mlp.net.0.weight', 'node_mlp.net.0.bias', 'node_mlp.net.2.weight', 'node_mlp.net.2.bias')
+
+
+def egnn_flat_key_order(num_layers: int):
+    return [f'net.{l}.{k}' for l in range(num_layers) for k in EGNN_LAYER_KEYS]
+
+
+def graph_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
+    """CSR offsets of a sorted PyG ``batch`` vector (td_graph_ptr); no model handle needed."""
+    lib = load_library()
+    ptr = torch.empty(B + 1, dtype=torch.int32, device=batch.device)
+    _check(lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream()), 'td_graph_ptr')
+    return ptr
+
+
+class NativeEgnn:
+    """Owns a td_egnn handle: the EGNN refine net of models/egnn.py with packed weights on the current HIP device."""
+
+    def __init__(self, num_layers: int, state_dict, hidden_dim=HIDDEN, edge_feat_dim=4, k=KNN, device=None, prefix=''):
+        self.lib = load_library()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.num_layers = int(num_layers)
+        blob = np.ascontiguousarray(np.concatenate(
+            [state_dict[prefix + key].detach().cpu().numpy().astype(np.float32).reshape(-1)
+             for key in egnn_flat_key_order(self.num_layers)]))
+        handle = c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.td_egnn_create(self.num_layers, hidden_dim, edge_feat_dim, k, blob.ctypes.data_as(POINTER(c_float)),
+                                           blob.size, ctypes.byref(handle)), 'td_egnn_create')
+        self.handle = handle
+        self._ws = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h and getattr(self, 'lib', None) is not None:
+            self.lib.td_egnn_destroy(h)
+
+    def forward(self, h, x, mask_ligand, node_ptr, return_all=False, max_graph_nodes=0):
+        N, B, L = h.shape[0], node_ptr.numel() - 1, self.num_layers
+        out_h, out_x = torch.empty_like(h), torch.empty_like(x)
+        all_h = torch.empty(L, N, HIDDEN, dtype=torch.float32, device=h.device) if return_all else None
+        all_x = torch.empty(L, N, 3, dtype=torch.float32, device=h.device) if return_all else None
+        need = int(self.lib.td_egnn_workspace_bytes(N))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=h.device)
+        mask_u8 = mask_ligand.to(torch.uint8).contiguous()
+        _check(self.lib.td_egnn_forward(
+            self.handle, _ptr(h, torch.float32, 'h'), _ptr(x, torch.float32, 'x'), _ptr(mask_u8),
+            _ptr(node_ptr, torch.int32, 'node_ptr'), N, B, max_graph_nodes, _ptr(out_h), _ptr(out_x), _ptr(all_h), _ptr(all_x),
+            _ptr(self._ws), self._ws.numel(), _stream()), 'td_egnn_forward')
+        return out_h, out_x, all_h, all_x

@@ -681,6 +681,172 @@ extern "C" int td_posterior_step(const td_model *m, const int32_t *d_t, const in
                                d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream));
 }
 
+// ------------------------------------------------------------------------------------------ standalone EGNN refine net
+struct td_egnn {
+    int num_layers;
+    float *blob;
+    TdEgnnLayer *layers;     // host array
+};
+
+namespace {
+constexpr int EGNN_EDGE_IN = 2 * TD_H + 1 + 4;      // [h_i | h_j | d^2 | one_hot(type)]  (models/egnn.py:22, num_r_gaussian = 1)
+size_t egnn_layer_floats() {
+    return (size_t)TD_H * EGNN_EDGE_IN + TD_H + (size_t)TD_H * TD_H + TD_H + TD_H + 1 + (size_t)TD_H * TD_H + TD_H + TD_H +
+           (size_t)TD_H * 2 * TD_H + TD_H + (size_t)TD_H * TD_H + TD_H;
+}
+// 128 x 128 weight (row-major [out][in]) as A fragments of the 16x16x4 product: [ot][hb][lane] x 4 r
+size_t pack_A16(Packer &pk, const float *W) {
+    size_t off = pk.alloc((size_t)8 * 8 * 64 * 4);
+    float *d = pk.data.data() + off;
+    for (int ot = 0; ot < 8; ++ot)
+        for (int hb = 0; hb < 8; ++hb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    d[(((size_t)ot * 8 + hb) * 64 + lane) * 4 + r] = W[(size_t)(16 * ot + (lane & 15)) * TD_H + 16 * hb + 4 * (lane >> 4) + r];
+    return off;
+}
+}  // namespace
+
+extern "C" size_t td_egnn_num_weights(int32_t num_layers) { return num_layers > 0 ? (size_t)num_layers * egnn_layer_floats() : 0; }
+
+extern "C" int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t edge_feat_dim, int32_t knn,
+                              const float *host_weights, size_t num_weights, td_egnn **out) {
+    if (!host_weights || !out || num_layers <= 0) { td_set_error("td_egnn_create: bad argument"); return TD_EINVAL; }
+    if (hidden_dim != TD_H || edge_feat_dim != 4 || knn != TD_K) {
+        td_set_error("td_egnn_create: unsupported configuration (need hidden 128, edge_feat_dim 4, knn 32; got %d/%d/%d)",
+                     hidden_dim, edge_feat_dim, knn);
+        return TD_EINVAL;
+    }
+    if (num_weights != td_egnn_num_weights(num_layers)) {
+        td_set_error("td_egnn_create: weight blob has %zu floats, expected %zu", num_weights, td_egnn_num_weights(num_layers));
+        return TD_EINVAL;
+    }
+    struct Off { size_t projB, projBias, W2f, Wxf, vec, nodeB, nb1, nb2; };
+    std::vector<Off> off((size_t)num_layers);
+    Packer pk;
+    Cursor cur{host_weights, num_weights};
+    for (int l = 0; l < num_layers; ++l) {
+        const float *W1 = cur.take((size_t)TD_H * EGNN_EDGE_IN), *b1 = cur.take(TD_H);
+        const float *W2 = cur.take((size_t)TD_H * TD_H), *b2 = cur.take(TD_H);
+        const float *winf = cur.take(TD_H), *binf = cur.take(1);
+        const float *Wx = cur.take((size_t)TD_H * TD_H), *bx = cur.take(TD_H), *wx2 = cur.take(TD_H);
+        const float *Wn1 = cur.take((size_t)TD_H * 2 * TD_H), *bn1 = cur.take(TD_H);
+        const float *Wn2 = cur.take((size_t)TD_H * TD_H), *bn2 = cur.take(TD_H);
+        Off &o = off[(size_t)l];
+        o.projB = pack_B128(pk, W1, EGNN_EDGE_IN, 0);          // h_i columns (dst)
+        pack_B128(pk, W1, EGNN_EDGE_IN, TD_H);                 // h_j columns (src): consecutive block
+        o.projBias = pk.alloc(5 * TD_H);
+        memcpy(pk.data.data() + o.projBias, b1, TD_H * sizeof(float));
+        o.W2f = pack_A16(pk, W2);
+        o.Wxf = pack_A16(pk, Wx);
+        o.vec = pk.alloc(128 + 512 + 128 + 132 + 128 + 128);
+        float *v = pk.data.data() + o.vec;
+        for (int n = 0; n < TD_H; ++n) {
+            v[n] = W1[(size_t)n * EGNN_EDGE_IN + 2 * TD_H];                                    // d^2 column
+            for (int t = 0; t < 4; ++t) v[128 + t * TD_H + n] = W1[(size_t)n * EGNN_EDGE_IN + 2 * TD_H + 1 + t];
+            v[640 + n] = b2[n];
+            v[768 + n] = winf[n];
+            v[900 + n] = bx[n];
+            v[1028 + n] = wx2[n];
+        }
+        v[768 + 128] = binf[0];
+        o.nodeB = pack_B128(pk, Wn1, 2 * TD_H, 0);             // mi half of node_mlp.net.0  (cat([mi, h]), models/egnn.py:56)
+        pack_B128(pk, Wn1, 2 * TD_H, TD_H);                    // h half
+        pack_B128(pk, Wn2, TD_H, 0);
+        o.nb1 = pack_vec(pk, bn1, TD_H);
+        o.nb2 = pack_vec(pk, bn2, TD_H);
+    }
+    if (!cur.ok || cur.left != 0) { td_set_error("td_egnn_create: weight blob layout mismatch"); return TD_EINVAL; }
+    td_egnn *m = new (std::nothrow) td_egnn();
+    if (!m) { td_set_error("td_egnn_create: out of host memory"); return TD_ENOMEM; }
+    m->num_layers = num_layers;
+    m->layers = new (std::nothrow) TdEgnnLayer[(size_t)num_layers];
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->blob), pk.data.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->blob, pk.data.data(), pk.data.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess || !m->layers) {
+        td_set_error("td_egnn_create: device upload failed: %s", hipGetErrorString(e));
+        if (m->blob) (void)hipFree(m->blob);
+        delete[] m->layers;
+        delete m;
+        return TD_EHIP;
+    }
+    const float *D = m->blob;
+    for (int l = 0; l < num_layers; ++l) {
+        const Off &o = off[(size_t)l];
+        TdEgnnLayer &L = m->layers[l];
+        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr};
+        L.W2f = D + o.W2f; L.Wxf = D + o.Wxf; L.vec = D + o.vec; L.nodeB = D + o.nodeB; L.nb1 = D + o.nb1; L.nb2 = D + o.nb2;
+    }
+    *out = m;
+    return TD_OK;
+}
+
+extern "C" void td_egnn_destroy(td_egnn *m) {
+    if (!m) return;
+    if (m->blob) (void)hipFree(m->blob);
+    delete[] m->layers;
+    delete m;
+}
+
+namespace {
+struct EgnnWs { float4 *x4a, *x4b; int32_t *gid, *nbr; float *P, *mi; size_t bytes; };
+EgnnWs egnn_carve(char *base, int64_t N) {
+    EgnnWs w;
+    size_t off = 0;
+    auto take = [&](size_t n) { char *p = base ? base + off : nullptr; off += align_up(n); return p; };
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    w.x4a = reinterpret_cast<float4 *>(take(n * sizeof(float4)));
+    w.x4b = reinterpret_cast<float4 *>(take(n * sizeof(float4)));
+    w.gid = reinterpret_cast<int32_t *>(take(n * sizeof(int32_t)));
+    w.nbr = reinterpret_cast<int32_t *>(take(n * TD_K * sizeof(int32_t)));
+    w.P = reinterpret_cast<float *>(take(n * 4 * TD_H * sizeof(float)));
+    w.mi = reinterpret_cast<float *>(take(n * TD_H * sizeof(float)));
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t td_egnn_workspace_bytes(int64_t N) { return egnn_carve(nullptr, N).bytes; }
+
+// EGNN.forward (models/egnn.py:121-133): per layer a fresh kNN graph on the current coordinates, then one EnBaseLayer.
+extern "C" int td_egnn_forward(const td_egnn *m, const float *d_h, const float *d_x, const uint8_t *d_mask_ligand,
+                               const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t max_graph_nodes, float *d_out_h,
+                               float *d_out_x, float *d_all_h, float *d_all_x, void *d_workspace, size_t workspace_bytes,
+                               void *stream) {
+    if (!m || N < 0 || B < 0) { td_set_error("td_egnn_forward: bad argument"); return TD_EINVAL; }
+    if (N == 0) return TD_OK;
+    if (!d_h || !d_x || !d_mask_ligand || !d_node_ptr || !d_out_h || !d_out_x || !d_workspace) {
+        td_set_error("td_egnn_forward: null pointer");
+        return TD_EINVAL;
+    }
+    EgnnWs w = egnn_carve(static_cast<char *>(d_workspace), N);
+    if (w.bytes > workspace_bytes) {
+        td_set_error("td_egnn_forward: workspace has %zu bytes, need %zu", workspace_bytes, w.bytes);
+        return TD_ENOMEM;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc;
+    if ((rc = td_launch_node_gid(d_node_ptr, N, B, w.gid, s)) != TD_OK) return rc;
+    if ((rc = td_launch_pack_x(d_x, d_mask_ligand, N, w.x4a, s)) != TD_OK) return rc;
+    TD_CHECK_HIP(hipMemcpyAsync(w.x4b, w.x4a, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (d_out_h != d_h) TD_CHECK_HIP(hipMemcpyAsync(d_out_h, d_h, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    float4 *xc = w.x4a, *xn = w.x4b;
+    for (int l = 0; l < m->num_layers; ++l) {
+        const TdEgnnLayer &L = m->layers[l];
+        if ((rc = td_launch_knn(xc, d_node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
+        if ((rc = td_launch_node_proj(L.proj, d_out_h, N, nullptr, 0x03, w.P, w.P, s)) != TD_OK) return rc;
+        if ((rc = td_launch_egnn_edge(L, xc, xn, w.nbr, w.P, w.mi, N, s)) != TD_OK) return rc;
+        if ((rc = td_launch_egnn_node(L, w.mi, d_out_h, N, s)) != TD_OK) return rc;
+        float4 *t = xc; xc = xn; xn = t;
+        // keep the protein rows of the (now stale) buffer in sync is not needed: only ligand rows ever change and the
+        // edge kernel rewrites every ligand row of its output buffer
+        if (d_all_x && (rc = td_launch_unpack_x(xc, N, d_all_x + (size_t)l * N * 3, s)) != TD_OK) return rc;
+        if (d_all_h) TD_CHECK_HIP(hipMemcpyAsync(d_all_h + (size_t)l * N * TD_H, d_out_h, (size_t)N * TD_H * sizeof(float),
+                                                 hipMemcpyDeviceToDevice, s));
+    }
+    return td_launch_unpack_x(xc, N, d_out_x, s);
+}
+
 // ---- the other forward consumers: likelihood estimation (scripts/likelihood_est_diffusion.py) and return_all
 extern "C" int td_perturb(const td_model *m, const int32_t *d_t, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
                           const float *d_ligand_pos, const int64_t *d_ligand_v, const float *d_noise, const float *d_uniform,

@@ -261,3 +261,80 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
     total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, false, 128);
     return np_launch(a, h, total, 1u, 256u, s);
 }
+
+// ------------------------------------------------------------------------------------------ EGNN node update
+// h_i += W2 SiLU(W1 [mi | h_i] + b1) + b2   (models/egnn.py:56, node_mlp = Linear(256,128) -> SiLU -> Linear(128,128)).
+// Same decomposition as node_proj_kernel: 32 rows per wave, A tiles in registers, B staged through LDS; the 256-deep first
+// Linear is two 128-deep GEMMs into one accumulator (mi tile, then h tile).
+__global__ __launch_bounds__(256, 2) void egnn_node_kernel(const float4 *__restrict__ B, const float *__restrict__ b1,
+                                                           const float *__restrict__ b2, const float *__restrict__ mi,
+                                                           float *__restrict__ h, int64_t N) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float4 *bufs = reinterpret_cast<float4 *>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;
+    const int c = lane & 31, hi = lane >> 5;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int64_t arow = row0 + c < N ? row0 + c : -1;
+    const float4 *B0 = B, *B1 = B + (size_t)TD_KSTEPS * 64, *B2 = B + (size_t)2 * TD_KSTEPS * 64;
+    for (int u = tid; u < NP_CHUNK_F4; u += blockDim.x) bufs[u] = B0[u];
+    __syncthreads();
+    int cur = 0;
+    float4 a[16];
+    floatx16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float bv = b1[32 * t + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = bv;
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        a[m] = arow >= 0 ? *reinterpret_cast<const float4 *>(mi + arow * TD_H + 8 * m + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gemm128_lds(a, B0, B1, bufs, cur, tid, lane, acc);
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        a[m] = arow >= 0 ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gemm128_lds(a, B1, B2, bufs, cur, tid, lane, acc);
+    // SiLU, then C layout -> A layout through the wave-private tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][r];
+            tb[td_erow(r, hi) * NP_TSTRIDE + c] = v * __frcp_rn(1.0f + __expf(-v));
+        }
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float bv = b2[32 * t + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = bv;
+    }
+    gemm128_lds(a, B2, nullptr, bufs, cur, tid, lane, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int slot = (int)row0 + td_erow(r, hi);
+        asm volatile("" : "+v"(slot));
+        if (slot < N) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h[(size_t)slot * TD_H + 32 * t + c] += acc[t][r];
+        }
+    }
+}
+
+int td_launch_egnn_node(const TdEgnnLayer &L, const float *mi, float *h, int64_t N, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(egnn_node_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_LDS_BYTES));
+        attr_set = true;
+    }
+    egnn_node_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), NP_LDS_BYTES, s>>>(
+        reinterpret_cast<const float4 *>(L.nodeB), L.nb1, L.nb2, mi, h, N);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

@@ -81,6 +81,16 @@ struct TdHead {            // v_inference (models/molopt_score_model.py:307-311)
     const float *b2;       // [16]
 };
 
+// One EnBaseLayer of the standalone EGNN refine net (models/egnn.py:10-35), packed by td_egnn_create
+struct TdEgnnLayer {
+    TdNodeStage proj;      // node_proj_kernel, mask 0x03: mat 0 = edge_mlp.net.0[:, 0:128] (+ bias), mat 1 = [:, 128:256]
+    const float *W2f;      // edge_mlp.net.2 as 16x16x4 A fragments [ot][hb][lane] x 4 r
+    const float *Wxf;      // x_mlp.0, same layout
+    const float *vec;      // [w_d 128 | W_t 4 x 128 | b2 128 | w_inf 128, b_inf, pad 3 | b_x 128 | w_x2 128]
+    const float *nodeB;    // 3 x B fragments (pack_B128): node_mlp.net.0[:, 0:128] (mi), [:, 128:256] (h), node_mlp.net.2
+    const float *nb1, *nb2;
+};
+
 struct TdSchedules {       // [T] each
     const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_ca, *log_1mca;
     const float *abar;     // alphas_cumprod of the position schedule; nullptr when the model was created without it
@@ -169,6 +179,10 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
                         const float *pred_v, const float *noise, const float *uni, float *pos_next,
                         int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
+// egnn.hip / node.hip
+int td_launch_egnn_edge(const TdEgnnLayer &L, const float4 *x4, float4 *x4_out, const int32_t *nbr, const float *P, float *mi,
+                        int64_t N, hipStream_t s);
+int td_launch_egnn_node(const TdEgnnLayer &L, const float *mi, float *h, int64_t N, hipStream_t s);
 // likelihood.hip
 int td_launch_perturb(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B, int classes,
                       const float *pos, const int64_t *v, const float *noise, const float *uni, float *pos_t, int64_t *v_t,

@@ -129,9 +129,13 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
 
 def get_refine_net(refine_net_type, config):
     """models/molopt_score_model.py:13-45."""
+    g = lambda k, d=None: _cfg_get(config, k, d)
+    if refine_net_type == 'egnn':                                                       # :34-42
+        from .egnn import EGNN
+        return EGNN(num_layers=g('num_layers'), hidden_dim=g('hidden_dim'), edge_feat_dim=g('edge_feat_dim'),
+                    num_r_gaussian=1, k=g('knn'), cutoff_mode=g('cutoff_mode'))
     if refine_net_type != 'uni_o2':
-        # 'egnn' cannot be reached through ScorePosNet3D in the reference either (TypeError at :349, SURVEY.md section 0)
-        raise NotImplementedError(f'refine_net_type {refine_net_type!r}: only uni_o2 is built')
+        raise ValueError(refine_net_type)
     g = lambda k, d=None: _cfg_get(config, k, d)
     return UniTransformerO2TwoUpdateGeneral(
         num_blocks=g('num_blocks'), num_layers=g('num_layers'), hidden_dim=g('hidden_dim'), n_heads=g('n_heads'),
@@ -238,6 +242,10 @@ class ScorePosNet3D(nn.Module):
         self.time_emb_dim = 0
         self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim, emb_dim)
         self.refine_net_type = g('model_type')
+        if self.refine_net_type != 'uni_o2':
+            # the reference builds an EGNN here but cannot run it: forward passes fix_x=, which EGNN.forward does not
+            # accept (TypeError at models/molopt_score_model.py:349).  Use targetdiff_amd.egnn.EGNN standalone.
+            raise NotImplementedError(f"ScorePosNet3D(model_type={self.refine_net_type!r}): only 'uni_o2' is reachable")
         self.refine_net = get_refine_net(self.refine_net_type, config)
         import weakref
         self.refine_net._owner = weakref.ref(self)

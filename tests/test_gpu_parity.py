@@ -596,3 +596,32 @@ def test_full_size_c2_pack_reproduces_reference_golden(model):
         assert torch.equal(out[k], got[k]), k
     n_all, dirty, levels = sess.row_counts()
     assert n_all == ppos_c.shape[0] + lpos_p.shape[0] and dirty < n_all and levels[0] < n_all
+
+
+# ------------------------------------------------------------------------------------------ standalone EGNN refine net
+def test_egnn_vs_reference_golden():
+    """models/egnn.py EGNN built as get_refine_net('egnn', config) does, 9 layers with a fresh kNN graph each: every
+    layer's coordinates and the recorded feature layers against the real reference's outputs."""
+    from oracle import weights
+    from targetdiff_amd.models import get_refine_net
+    dev = _dev()
+    g = load_golden('egnn_small.npz')
+    L = int(g['num_layers'])
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    net = get_refine_net('egnn', cfg)
+    assert net.num_layers == L
+    res = net.load_state_dict(weights.make_egnn_state_dict(2021, num_layers=L), strict=True)
+    net = net.to(dev)
+    h, x = torch.from_numpy(g['h']).to(dev), torch.from_numpy(g['x']).to(dev)
+    mask, batch = torch.from_numpy(g['mask_ligand']).to(dev), torch.from_numpy(g['batch']).to(dev)
+    out = net(h, x, mask, batch, return_all=True)
+    assert len(out['all_x']) == L + 1 and len(out['all_h']) == L + 1
+    d = {'x': max(_maxdiff(out['all_x'][l], g['all_x'][l]) for l in range(L + 1)),
+         'h1': _maxdiff(out['all_h'][1], g['h_layer1']), 'h5': _maxdiff(out['all_h'][5], g['h_layer5']),
+         'h': _maxdiff(out['h'], g['h_final'])}
+    print(d)
+    assert d['x'] < 5e-5 and d['h1'] < TOL_H and d['h5'] < TOL_H and d['h'] < 5e-4
+    # protein rows never move
+    assert torch.equal(out['x'][~mask], x[~mask])
+    out2 = net(h, x, mask, batch)
+    assert torch.equal(out2['h'], out['h']) and torch.equal(out2['x'], out['x'])
