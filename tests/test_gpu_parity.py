@@ -625,3 +625,36 @@ def test_egnn_vs_reference_golden():
     assert torch.equal(out['x'][~mask], x[~mask])
     out2 = net(h, x, mask, batch)
     assert torch.equal(out2['h'], out['h']) and torch.equal(out2['x'], out['x'])
+
+
+def test_egnn_large_batch_replicas():
+    """EGNN at a size that takes the large-launch code paths (N > 16 k): every replica of the same graph gets bit-identical
+    outputs wherever it sits in the pack, equal to a 2-replica run of the same graph, and reruns are bit-identical."""
+    from oracle import weights
+    from targetdiff_amd import workloads
+    from targetdiff_amd.egnn import EGNN
+    dev = _dev()
+    net = EGNN(num_layers=3, hidden_dim=128, edge_feat_dim=4, num_r_gaussian=1, k=32, cutoff_mode='knn')
+    net.load_state_dict(weights.make_egnn_state_dict(7, num_layers=3), strict=True)
+    net = net.to(dev)
+    pocket = workloads.synthetic_pocket(2000, 300)
+    g = torch.Generator().manual_seed(3)
+    h1 = torch.randn(325, 128, generator=g)
+    one = workloads.pack_samples(pocket, 1, [25])
+    lpos1, _ = workloads.init_ligand(one, generator=g, spread=2.0)
+    x1 = torch.cat([one.protein_pos, lpos1])
+    mask1 = torch.cat([torch.zeros(300, dtype=torch.bool), torch.ones(25, dtype=torch.bool)])
+
+    def run(reps):
+        h = h1.repeat(reps, 1).to(dev)
+        x = x1.repeat(reps, 1).to(dev)
+        mask = mask1.repeat(reps).to(dev)
+        batch = torch.arange(reps).repeat_interleave(325).to(dev)
+        return net(h, x, mask, batch)
+    big, big2, small = run(60), run(60), run(2)
+    assert big['h'].shape[0] == 60 * 325 > 16384
+    assert torch.equal(big['h'], big2['h']) and torch.equal(big['x'], big2['x'])
+    hb, xb = big['h'].view(60, 325, 128), big['x'].view(60, 325, 3)
+    assert torch.equal(hb, hb[:1].expand_as(hb)) and torch.equal(xb, xb[:1].expand_as(xb))
+    assert torch.equal(hb[0], small['h'][:325]) and torch.equal(xb[0], small['x'][:325])
+    assert float((big['x'].view(60, 325, 3)[0, 300:] - x1[300:].to(dev)).abs().max()) > 1e-3      # the ligand moved
