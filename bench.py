@@ -222,8 +222,10 @@ def main():
     if sampler.session is not None:
         n_all, n_dirty, levels = sampler.session.row_counts()
         tail = levels[:n_layers - 1]          # level k + 1 = rows the layer k from the end updates
-        rows_per_launch = (n_dirty + (n_layers - 1 - len(tail)) * n_all + sum(tail)) / n_layers
-        session_rows = {'nodes': n_all, 'layer0_rows': n_dirty, 'receptive_field_levels': levels}
+        n_fwd = sampler.session.forward_reach_rows()
+        full_layers = n_layers - 1 - len(tail) - (1 if n_fwd is not None else 0)
+        rows_per_launch = (n_dirty + (n_fwd or 0) + full_layers * n_all + sum(tail)) / n_layers
+        session_rows = {'nodes': n_all, 'layer0_rows': n_dirty, 'layer1_rows': n_fwd, 'receptive_field_levels': levels}
 
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]

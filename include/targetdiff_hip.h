@@ -182,7 +182,8 @@ int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *
 /* rows processed by the last td_session_forward: counts[0] = N, counts[1] = rows recomputed at layer 0 (ligand +
  * displaced protein rows), counts[2 + k] = size of receptive-field level k + 1 of the ligand outputs (level 1 = ligand
  * atoms + their neighbours, level k + 1 = level k + its neighbours; the layer e from the end updates level e + 1 only),
- * -1 for levels the session does not track; synchronises */
+ * -1 for levels the session does not track (k < 4); counts[6] = rows of layer 1 inside the ligand's one-hop forward reach
+ * (the others keep the protein-only graph's cached layer-1 output), -1 when off; synchronises */
 int td_session_row_counts(td_session *s, int32_t *host_counts, int32_t n_counts, void *stream);
 
 /* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event

@@ -375,9 +375,18 @@ class NativeSession:
         """(N, rows recomputed at layer 0, [receptive-field level sizes ...]) of the last forward; synchronises.
 
         Level k (1-based) is what the layer k - 1 from the end has to update when only ligand outputs are read."""
-        n = (c_int32 * 10)()
-        _check(self.lib.td_session_row_counts(self.handle, n, 10, _stream()), 'td_session_row_counts')
-        return int(n[0]), int(n[1]), [int(v) for v in n[2:] if v >= 0]
+        n = self._counts()
+        return int(n[0]), int(n[1]), [int(v) for v in n[2:6] if v >= 0]
+
+    def forward_reach_rows(self):
+        """Rows layer 1 recomputes (the ligand's one-hop forward reach), or None when that pruning is off."""
+        v = int(self._counts()[6])
+        return v if v >= 0 else None
+
+    def _counts(self):
+        n = (c_int32 * 8)()
+        _check(self.lib.td_session_row_counts(self.handle, n, 8, _stream()), 'td_session_row_counts')
+        return n
 
     def dirty_rows(self) -> int:
         return self.row_counts()[1]

@@ -501,9 +501,17 @@ int h2x_attend(const TdLayer &L, Workspace &w, float *h, int64_t Nl, float4 *xc,
 // the buffer holding the final coordinates through *x_final.  hop_rows (optional, sampling session): the ligand atoms
 // and their neighbours -- the only rows whose h2x-stage projections and last-layer features are ever read when just the
 // ligand outputs are consumed.
+// Sampling session, layer 1: rows outside the ligand's one-hop forward reach keep the protein-only graph's layer-1
+// output (`hs`), so the attention passes run on `rows` only and `rest` is restored from the cache afterwards.
+struct FwdReach {
+    const int32_t *rows, *rest, *counts;     // counts[0] = |rows|, counts[1] = |rest|
+    const float *hs;
+};
+
 int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
                  float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
-                 const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr, int hop_levels = 0) {
+                 const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr, int hop_levels = 0,
+                 const FwdReach *fwd = nullptr) {
     int rc;
     const int Lc = m->cfg.num_layers;
     if (!fast_edges()) hop_levels = 0;
@@ -527,6 +535,8 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         if (!(l == 0 && layer0_x2h_done)) {
             const int e = Lc - 1 - l;
             const int32_t *rws = l > 0 ? level_rows(e + 1) : nullptr, *cnt = l > 0 ? level_count(e + 1) : nullptr;
+            const bool use_fwd = fwd && l == 1 && !rws && fast_edges();
+            if (use_fwd) { rws = fwd->rows; cnt = fwd->counts; }
             if (!proj_done) {
                 ProfScope ps(PC_NODE, s);
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
@@ -535,6 +545,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             if (fast_edges()) {
                 { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
                 { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
+                if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
             } else {
                 { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
                 { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
@@ -948,7 +959,10 @@ struct td_session {
     int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count, *hop_rows, *hop_count;
     int hop_levels;
     unsigned long long *skeys;
-    float *ews, *h0, *h1s, *P0, *q0;
+    float *ews, *h0, *h1s, *h2s, *P0, *q0;
+    uint8_t *flags2;
+    int32_t *fwd_rows, *fwd_rest, *fwd_counts;
+    bool use_fwd;
     uint8_t *clean;
 };
 
@@ -971,7 +985,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     const size_t n = (size_t)N;
     const size_t o_prot = reserve((size_t)N_p * 4), o_pptr = reserve((size_t)(B + 1) * 4), o_lptr = reserve((size_t)(B + 1) * 4),
                  o_snbr = reserve(n * TD_K * 4), o_skeys = reserve(n * TD_K * 8), o_ews = reserve(n * TD_K * 4),
-                 o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_P0 = reserve(n * 4 * TD_H * 4),
+                 o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_h2s = reserve(n * TD_H * 4), o_f2 = reserve(n),
+                 o_frows = reserve(n * 4), o_frest = reserve(n * 4), o_fcnt = reserve(256), o_P0 = reserve(n * 4 * TD_H * 4),
                  o_q0 = reserve(n * TD_H * 4), o_clean = reserve(n), o_dirty = reserve(n * 4), o_dcnt = reserve(256),
                  o_hop = reserve(n * 4 * TD_HOP_LEVELS), o_hcnt = reserve(256),
                  o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8);
@@ -991,6 +1006,15 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->ews = reinterpret_cast<float *>(b + o_ews);
     S->h0 = reinterpret_cast<float *>(b + o_h0);
     S->h1s = reinterpret_cast<float *>(b + o_h1s);
+    S->h2s = reinterpret_cast<float *>(b + o_h2s);
+    S->flags2 = reinterpret_cast<uint8_t *>(b + o_f2);
+    S->fwd_rows = reinterpret_cast<int32_t *>(b + o_frows);
+    S->fwd_rest = reinterpret_cast<int32_t *>(b + o_frest);
+    S->fwd_counts = reinterpret_cast<int32_t *>(b + o_fcnt);
+    {
+        const char *e = getenv("TD_SESSION_FORWARD_REACH");
+        S->use_fwd = !(e && e[0] == '0') && m->cfg.num_layers >= 2 && fast_edges();
+    }
     S->P0 = reinterpret_cast<float *>(b + o_P0);
     S->q0 = reinterpret_cast<float *>(b + o_q0);
     S->clean = reinterpret_cast<uint8_t *>(b + o_clean);
@@ -1031,6 +1055,13 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     TD_TRY(key_pass(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
     TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
     TD_TRY(value_pass(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, s));
+    if (S->use_fwd) {      // layer-1 x2h output of the protein-only graph (valid wherever the ligand is two hops away)
+        const TdLayer &L1 = m->layers[1];
+        TD_TRY(td_launch_node_proj(L1.nodeX2h, S->h1s, N, nullptr, 0x1f, w.P, w.q, s));
+        TD_TRY(key_pass(L1.hk, L1, w.x4a, S->snbr, S->ews, w.P, w.q, S->prot_node, nullptr, N_p, w.alpha, s));
+        TD_TRY_HIP(hipMemcpyAsync(S->h2s, S->h1s, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
+        TD_TRY(value_pass(L1.hv, L1, w.x4a, S->snbr, w.P, S->prot_node, nullptr, N_p, S->h2s, w.alpha, s));
+    }
 #undef TD_TRY
 #undef TD_TRY_HIP
     *out = S;
@@ -1065,6 +1096,8 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
                                       S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, s)) != TD_OK) return rc;
         if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
         if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
+        if (S->use_fwd && (rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest,
+                                                        S->fwd_counts, s)) != TD_OK) return rc;
     }
     {
         ProfScope ps(PC_GATE, s);
@@ -1079,7 +1112,9 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
     if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s)) != TD_OK) return rc;
     float4 *xf = nullptr;
-    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels)) != TD_OK) return rc;
+    const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s};
+    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels,
+                           S->use_fwd ? &fwd : nullptr)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
@@ -1090,9 +1125,12 @@ extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_
     hipStream_t s = static_cast<hipStream_t>(stream);
     host_counts[0] = (int32_t)S->N;
     TD_CHECK_HIP(hipMemcpyAsync(host_counts + 1, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    for (int k = 0; k + 2 < n_counts; ++k) host_counts[k + 2] = -1;
-    const int lv = S->hop_levels < n_counts - 2 ? S->hop_levels : n_counts - 2;
+    for (int k = 2; k < n_counts; ++k) host_counts[k] = -1;
+    const int room = n_counts - 2 < TD_HOP_LEVELS ? n_counts - 2 : TD_HOP_LEVELS;
+    const int lv = S->hop_levels < room ? S->hop_levels : room;
     if (lv > 0) TD_CHECK_HIP(hipMemcpyAsync(host_counts + 2, S->hop_count, sizeof(int32_t) * (size_t)lv, hipMemcpyDeviceToHost, s));
+    if (n_counts > 2 + TD_HOP_LEVELS && S->use_fwd)
+        TD_CHECK_HIP(hipMemcpyAsync(host_counts + 2 + TD_HOP_LEVELS, S->fwd_counts, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }

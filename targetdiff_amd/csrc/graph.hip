@@ -325,6 +325,70 @@ int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, i
     return TD_OK;
 }
 
+// Forward reach of the ligand, one hop: flags2[i] = 1 when row i is dirty (a ligand atom, or a protein row with a ligand
+// neighbour) or has a dirty neighbour -- the only rows whose layer-1 x2h output differs from the protein-only graph's.
+// Rows outside keep the cached static feature row (copied by the same kernel: one wave per row would be wasteful, so the
+// copy is a second kernel over the complement list).
+__global__ void forward_reach_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4,
+                                     const int32_t *__restrict__ nbr, int64_t N, uint8_t *__restrict__ flags2) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 5;
+    if (i >= N) return;
+    const int e = (int)(t & 31);
+    const int j = nbr[i * TD_K + e];
+    bool d = e == 0 && (x4[i].w > 0.5f || !clean[i]);
+    if (j >= 0) d = d || x4[j].w > 0.5f || !clean[j];
+    if (d) flags2[i] = 1;                                  // racing writers store the same value
+}
+
+// rows with flags != 0 -> rows_on / count[0]; the others -> rows_off / count[1]
+__global__ void compact_split_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows_on,
+                                     int32_t *__restrict__ rows_off, int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < N, on = in && flags[i];
+    const unsigned long long m = __ballot(on), z = __ballot(in && !on);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int b1 = 0, b0 = 0;
+    if (lane == 0 && m) b1 = atomicAdd(count, __popcll(m));
+    if (lane == 0 && z) b0 = atomicAdd(count + 1, __popcll(z));
+    b1 = __shfl(b1, 0);
+    b0 = __shfl(b0, 0);
+    if (on) rows_on[b1 + __popcll(m & below)] = (int32_t)i;
+    else if (in) rows_off[b0 + __popcll(z & below)] = (int32_t)i;
+}
+
+int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
+                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    TD_CHECK_HIP(hipMemsetAsync(flags2, 0, (size_t)N, s));
+    TD_CHECK_HIP(hipMemsetAsync(counts2, 0, 2 * sizeof(int32_t), s));
+    forward_reach_kernel<<<dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, s>>>(clean, x4, nbr, N, flags2);
+    TD_CHECK_HIP(hipGetLastError());
+    compact_split_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags2, N, rows_on, rows_off, counts2);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// h[i] = hs[i] for the listed rows (device-side count)
+__global__ void restore_rows_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ count_ptr,
+                                    const float4 *__restrict__ hs, float4 *__restrict__ h) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t a = t >> 5;                 // 32 float4 per row
+    if (a >= *count_ptr) return;
+    const int64_t i = rows[a];
+    h[i * 32 + (t & 31)] = hs[i * 32 + (t & 31)];
+}
+
+int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_t max_rows, const float *hs, float *h,
+                           hipStream_t s) {
+    if (max_rows == 0) return TD_OK;
+    restore_rows_kernel<<<dim3((unsigned)((max_rows * 32 + 255) / 256)), dim3(256), 0, s>>>(
+        rows, count_ptr, reinterpret_cast<const float4 *>(hs), reinterpret_cast<float4 *>(h));
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 // Receptive field of the ligand outputs, one level per layer counted from the last: level 1 = the ligand atoms and
 // their neighbours (the last h2x reads the neighbours' projections), level k + 1 = level k plus its neighbours.  When
 // only ligand outputs are consumed, the layer e from the end needs new features for level e + 1 only.

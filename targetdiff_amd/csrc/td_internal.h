@@ -129,6 +129,10 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
                         uint8_t *clean, hipStream_t s);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
+int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
+                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, hipStream_t s);
+int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_t max_rows, const float *hs, float *h,
+                           hipStream_t s);
 constexpr int TD_HOP_LEVELS = 4;
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
                          int32_t *rows, int32_t *counts, int levels, hipStream_t s);
