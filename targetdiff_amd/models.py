@@ -115,16 +115,19 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         self._owner = None       # set by ScorePosNet3D: the module that owns the packed native weights
 
     def forward(self, h, x, mask_ligand, batch, return_all=False, fix_x=False):
-        if return_all:
-            raise NotImplementedError('return_all=True (per-block outputs) is not built yet')
+        """models/uni_transformer.py:301-328 -> {'x', 'h'[, 'all_x', 'all_h']}; with num_blocks == 1 the lists hold the
+        block input and the block output (:304-305, :322-323)."""
         if self._owner is None:
             raise RuntimeError('refine_net must be owned by a ScorePosNet3D (it packs the weights for the HIP library)')
         native = self._owner()._native(h.device)
         B = int(batch.max().item()) + 1 if batch.numel() else 0
         node_ptr = native.graph_ptr(batch.contiguous(), B)
-        out_h, out_x, _, _ = native.refine_forward(h.contiguous().float(), x.contiguous().float(), mask_ligand,
-                                                   node_ptr, fix_x=fix_x)
-        return {'x': out_x, 'h': out_h}
+        h_in, x_in = h.contiguous().float(), x.contiguous().float()
+        out_h, out_x, _, _ = native.refine_forward(h_in, x_in, mask_ligand, node_ptr, fix_x=fix_x)
+        outputs = {'x': out_x, 'h': out_h}
+        if return_all:
+            outputs.update({'all_x': [x_in, out_x], 'all_h': [h_in, out_h]})
+        return outputs
 
 
 def get_refine_net(refine_net_type, config):

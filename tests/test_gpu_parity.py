@@ -207,7 +207,8 @@ def test_refine_net_module_full_depth(model, state_dict, golden_small):
     h_l = torch.cat([h_l, torch.ones(len(h_l), 1)], -1)
     h, x, batch_all, mask = R.compose_context(h_p, h_l, inp['protein_pos'], inp['ligand_pos'], inp['batch_protein'],
                                               inp['batch_ligand'])
-    out = model.refine_net(h.to(dev), x.to(dev), mask.to(dev), batch_all.to(dev))
+    out = model.refine_net(h.to(dev), x.to(dev), mask.to(dev), batch_all.to(dev), return_all=True)
+    assert len(out['all_x']) == 2 and torch.equal(out['all_x'][1], out['x']) and torch.equal(out['all_h'][0].cpu(), h)
     dh = _maxdiff(out['h'], g['h_layers'][8])
     dx = _maxdiff(out['x'], g['x_layers'][8])
     print(f'layer8: |dh|={dh:.3e} |dx|={dx:.3e}')
