@@ -410,6 +410,18 @@ def graph_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
     return ptr
 
 
+def protein_centroids(protein_pos: torch.Tensor, protein_ptr: torch.Tensor) -> torch.Tensor:
+    """Per-graph centroid [B, 3] of the protein atoms (td_center_pos's offset: one block reduction per graph, so the
+    result is run-to-run reproducible, unlike an atomics-based scatter_mean)."""
+    lib = load_library()
+    B = protein_ptr.numel() - 1
+    scratch = protein_pos.detach().clone().contiguous().float()
+    offset = torch.empty(B, 3, dtype=torch.float32, device=protein_pos.device)
+    _check(lib.td_center_pos(_ptr(scratch), _ptr(protein_ptr, torch.int32, 'protein_ptr'), None,
+                             _ptr(protein_ptr, torch.int32, 'protein_ptr'), B, _ptr(offset), 1, -1, _stream()), 'td_center_pos')
+    return offset
+
+
 class NativeEgnn:
     """Owns a td_egnn handle: the EGNN refine net of models/egnn.py with packed weights on the current HIP device."""
 

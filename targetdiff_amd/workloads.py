@@ -141,9 +141,16 @@ def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, gener
     it to emulate the geometry of a later, spread-out ligand; the reference's initial state is spread = 1)."""
     dev = batch.protein_pos.device
     B = batch.num_graphs
-    s = torch.zeros(B, 3, device=dev).index_add_(0, batch.protein_element_batch, batch.protein_pos)
-    c = torch.bincount(batch.protein_element_batch, minlength=B).clamp(min=1).unsqueeze(-1).float()
-    center = (s / c)[batch.ligand_element_batch]
+    if dev.type == 'cuda':
+        # deterministic per-graph reduction in the HIP library (an index_add_ / scatter_mean on the GPU sums with atomics
+        # and makes the starting positions differ in the last bit from run to run)
+        from . import capi
+        cen = capi.protein_centroids(batch.protein_pos, capi.graph_ptr(batch.protein_element_batch.contiguous(), B))
+    else:
+        s = torch.zeros(B, 3, device=dev).index_add_(0, batch.protein_element_batch, batch.protein_pos)
+        c = torch.bincount(batch.protein_element_batch, minlength=B).clamp(min=1).unsqueeze(-1).float()
+        cen = s / c
+    center = cen[batch.ligand_element_batch]
     n = center.shape[0]
     pos = center + spread * torch.randn(n, 3, generator=generator, device=dev)
     u = torch.rand(n, num_classes, generator=generator, device=dev)

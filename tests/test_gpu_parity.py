@@ -659,3 +659,20 @@ def test_egnn_large_batch_replicas():
     assert torch.equal(hb, hb[:1].expand_as(hb)) and torch.equal(xb, xb[:1].expand_as(xb))
     assert torch.equal(hb[0], small['h'][:325]) and torch.equal(xb[0], small['x'][:325])
     assert float((big['x'].view(60, 325, 3)[0, 300:] - x1[300:].to(dev)).abs().max()) > 1e-3      # the ligand moved
+
+
+def test_same_seed_sampling_is_bit_reproducible(model):
+    """No atomics-ordered arithmetic anywhere on the path (including the initial centroid): two driver calls with the same
+    torch seed return identical coordinates, types and trajectories."""
+    from targetdiff_amd import sampling
+    dev = _dev()
+    pocket, sizes = pocket_1h36()
+    sizes = [int(v) for v in sizes[:12]]
+
+    def run():
+        torch.manual_seed(123)
+        return sampling.sample_diffusion_ligand(model, pocket, num_samples=12, batch_size=12, device=dev, num_steps=25,
+                                                ligand_num_atoms=sizes)
+    a, b = run(), run()
+    for k in range(6):
+        assert all(np.array_equal(x, y) for x, y in zip(a[k], b[k])), k

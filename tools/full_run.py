@@ -67,20 +67,23 @@ def main():
 
     # the timed end-to-end calls: the first one pays one-time costs (RNG / allocator warm-up), the second is steady state
     walls = []
-    for rep in range(2):
-        torch.manual_seed(2021 + rep)
+    finals = []
+    for rep in range(3):
+        torch.manual_seed(2021 + min(rep, 1))          # calls 1 and 2 share a seed: the whole run must be reproducible
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = sampling.sample_diffusion_ligand(model, pockets[0], args.samples, batch_size=args.samples, device=dev,
                                                num_steps=args.steps, ligand_num_atoms=sizes)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
+        finals.append(np.concatenate([p.ravel() for p in out[0]] + [v.ravel().astype(np.float64) for v in out[1]]))
     wall = walls[-1]
+    reproducible = bool(np.array_equal(finals[1], finals[2]))
     pos = out[0]
     finite = all(np.isfinite(p).all() for p in pos)
     res = {'workload': desc, 'samples': args.samples, 'steps': args.steps, 'wall_s': wall, 'wall_s_first_call': walls[0],
            'ligands_per_s_end_to_end': args.samples / wall * (1000.0 / args.steps), 'driver_time_list_s': out[6],
-           'final_positions_finite': bool(finite),
+           'final_positions_finite': bool(finite), 'same_seed_runs_bit_identical': reproducible,
            'final_ligand_coordinate_std_A': float(np.mean([p.std(axis=0).mean() for p in pos])),
            'trajectory_row_stats': stats}
     print(json.dumps(res))
