@@ -64,10 +64,25 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
             sizes = _prior_sizes(pocket, n_data, atom_num_sampler)
         elif sample_num_atoms == 'range':
             sizes = list(range(current_i + 1, current_i + n_data + 1))                      # :51-53
+        elif sample_num_atoms == 'ref':                                                         # :54-56
+            ref_lig = getattr(data, 'ligand_element', None)
+            if ref_lig is None:
+                ref_lig = getattr(data, 'ligand_pos', None)
+            if ref_lig is None:
+                raise ValueError("sample_num_atoms='ref' needs the reference ligand on `data` (ligand_element / ligand_pos)")
+            sizes = [int(len(ref_lig))] * n_data
         else:
-            raise NotImplementedError(f"sample_num_atoms={sample_num_atoms!r} ('ref' needs the ligand of `data`)")
+            raise ValueError(sample_num_atoms)
         batch = workloads.pack_samples(pocket, n_data, sizes).to(device)
         init_pos, init_v = workloads.init_ligand(batch, model.num_classes, generator=generator)   # :60-70
+        if pos_only:                                                                              # :66-67
+            full = getattr(data, 'ligand_atom_feature_full', None)
+            if full is None:
+                raise ValueError('pos_only=True takes the atom types from data.ligand_atom_feature_full')
+            full = torch.as_tensor(full, dtype=torch.long)
+            if any(sz != full.numel() for sz in sizes):
+                raise ValueError("pos_only=True needs ligands of the reference size (sample_num_atoms='ref')")
+            init_v = full.repeat(n_data).to(device)
         r = model.sample_diffusion(
             protein_pos=batch.protein_pos, protein_v=batch.protein_atom_feature.float(),
             batch_protein=batch.protein_element_batch, init_ligand_pos=init_pos, init_ligand_v=init_v,
@@ -81,7 +96,7 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
         v = r['v'].cpu().numpy()
         all_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]                               # :102-103
         all_v_traj += unbatch_v_traj(r['v_traj'], n_data, cum)
-        all_v0_traj += unbatch_v_traj(r['v0_traj'], n_data, cum)
+        all_v0_traj += unbatch_v_traj(r['v0_traj'], n_data, cum)      # empty lists (pos_only) raise here, as in the reference
         all_vt_traj += unbatch_v_traj(r['vt_traj'], n_data, cum)
         time_list.append(time.time() - t1)
         current_i += n_data
