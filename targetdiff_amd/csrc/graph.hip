@@ -151,12 +151,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
             unsigned long long lmin = carry;
 #pragma unroll
             for (int u = 0; u < CH; ++u) lmin = key[u] < lmin ? key[u] : lmin;
-            unsigned long long wmin = lmin;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                unsigned long long o = __shfl_xor(wmin, off);
-                wmin = o < wmin ? o : wmin;
-            }
+            const unsigned long long wmin = td_wave_min_u64(lmin);
             if (wmin != TD_KEY_MAX) {        // keys are unique (they embed the index): exactly one owner
                 if (carry == wmin) carry = TD_KEY_MAX;
 #pragma unroll
@@ -263,12 +258,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
                 unsigned long long lmin = carry;
                 lmin = kl[0] < lmin ? kl[0] : lmin;
                 lmin = kl[1] < lmin ? kl[1] : lmin;
-                unsigned long long wmin = lmin;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    unsigned long long o = __shfl_xor(wmin, off);
-                    wmin = o < wmin ? o : wmin;
-                }
+                const unsigned long long wmin = td_wave_min_u64(lmin);
                 if (wmin != TD_KEY_MAX) {
                     if (carry == wmin) carry = TD_KEY_MAX;
                     if (kl[0] == wmin) kl[0] = TD_KEY_MAX;

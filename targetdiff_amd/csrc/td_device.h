@@ -87,6 +87,36 @@ __device__ __forceinline__ float td_sum64(float v) {
     return td_sum_halves(v);
 }
 
+// Minimum of a 64-bit key over the 64 lanes, result in every lane: 4 DPP steps inside each row of 16, then the two
+// cross-row exchanges (v_permlane16_swap / v_permlane32_swap) -- all VALU, no LDS crossbar (a __shfl_xor butterfly on a
+// 64-bit value is 12 ds_bpermute per reduction and dominated the k-NN extraction loops).
+template <int CTRL>
+__device__ __forceinline__ unsigned long long td_dpp_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long td_min_u64(unsigned long long a, unsigned long long b) { return b < a ? b : a; }
+__device__ __forceinline__ unsigned long long td_wave_min_u64(unsigned long long v) {
+    v = td_min_u64(v, td_dpp_u64<DPP_QUAD_XOR1>(v));
+    v = td_min_u64(v, td_dpp_u64<DPP_QUAD_XOR2>(v));
+    v = td_min_u64(v, td_dpp_u64<DPP_ROW_HALF_MIRROR>(v));
+    v = td_min_u64(v, td_dpp_u64<DPP_ROW_MIRROR>(v));
+    {
+        unsigned alo = (unsigned)v, blo = (unsigned)v, ahi = (unsigned)(v >> 32), bhi = (unsigned)(v >> 32);
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+        v = td_min_u64(((unsigned long long)ahi << 32) | alo, ((unsigned long long)bhi << 32) | blo);
+    }
+    {
+        unsigned alo = (unsigned)v, blo = (unsigned)v, ahi = (unsigned)(v >> 32), bhi = (unsigned)(v >> 32);
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+        v = td_min_u64(((unsigned long long)ahi << 32) | alo, ((unsigned long long)bhi << 32) | blo);
+    }
+    return v;
+}
+
 // distance^2 with the project's fixed association and no FMA contraction (oracle/shims.py)
 __device__ __forceinline__ float td_dist2(float dx, float dy, float dz) {
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
