@@ -136,6 +136,43 @@ size_t pack_B128(Packer &pk, const float *W, int ld, int col0) {
     return off;
 }
 
+// bf16 round-to-nearest-even of an fp32 value, returned as the upper 16 bits
+inline uint32_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+    return r >> 16;
+}
+inline float bf16_to_f32(uint32_t b) {
+    const uint32_t u = b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+// B operand of the split node-projection GEMM: [s 8][piece 3][lane 64][tile 4] x 8 bf16 (two per 32-bit word, slot j of lane
+// half hi = k index 16s + 8(j >> 2) + 4hi + (j & 3)); piece p of W = bf16 of the residual left by pieces 0 .. p-1 (exact)
+size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
+    size_t off = pk.alloc((size_t)8 * 3 * 64 * 4 * 4);
+    uint32_t *d = reinterpret_cast<uint32_t *>(pk.data.data() + off);
+    for (int s = 0; s < 8; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 4; ++t) {
+                uint32_t pieces[3][8];
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                    float r = W[(size_t)(32 * t + (lane & 31)) * ld + col0 + k];
+                    for (int p = 0; p < 3; ++p) {
+                        pieces[p][j] = bf16_rne(r);
+                        r -= bf16_to_f32(pieces[p][j]);
+                    }
+                }
+                for (int p = 0; p < 3; ++p)
+                    for (int w = 0; w < 4; ++w)
+                        d[((((size_t)s * 3 + p) * 64 + lane) * 4 + t) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+            }
+    return off;
+}
+
 size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     size_t off = pk.alloc(padded ? padded : n);
     if (v) memcpy(pk.data.data() + off, v, n * sizeof(float));
@@ -240,7 +277,7 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
     return o;
 }
 
-struct NodeOff { size_t projB, projBias, qGamma, qBeta, q3B, q3Bias; };
+struct NodeOff { size_t projB, projBias, qGamma, qBeta, q3B, q3Bias, projB3, q3B3; };
 
 NodeOff pack_node_stage(Packer &pk, const MlpSrc &k, const MlpSrc &v, const MlpSrc &q, int in_dim) {
     NodeOff o;
@@ -258,6 +295,12 @@ NodeOff pack_node_stage(Packer &pk, const MlpSrc &k, const MlpSrc &v, const MlpS
     o.qBeta = pack_vec(pk, q.b, TD_H);
     o.q3B = pack_B128(pk, q.w3, TD_H, 0);
     o.q3Bias = pack_vec(pk, q.b3, TD_H);
+    o.projB3 = pack_B128_split(pk, k.w0, in_dim, hi_col);      // consecutive blocks, same matrix order as projB
+    pack_B128_split(pk, k.w0, in_dim, hj_col);
+    pack_B128_split(pk, v.w0, in_dim, hi_col);
+    pack_B128_split(pk, v.w0, in_dim, hj_col);
+    pack_B128_split(pk, q.w0, TD_H, 0);
+    o.q3B3 = pack_B128_split(pk, q.w3, TD_H, 0);
     return o;
 }
 
@@ -381,7 +424,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
     auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt}; };
     auto node = [&](const NodeOff &o) {
-        return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias};
+        return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3};
     };
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
@@ -785,7 +828,7 @@ extern "C" int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t ed
     for (int l = 0; l < num_layers; ++l) {
         const Off &o = off[(size_t)l];
         TdEgnnLayer &L = m->layers[l];
-        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr};
+        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         L.W2f = D + o.W2f; L.Wxf = D + o.Wxf; L.vec = D + o.vec; L.nodeB = D + o.nodeB; L.nb1 = D + o.nb1; L.nb2 = D + o.nb2;
     }
     *out = m;

@@ -11,6 +11,8 @@
 // tile) and all 128 output columns (4 N-tiles -> 64 accumulator VGPRs).  A operands (the 32 x 128 h tile)
 // stay in registers for all six GEMMs; B operands (pre-packed fragment order) are staged through LDS in 16 KiB
 // chunks shared by the workgroup's 4 waves (gemm128_lds).
+#include <cstdlib>
+
 #include "td_device.h"
 #include "td_internal.h"
 
@@ -55,6 +57,83 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
     }
 }
 
+// ---- experimental: exact 3-way bf16 splitting of both GEMM operands (TD_NODE_PROJ_SPLIT=1) ------------------------------
+// An fp32 significand (24 bits) is exactly the sum of three bf16 pieces (8 bits each): x = x1 + x2 + x3.  The six largest of
+// the nine piece products (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) on v_mfma_f32_32x32x16_bf16, accumulated in fp32, reproduce
+// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time ([s 8][piece 3][lane][tile 4]
+// x 8 bf16, the 8 k-slots of lane half `hi` in k-step s being k = 16s + 8(j >> 2) + 4hi + (j & 3), i.e. exactly the two float4
+// of the fp32 A tile), A is split once per tile in registers.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int NPS_CHUNK_U4 = 2 * 3 * 64 * 4;            // uint4 per staged chunk: 2 k-steps x 3 pieces x 64 lanes x 4 tiles (24 KiB)
+constexpr int NPS_CHUNKS = 4;
+constexpr size_t NPS_LDS_BYTES = (size_t)2 * NPS_CHUNK_U4 * 16 + (size_t)4 * 32 * NP_TSTRIDE * sizeof(float);
+
+__device__ __forceinline__ floatx16 td_mfma_bf16(uint4 a, uint4 b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned td_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void td_split2(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = td_cvt_pk_bf16(x, y);
+    float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);      // exact in fp32
+    p2 = td_cvt_pk_bf16(rx, ry);
+    rx -= __uint_as_float(p2 << 16);
+    ry -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = td_cvt_pk_bf16(rx, ry);
+}
+// A tile (fp32, a[m] = h[row][8m + 4hi .. + 3]) -> three bf16 pieces per k-step
+__device__ __forceinline__ void td_split_tile(const float4 (&a)[16], uint4 (&ap)[3][8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 u = a[2 * s], v = a[2 * s + 1];
+        td_split2(u.x, u.y, ap[0][s].x, ap[1][s].x, ap[2][s].x);
+        td_split2(u.z, u.w, ap[0][s].y, ap[1][s].y, ap[2][s].y);
+        td_split2(v.x, v.y, ap[0][s].z, ap[1][s].z, ap[2][s].z);
+        td_split2(v.z, v.w, ap[0][s].w, ap[1][s].w, ap[2][s].w);
+    }
+}
+__device__ __forceinline__ void gemm128_split(const uint4 (&ap)[3][8], const uint4 *__restrict__ B, const uint4 *__restrict__ next,
+                                              uint4 *__restrict__ bufs, int &cur, int tid, int lane, floatx16 (&acc)[4]) {
+#pragma unroll
+    for (int ch = 0; ch < NPS_CHUNKS; ++ch) {
+        const uint4 *src = ch + 1 < NPS_CHUNKS ? B + (size_t)(ch + 1) * NPS_CHUNK_U4 : next;
+        if (src) {
+            uint4 *dst = bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63);
+            const int nthr = blockDim.x;
+            for (int u = 0; u < NPS_CHUNK_U4; u += nthr)
+                td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
+        }
+        const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane * 4;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const int s = 2 * ch + ss;
+            uint4 b[3][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[p][t] = bl[(ss * 3 + p) * 256 + t];
+            // low-order products first
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[1][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[2][s], b[0][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[2][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[0][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[1][t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[0][t], acc[t]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // One launch processes up to three row segments, each with its own stage weights, row list and outputs:
 //   mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP
 //   rows != nullptr: only the listed node ids; count_ptr != nullptr: device-side list length (N is then the bound the
@@ -79,6 +158,7 @@ struct NpArgs {
     int nseg;
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const float *__restrict__ h) {
     int bx = blockIdx.x, si = 0;
     while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
@@ -98,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
         if ((int64_t)bx * (blockDim.x >> 1) >= N) return;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
+    float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks (SPLIT: 2 x 24 KiB)
+    uint4 *bufs3 = reinterpret_cast<uint4 *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;          // wave-private transpose tile
+    float *tb = lds + (SPLIT ? 2 * NPS_CHUNK_U4 * 4 : 2 * NP_CHUNK_F4 * 4) + wave * 32 * NP_TSTRIDE;   // wave-private transpose tile
     const int c = lane & 31, hi = lane >> 5;
     const int64_t row0 = ((int64_t)bx * (blockDim.x >> 6) + wave) * 32;
     const int64_t aslot = row0 + c;
@@ -131,16 +212,19 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
         mat_mask = sel;
     }
     // the matrices this launch walks through, in order: selected projections, then q.net.0, then q.net.3
-    const float4 *Bp = reinterpret_cast<const float4 *>(st.projB);
+    constexpr size_t MAT_F4 = SPLIT ? (size_t)NPS_CHUNKS * NPS_CHUNK_U4 : (size_t)TD_KSTEPS * 64;     // 16-byte units per matrix
+    const float4 *Bp = reinterpret_cast<const float4 *>(SPLIT ? st.projB3 : st.projB);
     const float4 *seq[6];
     int mats[6], nseq = 0;
     for (int mat = 0; mat < 5; ++mat)
-        if ((mat_mask >> mat) & 1u) { seq[nseq] = Bp + (size_t)mat * TD_KSTEPS * 64; mats[nseq++] = mat; }
-    if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(st.q3B); mats[nseq++] = 5; }
+        if ((mat_mask >> mat) & 1u) { seq[nseq] = Bp + (size_t)mat * MAT_F4; mats[nseq++] = mat; }
+    if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(SPLIT ? st.q3B3 : st.q3B); mats[nseq++] = 5; }
     // prologue: first chunk of the first matrix
-    for (int u = tid; u < NP_CHUNK_F4; u += blockDim.x) bufs[u] = seq[0][u];
+    for (int u = tid; u < (SPLIT ? NPS_CHUNK_U4 : NP_CHUNK_F4); u += blockDim.x) bufs[u] = seq[0][u];
     __syncthreads();
     int cur = 0;
+    uint4 ap[SPLIT ? 3 : 1][8];
+    if constexpr (SPLIT) td_split_tile(a, ap);
 
     floatx16 acc[4];
     for (int si = 0; si < nseq; ++si) {
@@ -153,7 +237,10 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
             for (int r = 0; r < 16; ++r) acc[t][r] = bv;
         }
         const float4 *next = si + 1 < nseq ? seq[si + 1] : nullptr;
-        gemm128_lds(a, seq[si], next, bufs, cur, tid, lane, acc);     // for q.net.3 `a` holds the normalised hidden tile
+        if constexpr (SPLIT)
+            gemm128_split(ap, reinterpret_cast<const uint4 *>(seq[si]), reinterpret_cast<const uint4 *>(next), bufs3, cur, tid, lane, acc);
+        else
+            gemm128_lds(a, seq[si], next, bufs, cur, tid, lane, acc);     // for q.net.3 `a` holds the normalised hidden tile
         if (mat < 4) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -191,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
                 for (int mm = 0; mm < 4; ++mm)
                     a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);   // h tile no longer needed
             }
+            if constexpr (SPLIT) td_split_tile(a, ap);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -212,14 +300,28 @@ static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const i
     return g.blocks;
 }
 
+static bool np_split() {          // TD_NODE_PROJ_SPLIT=1: bf16 x 3 operand splitting (experimental, off by default)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TD_NODE_PROJ_SPLIT");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, unsigned y, unsigned threads, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel),
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_LDS_BYTES));
+        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NPS_LDS_BYTES));
         attr_set = true;
     }
-    node_proj_kernel<<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
+    bool split = np_split();
+    for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.projB3 != nullptr;
+    if (split) node_proj_kernel<true><<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
+    else node_proj_kernel<false><<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -50,6 +50,8 @@ struct TdNodeStage {
     const float *qGamma, *qBeta;   // [128]
     const float *q3B;      // [64 kstep][64 lane][4 ntile]  q.net.3
     const float *q3Bias;   // [128]
+    const float *projB3;   // optional: the same 5 matrices as bf16 piece triples [mat][8 kstep][3 piece][64 lane][4 ntile] x 8 bf16
+    const float *q3B3;     // optional: q.net.3 likewise (nullptr: the fp32 path is the only one)
 };
 
 struct TdLayer {

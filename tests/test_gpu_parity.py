@@ -464,11 +464,12 @@ np.savez(sys.argv[2], **{k: out[k].cpu().numpy() for k in ('pred_ligand_pos', 'p
 
 
 @pytest.mark.parametrize('env,bitwise', [({'TD_H2X_FUSED': '0'}, True), ({'TD_EDGE_IMPL': 'fast32'}, False),
-                                         ({'TD_EDGE_IMPL': 'plain'}, False)])
+                                         ({'TD_EDGE_IMPL': 'plain'}, False), ({'TD_NODE_PROJ_SPLIT': '1'}, False)])
 def test_alternative_kernel_paths_agree(model, golden_small, tmp_path, env, bitwise):
     """The debug switches select older kernels: the unfused h2x stage must match the fused one bit for bit (same
     arithmetic, alpha through memory instead of registers); the 32x32x2 and the materialised-k/v kernels re-associate
-    differently and must agree within the fp32 tolerance."""
+    differently and must agree within the fp32 tolerance; so must the experimental node projections that split both GEMM
+    operands exactly into three bf16 pieces (6 of the 9 piece products on the bf16 matrix cores, fp32 accumulate)."""
     import os
     import subprocess
     import sys
