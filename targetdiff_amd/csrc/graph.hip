@@ -396,35 +396,58 @@ __global__ void expand_hop_kernel(const int32_t *__restrict__ rows, int64_t coun
     if (j >= 0 && flags[j] == 0) flags[j] = (uint8_t)level;     // racing writers store the same value
 }
 
-__global__ void compact_flags_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
-                                     int32_t *__restrict__ count) {
+// level k (k >= 2): every row reached at a level < k marks its still unreached neighbours with k.  Runs over all rows, so
+// the levels need no compacted row lists in between.
+__global__ void expand_level_kernel(const int32_t *__restrict__ nbr, int64_t N, int level, uint8_t *__restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 5;
+    if (i >= N) return;
+    const int f = flags[i];
+    if (f == 0 || f >= level) return;                      // rows marked in this very pass (f == level) do not propagate yet
+    const int j = nbr[i * TD_K + (t & 31)];
+    if (j >= 0 && flags[j] == 0) flags[j] = (uint8_t)level;
+}
+
+// all level lists in one pass: level k = rows with 0 < flags <= k
+template <int LEVELS>
+__global__ void compact_levels_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
+                                      int32_t *__restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < N && flags[i];
-    const unsigned long long m = __ballot(on);
+    const int f = i < N ? (int)flags[i] : 0;
     const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0);
-    if (on) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < LEVELS; ++k) {
+        const bool on = f != 0 && f <= k + 1;
+        const unsigned long long m = __ballot(on);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(counts + k, __popcll(m));
+        base = __shfl(base, 0);
+        if (on) rows[(size_t)k * N + base + __popcll(m & below)] = (int32_t)i;
+    }
 }
 
 // rows: [levels][N] row lists, counts: [levels] device-side lengths
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
                          int32_t *rows, int32_t *counts, int levels, hipStream_t s) {
     if (N == 0 || levels <= 0) return TD_OK;
+    if (levels > TD_HOP_LEVELS) levels = TD_HOP_LEVELS;
     TD_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)N, s));
-    TD_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)levels, s));
-    for (int k = 0; k < levels; ++k) {
-        if (k == 0) {
-            if (Nl > 0) expand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nullptr, nbr, 1, flags);
-        } else {
-            expand_hop_kernel<<<dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, s>>>(rows + (size_t)(k - 1) * N, N, counts + k - 1,
-                                                                                         nbr, k + 1, flags);
-        }
-        TD_CHECK_HIP(hipGetLastError());
-        compact_flags_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags, N, rows + (size_t)k * N, counts + k);
+    TD_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)TD_HOP_LEVELS, s));
+    if (Nl > 0) expand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nullptr, nbr, 1, flags);
+    TD_CHECK_HIP(hipGetLastError());
+    for (int k = 2; k <= levels; ++k) {
+        expand_level_kernel<<<dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, s>>>(nbr, N, k, flags);
         TD_CHECK_HIP(hipGetLastError());
     }
+    const dim3 grid((unsigned)((N + 255) / 256));
+    switch (levels) {
+        case 1: compact_levels_kernel<1><<<grid, dim3(256), 0, s>>>(flags, N, rows, counts); break;
+        case 2: compact_levels_kernel<2><<<grid, dim3(256), 0, s>>>(flags, N, rows, counts); break;
+        case 3: compact_levels_kernel<3><<<grid, dim3(256), 0, s>>>(flags, N, rows, counts); break;
+        default: compact_levels_kernel<4><<<grid, dim3(256), 0, s>>>(flags, N, rows, counts); break;
+    }
+    TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
