@@ -107,3 +107,26 @@ def test_partition_is_the_reference_round_robin():
     parts = [workloads.partition_pockets(100, 8, r) for r in range(8)]
     assert sorted(sum(parts, [])) == list(range(100)) and parts[3][:3] == [3, 11, 19]
     assert workloads.partition_pockets(10, 4, 1, start_idx=4) == [5, 9]
+
+
+def test_egnn_mirror_state_dict_and_loud_failure():
+    """targetdiff_amd.egnn.EGNN has the reference's state_dict layout (models/egnn.py as get_refine_net('egnn') builds it),
+    its blob order matches the library's expectation, unsupported settings raise, and it refuses to run on CPU tensors."""
+    from targetdiff_amd.egnn import EGNN
+    from targetdiff_amd.models import get_refine_net
+    net = get_refine_net('egnn', dict(weights.DEFAULT_MODEL_CONFIG))
+    assert isinstance(net, EGNN) and net.num_layers == weights.DEFAULT_MODEL_CONFIG['num_layers']
+    spec = {k: tuple(s) for k, s, _, _ in weights.egnn_parameter_spec(net.num_layers)}
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == spec
+    net.load_state_dict(weights.make_egnn_state_dict(5, num_layers=net.num_layers), strict=True)
+    lib = capi.load_library()
+    n = sum(int(np.prod(spec[k])) for k in capi.egnn_flat_key_order(net.num_layers))
+    assert n == lib.td_egnn_num_weights(net.num_layers)
+    with pytest.raises(NotImplementedError):
+        EGNN(num_layers=2, hidden_dim=64, edge_feat_dim=4, num_r_gaussian=1)
+    with pytest.raises(NotImplementedError):
+        EGNN(num_layers=2, hidden_dim=128, edge_feat_dim=4, num_r_gaussian=1, cutoff_mode='hybrid')
+    with pytest.raises(ValueError):
+        get_refine_net('gcn', dict(weights.DEFAULT_MODEL_CONFIG))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(4, 128), torch.zeros(4, 3), torch.zeros(4, dtype=torch.bool), torch.zeros(4, dtype=torch.long))
