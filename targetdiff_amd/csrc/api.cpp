@@ -478,10 +478,9 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     return w;
 }
 
-// TD_EDGE_IMPL=plain selects the straightforward key/value kernels (edge.hip: per-edge k and v vectors are
-// materialised) instead of the re-associated ones (edge_fast.hip); used for A/B timing and as a cross-check.
-// TD_EDGE_IMPL: "plain" (edge.hip, materialised k/v), "fast32" (edge_fast.hip, 32x32x2 tiles) or the default
-// "fast16" (edge16.hip, 16x16x4 tiles).
+// TD_EDGE_IMPL selects the key / value kernels: "fast16" (default; edge16.hip, re-associated passes on 16x16x4 tiles),
+// "fast32" (edge_fast.hip, the same passes on 32x32x2 tiles) or "plain" (edge.hip, per-edge k and v vectors
+// materialised).  The alternatives exist for A/B timing and as cross-checks (tests: test_alternative_kernel_paths_agree).
 int edge_impl() {
     static int v = -1;
     if (v < 0) {
