@@ -1,0 +1,94 @@
+"""Oracle restatement vs the REAL reference model files on fresh inputs (beyond the committed golden vectors).
+
+Runs only where the reference tree exists (the build container); skipped on the GPU box, where /root/reference is
+absent by contract.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_loader, weights
+from oracle import restatement as R
+from targetdiff_amd import workloads
+
+pytestmark = pytest.mark.skipif(not reference_loader.available(), reason='reference tree not present')
+
+
+def _maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+@pytest.fixture(scope='module')
+def ref_model():
+    from oracle import make_golden
+    ref = reference_loader.load()
+    torch.set_num_threads(8)
+    model, sd = make_golden.build_reference_model(ref, seed=77)
+    return ref, model, sd
+
+
+def _batch(seed):
+    pockets = [workloads.synthetic_pocket(500 + seed, 70, 3.0, 9.0), workloads.synthetic_pocket(600 + seed, 40, 3.0, 8.0)]
+    b = workloads.pack_samples(pockets, 2, [8, 11, 6, 9])
+    lpos, lv = workloads.init_ligand(b, generator=torch.Generator().manual_seed(seed), spread=1.5)
+    return b, lpos, lv
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_forward_fresh_inputs(ref_model, seed):
+    ref, model, sd = ref_model
+    b, lpos, lv = _batch(seed)
+    ppos, lposc, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    with torch.no_grad():
+        want = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch)
+    got = R.model_forward(sd, None, ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv,
+                          b.ligand_element_batch)
+    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) < 2e-5
+    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) < 2e-5
+    assert _maxdiff(got['final_h'], want['final_h']) < 2e-5
+
+
+def test_likelihood_fresh_inputs(ref_model):
+    ref, model, sd = ref_model
+    b, lpos, lv = _batch(3)
+    rec = {}
+    o_normal, o_rand = torch.Tensor.normal_, torch.rand_like
+
+    def normal_(self, *a, **k):
+        out = o_normal(self, *a, **k)
+        rec['noise'] = out.clone()
+        return out
+
+    def rand_like(x, *a, **k):
+        out = o_rand(x, *a, **k)
+        rec['uniform'] = out.clone()
+        return out
+    ts = torch.tensor([12, 0, 999, 400], dtype=torch.long)
+    torch.Tensor.normal_, torch.rand_like = normal_, rand_like
+    try:
+        torch.manual_seed(5)
+        want = model.likelihood_estimation(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
+                                           b.ligand_element_batch, ts)
+    finally:
+        torch.Tensor.normal_, torch.rand_like = o_normal, o_rand
+    got = R.likelihood_estimation(sd, None, b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
+                                  b.ligand_element_batch, ts, noise=rec['noise'], uniform=rec['uniform'])
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.numpy(), w.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_egnn_fresh_inputs(ref_model):
+    import importlib
+    ref, _, _ = ref_model
+    egnn_mod = importlib.import_module('models.egnn')
+    net = egnn_mod.EGNN(num_layers=4, hidden_dim=128, edge_feat_dim=4, num_r_gaussian=1, k=32, cutoff_mode='knn').eval()
+    esd = weights.make_egnn_state_dict(9, num_layers=4)
+    net.load_state_dict(esd, strict=True)
+    b, lpos, _ = _batch(4)
+    g = torch.Generator().manual_seed(10)
+    h, x, batch, mask = R.compose_context(torch.randn(b.protein_pos.shape[0], 128, generator=g),
+                                          torch.randn(lpos.shape[0], 128, generator=g), b.protein_pos, lpos,
+                                          b.protein_element_batch, b.ligand_element_batch)
+    with torch.no_grad():
+        want = net(h, x, mask, batch)
+    got = R.egnn_forward(esd, h, x, mask, batch, num_layers=4)
+    assert _maxdiff(got['x'], want['x']) < 2e-5 and _maxdiff(got['h'], want['h']) < 5e-5
