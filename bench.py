@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- ligands/sec of the TargetDiff denoising hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1|c5|c4] [--no-cpu-baseline] [--no-full-run]
+
+`--gpus N` with no launcher around the script (no RANK / WORLD_SIZE in the environment) starts the N ranks itself, one
+process per GPU (targetdiff_amd/launch.py; the environment each rank sees is the one `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N` provides, so both launchers run the same code path).
 
 A "step" is one reverse-diffusion step (denoiser forward + posterior update + on-device trajectory
 record) over one packed batch.  Default workload = BASELINE.json configs[1] (the configuration the
@@ -38,7 +42,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from targetdiff_amd import capi, workloads  # noqa: E402
+from targetdiff_amd import capi, launch, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
@@ -90,6 +94,11 @@ def make_workload(name: str, rank: int):
     if name == 'c5':
         pocket = workloads.synthetic_pocket(5000 + rank, 1000, 4.0, 21.0)
         return [pocket], 256, [30] * 256, 'C5: synthetic 1000-atom pocket x 256 samples x 30 ligand atoms'
+    if name == 'c4':
+        # BASELINE config 4: 100 pockets x 100 samples, pocket i -> rank i % world (scripts/batch_sample_diffusion.sh:15-20);
+        # synthetic stand-ins sized 250-600 atoms (the CrossDocked test split is not available), ligand size 25
+        pockets = workloads.synthetic_test_set(100)
+        return pockets, 100, [25] * 100, 'C4: 100 synthetic pockets (250-600 atoms) x 100 samples x 25 ligand atoms, pocket i -> rank i % N'
     raise ValueError(name)
 
 
@@ -114,8 +123,9 @@ CPU_THREADS = 16       # fastest of 8 / 16 / 32 / 64 / 128 torch threads on the 
                        # step at 32 / 64 / 128: the small per-layer ops do not scale past one socket's worth of cores)
 
 
-def cpu_baseline(pocket, sizes, samples=4, steps=8):
-    """Oracle restatement on the host cores; bounded sample of the same workload (about 10 s of CPU work)."""
+def cpu_baseline(pocket, sizes, samples=4, steps=8, extrapolate=True):
+    """Oracle restatement on the host cores; bounded sample of the same workload (about 10 s of CPU work).
+    extrapolate=False: the sample IS a whole configuration (BASELINE config 1: 4 samples x 100 steps) and is reported as run."""
     from oracle import restatement as R
     from oracle import weights
     sd = weights.make_state_dict(2021)
@@ -137,10 +147,157 @@ def cpu_baseline(pocket, sizes, samples=4, steps=8):
         sec_per_step = (time.time() - t0) / steps
     finally:
         torch.set_num_threads(prev)
-    return {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/restatement.py (torch CPU fp32, {cores} threads = the fastest setting on this host), same pocket, '
-                      f'{samples} samples x {steps} steps ({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, '
-                      f'extrapolated to 1000 steps'}
+    res = {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'kind': 'port',
+           'sample': f'oracle/restatement.py (torch CPU fp32, {cores} threads = the fastest setting on this host), same pocket, '
+                     f'{samples} samples x {steps} steps ({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, '
+                     f'extrapolated to 1000 steps'}
+    if not extrapolate:
+        res['sample'] = (f'BASELINE config 1 in full: oracle/restatement.py (torch CPU fp32, {cores} threads), 1h36 pocket x {samples} '
+                         f'samples x {steps} steps run to completion in {sec_per_step * steps:.1f} s ({sec_per_step:.2f} s/step); value = '
+                         f'the same rate expressed per 1000-step ligand')
+        res['config1_wall_s'] = sec_per_step * steps
+    return res
+
+
+# ---- whole-step FLOP bookkeeping (2 flop per MAC; LayerNorm / activations / exp excluded) --------
+GEMM128 = 2 * 128 * 128                              # one 128 x 128 Linear on one row
+FIRST_LAYER = 2 * 32 * 128 * 20                      # radial/type first layer of one dst row (32 edges)
+H2X_ROW = KEY_PASS_FLOP_EXECUTED + FIRST_LAYER + 2 * 32 * 128 * 16     # key half + xv first layer + xv = W2xv z (16 heads)
+GATE_ROW = FIRST_LAYER + 2 * 32 * 128                # edge_pred_layer: 20 -> 128 per edge, 128 -> 1
+HEAD_ROW = GEMM128 + 2 * 128 * 13
+F_ALG_PER_NODE = 39.35e6                             # canonical, all stages on all edges
+F_REDUCED_PER_NODE = 24.5e6                          # same, h2x on ligand dst rows only (section 8d, last bullet)
+
+
+def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows):
+    """FLOPs the launched kernels execute in one denoiser step, from the rows every launch processes (the same row lists
+    run_backbone in csrc/api.cpp walks).  Stateless forward: every layer runs on every row."""
+    N, Nl, L = n_nodes, n_lig, n_layers
+    if session_rows is None:
+        x2h_rows = [N] * L
+        proj_rows = [N] * L
+        hop1 = N
+        gate_rows, layer0_proj = N, N
+    else:
+        levels = session_rows['receptive_field_levels']
+        lvl = lambda k: levels[k - 1] if 1 <= k <= len(levels) else N         # receptive-field level k (1-based) or all rows
+        x2h_rows, proj_rows = [session_rows['layer0_rows']], [Nl]             # layer 0: dirty rows; projections of ligand rows
+        for l in range(1, L):
+            e = L - 1 - l
+            rows = lvl(e + 1)
+            if l == 1 and e + 1 > len(levels) and session_rows.get('layer1_rows') is not None:
+                rows = session_rows['layer1_rows']
+            x2h_rows.append(rows)
+            proj_rows.append(lvl(e + 2))
+        hop1 = lvl(1)
+        gate_rows = session_rows['layer0_rows']
+    f = gate_rows * GATE_ROW + Nl * HEAD_ROW
+    for l in range(L):
+        f += proj_rows[l] * 6 * GEMM128                    # k_i, k_j, v_i, v_j, q.net.0, q.net.3
+        f += x2h_rows[l] * 2 * KEY_PASS_FLOP_EXECUTED      # key pass + value pass
+        f += hop1 * 2 * GEMM128 + Nl * 4 * GEMM128         # h2x stage: k_j, v_j on the hop rows; k_i, v_i, q.net.0/3 on ligand rows
+        f += Nl * H2X_ROW
+    return float(f)
+
+
+def build_model(dev):
+    model = ScorePosNet3D(MODEL_CONFIG, workloads.PROTEIN_FEATURE_DIM, workloads.NUM_LIGAND_CLASSES)
+    model.load_state_dict(seeded_state_dict(model), strict=False)
+    return model.to(dev).eval()
+
+
+def full_run(model, pocket, sizes, dev, steps=1000):
+    """One complete `sample_diffusion_ligand` call (the reference driver's unit of work, scripts/sample_diffusion.py:31-116):
+    every sample of the pocket in one batch, all `steps` reverse steps, wall-clocked end to end (batch construction, the
+    session set-up, the loop, the single trajectory D2H copy, un-batching to float64 numpy lists); then the same trajectory
+    once more through the stepping interface with HIP events around its first and last 10 steps."""
+    from targetdiff_amd import sampling
+    n = len(sizes)
+    torch.manual_seed(2021)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sampling.sample_diffusion_ligand(model, pocket, n, batch_size=n, device=dev, num_steps=steps, ligand_num_atoms=sizes)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    finite = all(np.isfinite(p).all() for p in out[0])
+    # first / last step times along the same trajectory
+    torch.manual_seed(2021)
+    pdev = workloads.DevicePocket(pocket, dev)
+    batch = workloads.pack_samples_device(pdev, n, sizes)
+    lpos, lv = workloads.init_ligand(batch)
+    sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch, lpos, lv,
+                                   batch.ligand_element_batch, num_steps=steps, center_pos_mode='protein',
+                                   max_graph_nodes=pocket.num_atoms + max(sizes))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    w = min(10, steps // 2)
+    for k in range(steps):
+        if k == 0:
+            ev[0].record()
+        if k == w:
+            ev[1].record()
+        if k == steps - w:
+            ev[2].record()
+        sampler.step()
+    ev[3].record()
+    torch.cuda.synchronize()
+    n_all, dirty, levels = sampler.session.row_counts()
+    return {'call': f'sample_diffusion_ligand(num_samples={n}, batch_size={n}, num_steps={steps})', 'samples': n, 'steps': steps,
+            'wall_s': wall, 'ligands_per_s': n / wall * (1000.0 / steps), 'driver_time_list_s': out[6],
+            'first_steps_ms': ev[0].elapsed_time(ev[1]) / w, 'last_steps_ms': ev[2].elapsed_time(ev[3]) / w,
+            'final_positions_finite': bool(finite),
+            'final_ligand_coordinate_std_A': float(np.mean([p.std(axis=0).mean() for p in out[0]])),
+            'last_step_session_rows': {'nodes': n_all, 'layer0_rows': dirty, 'receptive_field_levels': levels}}
+
+
+def run_c4(args, model, dev, rank, world, fence):
+    """BASELINE config 4: the test-set job of scripts/batch_sample_diffusion.sh.  Total work is fixed (100 pockets x 100
+    samples), pocket i goes to rank i % world; a "step" advances every pocket of the rank by one reverse step."""
+    import torch.distributed as dist
+    pockets, spp, sizes, desc = make_workload('c4', rank)
+    mine = workloads.partition_pockets(len(pockets), world, rank)
+    total = args.warmup + args.steps
+    samplers, nodes = [], 0
+    for i in mine:
+        pdev = workloads.DevicePocket(pockets[i], dev)
+        batch = workloads.pack_samples_device(pdev, spp, sizes)
+        gen = torch.Generator(device='cpu').manual_seed(2021 + i)
+        lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets[i], spp, sizes), generator=gen, spread=args.ligand_spread)
+        samplers.append(model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
+                                             lpos.to(dev), lv.to(dev), batch.ligand_element_batch, num_steps=total,
+                                             center_pos_mode='protein', max_graph_nodes=pockets[i].num_atoms + max(sizes),
+                                             use_session=not args.no_session))
+        nodes += int(batch.protein_pos.shape[0] + lpos.shape[0])
+    for sm in samplers:
+        for _ in range(args.warmup):
+            sm.step()
+    fence()
+    t0 = time.perf_counter()
+    for sm in samplers:
+        for _ in range(args.steps):
+            sm.step()
+    torch.cuda.synchronize()
+    mine_elapsed = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_rank = [mine_elapsed]
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([mine_elapsed], dtype=torch.float64, device=dev))
+        per_rank = [float(t.item()) for t in tall]
+    sec_per_step = elapsed / args.steps
+    return {
+        'metric': METRIC, 'value': len(pockets) * spp / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic (seeded random weights of the reference architecture; synthetic pockets; k-NN rule parity-unpinned upstream)',
+        'config': {'workload': desc, 'ligand_spread': args.ligand_spread, 'pockets_total': len(pockets),
+                   'pockets_this_rank': len(mine), 'nodes_rank0': nodes,
+                   'parallelism': f'pocket i -> rank i % {world} (no data-path collective)'},
+        'load_balance': {'per_rank_seconds': per_rank, 'max_over_mean': max(per_rank) / (sum(per_rank) / len(per_rank))},
+        'roofline': None}
 
 
 def main():
@@ -148,8 +305,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='c2', choices=['c1', 'c2', 'c3', 'c5'])
+    ap.add_argument('--workload', default='c2', choices=['c1', 'c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-full', action='store_true', help='time the CPU baseline on BASELINE config 1 in full (4 samples x 100 '
+                    'steps, ~2-5 min of host time) instead of the bounded sample')
+    ap.add_argument('--no-full-run', action='store_true', help='skip the complete 1000-step sample_diffusion_ligand call (c2, N = 1)')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel class, print a breakdown to stderr')
     ap.add_argument('--ligand-spread', type=float, default=LIGAND_SPREAD,
                     help='per-coordinate std (A) of the ligand cloud the timed steps start from; 1.0 = the sampler\'s '
@@ -158,6 +318,8 @@ def main():
                     help='after the timed region, also time 10 steps from the sampler\'s initial state N(0, I)')
     ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
     args = ap.parse_args()
+    # `--gpus N` without a launcher: become the launcher (N ranks of this same command line), exit with their status
+    launch.self_spawn_if_needed(args.gpus)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -172,16 +334,28 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI; rendezvous + timing max only
 
-    pockets, spp, sizes, desc = make_workload(args.workload, rank)
-    model = ScorePosNet3D(MODEL_CONFIG, workloads.PROTEIN_FEATURE_DIM, workloads.NUM_LIGAND_CLASSES)
-    model.load_state_dict(seeded_state_dict(model), strict=False)
-    model = model.to(dev).eval()
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
 
+    model = build_model(dev)
+    if args.workload == 'c4':
+        out = run_c4(args, model, dev, rank, world, fence)
+        if rank == 0:
+            print(json.dumps(out))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    pockets, spp, sizes, desc = make_workload(args.workload, rank)
     batch = workloads.pack_samples(pockets, spp, sizes).to(dev)
     gen = torch.Generator(device='cpu').manual_seed(2021 + rank)
     lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets, spp, sizes), generator=gen, spread=args.ligand_spread)
     lpos, lv = lpos.to(dev), lv.to(dev)
     n_nodes = int(batch.protein_pos.shape[0] + lpos.shape[0])
+    n_lig = int(lpos.shape[0])
     max_nodes = max(p.num_atoms for p in pockets) + max(sizes)
     total = args.warmup + args.steps
     if total > 1000:
@@ -191,11 +365,6 @@ def main():
                                    max_graph_nodes=max_nodes, use_session=not args.no_session)
     for _ in range(args.warmup):
         sampler.step()
-
-    def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k', 'x2h_v')
     fence()
@@ -233,18 +402,19 @@ def main():
             return None
         ms = p['ms'] / p['launches']
         achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (ms * 1e-3) / 1e12
-        # HBM traffic of the same kernel from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate passes, tools/pmc_collect.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- PMC counters
-        # cannot be read in-process
-        traffic = None
+        # HBM traffic of the same kernel: PMC counters cannot be read in-process, so this is the figure of the COMMITTED
+        # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
+        # FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- static, see traffic_source
+        traffic, source = None, None
         tpath = os.path.join(ROOT, 'profiles', traffic_file)
         if os.path.exists(tpath) and args.workload == 'c2' and sampler.session is not None:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
+            source = f'profiles/{traffic_file} (static: PMC pass of an earlier run of this command, not measured in this run)'
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                'traffic': traffic, 'launch_ms': ms, 'launches': p['launches'],
+                'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
                 'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
                 'hbm_frac': (traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
@@ -255,11 +425,25 @@ def main():
     roofline = pass_roofline('x2h_v', 'edge_value16_kernel (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', 'edge_key16_kernel<false, 16, 0> (x2h key pass)', 'traffic_x2h_key.json')
+    # whole step: FLOPs the launched kernels execute (from the row lists) against the fp32 peak, next to SURVEY 8d's algorithmic
+    # figures (which count work the session provably does not need to do: fractions above 1 there only say the eliminations are real)
+    f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows)
+    whole_step = {'executed_flop': f_exec, 'executed_tflops': f_exec / sec_per_step / 1e12,
+                  'executed_frac_of_fp32_peak': f_exec / sec_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                  'f_alg_flop': F_ALG_PER_NODE * n_nodes, 'f_alg_tflops': F_ALG_PER_NODE * n_nodes / sec_per_step / 1e12,
+                  'f_reduced_flop': F_REDUCED_PER_NODE * n_nodes,
+                  'f_reduced_frac_of_fp32_peak': F_REDUCED_PER_NODE * n_nodes / sec_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                  'note': 'executed = 2 flop/MAC of every Linear / attention product the launched kernels run on the rows they run '
+                          'on; f_alg / f_reduced = SURVEY.md section 8d (all rows, every layer)'}
+    if roofline is not None:
+        roofline['whole_step'] = whole_step
     out = {
         'metric': METRIC, 'value': value, 'unit': 'ligands/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded random weights of the reference architecture; '
-        + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets') + ')',
+        + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets')
+        + '; k-NN rule (d2 association, ties -> lower index) is the project\'s: torch_cluster is not in the reference tree, '
+          'parity-unpinned upstream)',
         'config': {'workload': desc, 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
@@ -282,14 +466,22 @@ def main():
         n0, d0, lv0c = s0.session.row_counts()
         out['initial_state'] = {'ligand_spread': 1.0, 'ms_per_step': ms0, 'value': world * graphs / ms0, 'steps': 10,
                                 'session_rows': {'nodes': n0, 'layer0_rows': d0, 'receptive_field_levels': lv0c}}
+    del sampler
     if rank == 0:
         if args.profile_all:
             for k, v in prof.items():
                 if v['launches']:
                     print(f'  {k:10s} {v["ms"] / args.steps:9.3f} ms/step  ({v["launches"] // args.steps} launches/step)',
                           file=sys.stderr)
+        # a complete run the driver's own clock can witness: outside the timed region, the 20-step line above is unchanged
+        if world == 1 and args.workload == 'c2' and not args.no_full_run and not args.no_session:
+            out['full_run'] = full_run(model, pockets[0], sizes, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(pockets[0], sizes)
+            if args.cpu_full:
+                c1p, c1n, c1s, _ = make_workload('c1', 0)
+                out['cpu_baseline'] = cpu_baseline(c1p[0], c1s, samples=c1n, steps=100, extrapolate=False)
+            else:
+                out['cpu_baseline'] = cpu_baseline(pockets[0], sizes)
         print(json.dumps(out))
     if distributed:
         dist.barrier()

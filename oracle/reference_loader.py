@@ -30,3 +30,24 @@ def load():
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib
     return importlib.import_module('models.molopt_score_model')
+
+
+def load_driver():
+    """Returns the reference ``scripts.sample_diffusion`` module (its ``sample_diffusion_ligand``, :31-116, is the
+    batching driver).  Its module-level imports that only ``__main__`` uses (``utils.transforms`` -> rdkit, ``datasets``
+    -> lmdb / rdkit) are stubbed; ``utils.misc``, ``utils.evaluation.atom_num`` and the model files are the real ones."""
+    import importlib
+    import types
+    load()
+    if 'utils.transforms' not in sys.modules:
+        importlib.import_module('utils')
+        sys.modules['utils.transforms'] = types.ModuleType('utils.transforms')
+    if 'datasets' not in sys.modules:
+        ds = types.ModuleType('datasets')
+        ds.get_dataset = None
+        pl = types.ModuleType('datasets.pl_data')
+        pl.FOLLOW_BATCH = ('protein_element', 'ligand_element', 'ligand_bond_type',)      # datasets/pl_data.py:7
+        ds.pl_data = pl
+        sys.modules['datasets'] = ds
+        sys.modules['datasets.pl_data'] = pl
+    return importlib.import_module('scripts.sample_diffusion')

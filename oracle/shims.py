@@ -145,6 +145,73 @@ def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow='sourc
                               'reads self.r which is never assigned)')
 
 
+# --------------------------------------------------------------------------- torch_geometric.data / .transforms
+class Data:
+    """Minimal stand-in for ``torch_geometric.data.Data`` as the sampling driver uses it (datasets/pl_data.py:10-36,
+    scripts/sample_diffusion.py:42): an attribute bag of tensors with ``clone()``."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith('_')]
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def __setitem__(self, k, v):
+        setattr(self, k, v)
+
+    def clone(self):
+        return type(self)(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.__dict__.items()})
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
+
+class Batch(Data):
+    """``Batch.from_data_list(list, follow_batch=K)``: every tensor attribute concatenated along
+    dim 0 (``*_index`` keys along the last dim, shifted by the running ligand atom count, datasets/pl_data.py:32-36) and
+    ``<key>_batch`` = graph id per row for each key in K."""
+
+    @classmethod
+    def from_data_list(cls, data_list, follow_batch=()):
+        out = cls()
+        keys = data_list[0].keys()
+        for k in keys:
+            vals = [d[k] for d in data_list]
+            if not torch.is_tensor(vals[0]):
+                setattr(out, k, vals)
+                continue
+            if k.endswith('index'):
+                shift, parts = 0, []
+                for d, v in zip(data_list, vals):
+                    parts.append(v + shift)
+                    shift += int(d['ligand_element'].size(0)) if hasattr(d, 'ligand_element') else 0
+                setattr(out, k, torch.cat(parts, dim=-1))
+            else:
+                setattr(out, k, torch.cat(vals, dim=0))
+            if k in follow_batch:
+                setattr(out, k + '_batch', torch.repeat_interleave(
+                    torch.arange(len(vals)), torch.tensor([int(v.size(0)) for v in vals])))
+        out.num_graphs = len(data_list)
+        return out
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+        return data
+
+
 # --------------------------------------------------------------------------- easydict
 class EasyDict(dict):
     """Attribute dict used by the reference config loader (utils/misc.py:23-25)."""
@@ -183,8 +250,15 @@ def install() -> None:
         tgnn.knn_graph = knn_graph
         tgnn.radius_graph = radius_graph
         tg.nn = tgnn
+        tgdata = types.ModuleType('torch_geometric.data')
+        tgdata.Data, tgdata.Batch = Data, Batch
+        tgtr = types.ModuleType('torch_geometric.transforms')
+        tgtr.Compose = Compose
+        tg.data, tg.transforms = tgdata, tgtr
         sys.modules['torch_geometric'] = tg
         sys.modules['torch_geometric.nn'] = tgnn
+        sys.modules['torch_geometric.data'] = tgdata
+        sys.modules['torch_geometric.transforms'] = tgtr
     if 'easydict' not in sys.modules:
         ed = types.ModuleType('easydict')
         ed.EasyDict = EasyDict

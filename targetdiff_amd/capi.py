@@ -123,8 +123,22 @@ def _ptr(t: torch.Tensor | None, dtype=None, what='tensor'):
     return c_void_p(t.data_ptr())
 
 
-def _stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """HIP stream of torch's current stream ON `device` (the tensors' device, not the process-wide current device)."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _canonical_device(device=None) -> torch.device:
+    d = torch.device('cuda') if device is None else torch.device(device)
+    if d.type != 'cuda':
+        raise RuntimeError(f'targetdiff_amd runs on HIP devices only (got {d}); there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device()) if d.index is None else d
+
+
+def _on(device):
+    """Every library call runs with the tensors' device current: the library launches on / allocates from the current HIP
+    device, and the reference CLI allows --device cuda:1 while the current device stays 0."""
+    return torch.cuda.device(device)
 
 
 # ----------------------------------------------------------------------------------------- weight blob
@@ -158,14 +172,28 @@ SCHEDULE_ORDER = ('posterior_mean_c0_coef', 'posterior_mean_ct_coef', 'posterior
 SCHEDULE_OPTIONAL = ('alphas_cumprod',)
 
 
+def _device_bound(fn):
+    """Run a method of a handle-owning class with the handle's device current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        for t in list(a) + list(k.values()):
+            if torch.is_tensor(t) and t.is_cuda and t.device != self.device:
+                raise RuntimeError(f'{fn.__name__}: tensor on {t.device}, but the native handle lives on {self.device}')
+        with _on(self.device):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class NativeModel:
-    """Owns a td_model handle (packed weights on the current HIP device) and a growable workspace."""
+    """Owns a td_model handle (packed weights on `device`) and a growable workspace."""
 
     def __init__(self, cfg: dict, state_dict, schedules: dict | None = None, device=None):
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError('no HIP device visible: targetdiff_amd needs an MI355X (gfx950); there is no CPU path')
-        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.device = _canonical_device(device)
         self.cfg = TdConfig(hidden_dim=cfg['hidden_dim'], n_heads=cfg['n_heads'], knn=cfg['knn'],
                             num_layers=cfg['num_layers'], num_r_gaussian=cfg['num_r_gaussian'],
                             edge_feat_dim=cfg['edge_feat_dim'], protein_feat_dim=cfg['protein_feat_dim'],
@@ -200,19 +228,22 @@ class NativeModel:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    @_device_bound
     def graph_ptr(self, batch: torch.Tensor, B: int) -> torch.Tensor:
         ptr = torch.empty(B + 1, dtype=torch.int32, device=batch.device)
-        _check(self.lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream()),
+        _check(self.lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream(self.device)),
                'td_graph_ptr')
         return ptr
 
+    @_device_bound
     def knn(self, x: torch.Tensor, node_ptr: torch.Tensor, k: int = KNN, max_graph_nodes: int = 0) -> torch.Tensor:
         N = x.shape[0]
         out = torch.empty(N, k, dtype=torch.int32, device=x.device)
         _check(self.lib.td_knn(_ptr(x, torch.float32, 'x'), _ptr(node_ptr, torch.int32, 'node_ptr'), N,
-                               node_ptr.numel() - 1, k, max_graph_nodes, _ptr(out), _stream()), 'td_knn')
+                               node_ptr.numel() - 1, k, max_graph_nodes, _ptr(out), _stream(self.device)), 'td_knn')
         return out
 
+    @_device_bound
     def refine_forward(self, h, x, mask_ligand, node_ptr, fix_x=False, max_graph_nodes=0, want_graph=False):
         N, B = h.shape[0], node_ptr.numel() - 1
         out_h = torch.empty_like(h)
@@ -224,9 +255,10 @@ class NativeModel:
         _check(self.lib.td_refine_forward(
             self.handle, _ptr(h, torch.float32, 'h'), _ptr(x, torch.float32, 'x'), _ptr(mask_u8),
             _ptr(node_ptr, torch.int32, 'node_ptr'), N, B, int(bool(fix_x)), max_graph_nodes, _ptr(out_h), _ptr(out_x),
-            _ptr(nbr), _ptr(ew), _ptr(ws), ws.numel(), _stream()), 'td_refine_forward')
+            _ptr(nbr), _ptr(ew), _ptr(ws), ws.numel(), _stream(self.device)), 'td_refine_forward')
         return out_h, out_x, nbr, ew
 
+    @_device_bound
     def model_forward(self, protein_pos, protein_v, protein_ptr, ligand_pos, ligand_v, ligand_ptr, fix_x=False,
                       max_graph_nodes=0, want_final_h=True, out=None):
         Np, Nl, B = protein_pos.shape[0], ligand_pos.shape[0], protein_ptr.numel() - 1
@@ -250,9 +282,10 @@ class NativeModel:
             _ptr(protein_ptr, torch.int32, 'protein_ptr'), Np, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
             _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
             int(bool(fix_x)), max_graph_nodes, _ptr(pred_pos), _ptr(pred_v), _ptr(lig_h), _ptr(final_h), _ptr(ws),
-            ws.numel(), _stream()), 'td_model_forward')
+            ws.numel(), _stream(self.device)), 'td_model_forward')
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': final_h, 'final_ligand_h': lig_h}
 
+    @_device_bound
     def posterior_step(self, t, ligand_ptr, ligand_pos, ligand_v, pred_pos, pred_v, noise, uniform,
                        pos_next=None, v_next=None, log_v0=None, log_post=None):
         Nl, B = ligand_pos.shape[0], ligand_ptr.numel() - 1
@@ -265,19 +298,21 @@ class NativeModel:
             _ptr(ligand_pos, torch.float32, 'ligand_pos'), _ptr(ligand_v, torch.int64, 'ligand_v'),
             _ptr(pred_pos, torch.float32, 'pred_pos'), _ptr(pred_v, torch.float32, 'pred_v'),
             _ptr(noise, torch.float32, 'noise'), _ptr(uniform, torch.float32, 'uniform'), _ptr(pos_next),
-            _ptr(v_next, torch.int64, 'v_next'), _ptr(log_v0), _ptr(log_post), _stream()), 'td_posterior_step')
+            _ptr(v_next, torch.int64, 'v_next'), _ptr(log_v0), _ptr(log_post), _stream(self.device)), 'td_posterior_step')
         return pos_next, v_next
 
     # ---- likelihood estimation / return_all (the other consumers of the denoiser)
+    @_device_bound
     def perturb(self, t, ligand_ptr, ligand_pos, ligand_v, noise, uniform):
         Nl, B = ligand_pos.shape[0], ligand_ptr.numel() - 1
         pos_t, v_t = torch.empty_like(ligand_pos), torch.empty_like(ligand_v)
         _check(self.lib.td_perturb(self.handle, _ptr(t, torch.int32, 't'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
                                    _ptr(ligand_pos, torch.float32, 'ligand_pos'), _ptr(ligand_v, torch.int64, 'ligand_v'),
                                    _ptr(noise, torch.float32, 'noise'), _ptr(uniform, torch.float32, 'uniform'),
-                                   _ptr(pos_t), _ptr(v_t), _stream()), 'td_perturb')
+                                   _ptr(pos_t), _ptr(v_t), _stream(self.device)), 'td_perturb')
         return pos_t, v_t
 
+    @_device_bound
     def likelihood_terms(self, t, ligand_ptr, pos_0, pos_t, v_0, v_t, pred_pos, pred_v):
         Nl, B = pos_0.shape[0], ligand_ptr.numel() - 1
         kl_pos = torch.empty(B, dtype=torch.float32, device=pos_0.device)
@@ -286,30 +321,34 @@ class NativeModel:
             self.handle, _ptr(t, torch.int32, 't'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
             _ptr(pos_0, torch.float32, 'pos_0'), _ptr(pos_t, torch.float32, 'pos_t'), _ptr(v_0, torch.int64, 'v_0'),
             _ptr(v_t, torch.int64, 'v_t'), _ptr(pred_pos, torch.float32, 'pred_pos'), _ptr(pred_v, torch.float32, 'pred_v'),
-            _ptr(kl_pos), _ptr(kl_v), _stream()), 'td_likelihood_terms')
+            _ptr(kl_pos), _ptr(kl_v), _stream(self.device)), 'td_likelihood_terms')
         return kl_pos, kl_v
 
+    @_device_bound
     def likelihood_prior(self, ligand_ptr, pos_0, v_index):
         Nl, B = pos_0.shape[0], ligand_ptr.numel() - 1
         kl_pos = torch.empty(B, dtype=torch.float32, device=pos_0.device)
         kl_v = torch.empty(B, dtype=torch.float32, device=pos_0.device)
         _check(self.lib.td_likelihood_prior(self.handle, _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
                                             _ptr(pos_0, torch.float32, 'pos_0'), _ptr(v_index, torch.int64, 'v_index'),
-                                            _ptr(kl_pos), _ptr(kl_v), _stream()), 'td_likelihood_prior')
+                                            _ptr(kl_pos), _ptr(kl_v), _stream(self.device)), 'td_likelihood_prior')
         return kl_pos, kl_v
 
+    @_device_bound
     def embed_ligand(self, ligand_v):
         h = torch.empty(ligand_v.shape[0], HIDDEN, dtype=torch.float32, device=ligand_v.device)
         _check(self.lib.td_embed_ligand(self.handle, _ptr(ligand_v, torch.int64, 'ligand_v'), ligand_v.shape[0], _ptr(h),
-                                        _stream()), 'td_embed_ligand')
+                                        _stream(self.device)), 'td_embed_ligand')
         return h
 
+    @_device_bound
     def v_inference(self, h):
         out = torch.empty(h.shape[0], self.num_classes, dtype=torch.float32, device=h.device)
-        _check(self.lib.td_v_inference(self.handle, _ptr(h, torch.float32, 'h'), h.shape[0], _ptr(out), _stream()),
+        _check(self.lib.td_v_inference(self.handle, _ptr(h, torch.float32, 'h'), h.shape[0], _ptr(out), _stream(self.device)),
                'td_v_inference')
         return out
 
+    @_device_bound
     def center_pos(self, protein_pos, protein_ptr, ligand_pos, ligand_ptr, offset=None, sign=-1):
         """In place.  offset=None: compute the protein centroids and subtract them (sign=-1)."""
         B = protein_ptr.numel() - 1
@@ -319,16 +358,17 @@ class NativeModel:
         _check(self.lib.td_center_pos(_ptr(protein_pos) if protein_pos is not None else None,
                                       _ptr(protein_ptr, torch.int32, 'protein_ptr'), _ptr(ligand_pos),
                                       _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), B, _ptr(offset), int(compute), sign,
-                                      _stream()), 'td_center_pos')
+                                      _stream(self.device)), 'td_center_pos')
         return offset
 
+    @_device_bound
     def debug_node_stage(self, layer: int, stage: int, h: torch.Tensor):
         """Test hook: node projections P [N,512] and query vectors q [N,128] of one attention stage."""
         N = h.shape[0]
         P = torch.empty(N, 4 * HIDDEN, dtype=torch.float32, device=h.device)
         q = torch.empty(N, HIDDEN, dtype=torch.float32, device=h.device)
         _check(self.lib.td_debug_node_stage(self.handle, layer, stage, _ptr(h, torch.float32, 'h'), N, _ptr(P), _ptr(q),
-                                            _stream()), 'td_debug_node_stage')
+                                            _stream(self.device)), 'td_debug_node_stage')
         return P, q
 
 
@@ -343,17 +383,24 @@ class NativeSession:
         self.C = native.num_classes
         self.device = protein_pos.device
         handle = c_void_p()
-        _check(self.lib.td_session_create(
-            native.handle, _ptr(protein_pos, torch.float32, 'protein_pos'), _ptr(protein_v, torch.float32, 'protein_v'),
-            _ptr(protein_ptr, torch.int32, 'protein_ptr'), protein_pos.shape[0], _ptr(ligand_ptr, torch.int32, 'ligand_ptr'),
-            self.Nl, protein_ptr.numel() - 1, max_graph_nodes, _stream(), ctypes.byref(handle)), 'td_session_create')
+        with _on(self.device):          # the session block is hipMalloc'ed on the current device
+            _check(self.lib.td_session_create(
+                native.handle, _ptr(protein_pos, torch.float32, 'protein_pos'), _ptr(protein_v, torch.float32, 'protein_v'),
+                _ptr(protein_ptr, torch.int32, 'protein_ptr'), protein_pos.shape[0], _ptr(ligand_ptr, torch.int32, 'ligand_ptr'),
+                self.Nl, protein_ptr.numel() - 1, max_graph_nodes, _stream(self.device), ctypes.byref(handle)),
+                'td_session_create')
         self.handle = handle
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None
         if h and getattr(self, 'lib', None) is not None:
-            self.lib.td_session_destroy(h)
+            try:
+                with _on(self.device):
+                    self.lib.td_session_destroy(h)
+            except Exception:            # interpreter shutdown: torch may already be gone
+                self.lib.td_session_destroy(h)
 
+    @_device_bound
     def forward(self, ligand_pos, ligand_v, out=None):
         out = out or {}
         dev = ligand_pos.device
@@ -368,7 +415,7 @@ class NativeSession:
             lig_h = torch.empty(self.Nl, HIDDEN, dtype=torch.float32, device=dev)
         _check(self.lib.td_session_forward(self.handle, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
                                            _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(pred_pos), _ptr(pred_v),
-                                           _ptr(lig_h), _stream()), 'td_session_forward')
+                                           _ptr(lig_h), _stream(self.device)), 'td_session_forward')
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': None, 'final_ligand_h': lig_h}
 
     def row_counts(self):
@@ -383,9 +430,10 @@ class NativeSession:
         v = int(self._counts()[6])
         return v if v >= 0 else None
 
+    @_device_bound
     def _counts(self):
         n = (c_int32 * 8)()
-        _check(self.lib.td_session_row_counts(self.handle, n, 8, _stream()), 'td_session_row_counts')
+        _check(self.lib.td_session_row_counts(self.handle, n, 8, _stream(self.device)), 'td_session_row_counts')
         return n
 
     def dirty_rows(self) -> int:
@@ -406,7 +454,9 @@ def graph_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
     """CSR offsets of a sorted PyG ``batch`` vector (td_graph_ptr); no model handle needed."""
     lib = load_library()
     ptr = torch.empty(B + 1, dtype=torch.int32, device=batch.device)
-    _check(lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream()), 'td_graph_ptr')
+    with _on(batch.device):
+        _check(lib.td_graph_ptr(_ptr(batch, torch.int64, 'batch'), batch.numel(), B, _ptr(ptr), _stream(batch.device)),
+               'td_graph_ptr')
     return ptr
 
 
@@ -417,8 +467,10 @@ def protein_centroids(protein_pos: torch.Tensor, protein_ptr: torch.Tensor) -> t
     B = protein_ptr.numel() - 1
     scratch = protein_pos.detach().clone().contiguous().float()
     offset = torch.empty(B, 3, dtype=torch.float32, device=protein_pos.device)
-    _check(lib.td_center_pos(_ptr(scratch), _ptr(protein_ptr, torch.int32, 'protein_ptr'), None,
-                             _ptr(protein_ptr, torch.int32, 'protein_ptr'), B, _ptr(offset), 1, -1, _stream()), 'td_center_pos')
+    with _on(protein_pos.device):
+        _check(lib.td_center_pos(_ptr(scratch), _ptr(protein_ptr, torch.int32, 'protein_ptr'), None,
+                                 _ptr(protein_ptr, torch.int32, 'protein_ptr'), B, _ptr(offset), 1, -1,
+                                 _stream(protein_pos.device)), 'td_center_pos')
     return offset
 
 
@@ -427,7 +479,7 @@ class NativeEgnn:
 
     def __init__(self, num_layers: int, state_dict, hidden_dim=HIDDEN, edge_feat_dim=4, k=KNN, device=None, prefix=''):
         self.lib = load_library()
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = _canonical_device(device)
         self.num_layers = int(num_layers)
         blob = np.ascontiguousarray(np.concatenate(
             [state_dict[prefix + key].detach().cpu().numpy().astype(np.float32).reshape(-1)
@@ -444,6 +496,7 @@ class NativeEgnn:
         if h and getattr(self, 'lib', None) is not None:
             self.lib.td_egnn_destroy(h)
 
+    @_device_bound
     def forward(self, h, x, mask_ligand, node_ptr, return_all=False, max_graph_nodes=0):
         N, B, L = h.shape[0], node_ptr.numel() - 1, self.num_layers
         out_h, out_x = torch.empty_like(h), torch.empty_like(x)
@@ -456,5 +509,5 @@ class NativeEgnn:
         _check(self.lib.td_egnn_forward(
             self.handle, _ptr(h, torch.float32, 'h'), _ptr(x, torch.float32, 'x'), _ptr(mask_u8),
             _ptr(node_ptr, torch.int32, 'node_ptr'), N, B, max_graph_nodes, _ptr(out_h), _ptr(out_x), _ptr(all_h), _ptr(all_x),
-            _ptr(self._ws), self._ws.numel(), _stream()), 'td_egnn_forward')
+            _ptr(self._ws), self._ws.numel(), _stream(self.device)), 'td_egnn_forward')
         return out_h, out_x, all_h, all_x

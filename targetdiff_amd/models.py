@@ -32,6 +32,23 @@ def _cfg_get(config, key, default=None):
     return getattr(config, key, default)
 
 
+def _check_graph_inputs(batch_protein, batch_ligand, ligand_v, num_classes):
+    """Host-side input checks at the points where the reference would raise or silently re-order:
+
+    * ``compose_context`` stable-sorts by graph id (models/common.py:126), so unsorted ``batch_*`` vectors are legal
+      there; the HIP path builds CSR offsets from sorted vectors (td_graph_ptr) -> refuse unsorted input loudly;
+    * ``F.one_hot(ligand_v, num_classes)`` (models/molopt_score_model.py:317) and ``index_to_log_onehot`` (:125) raise
+      on out-of-range atom types; the kernels would clamp them silently -> same check here.
+    One host sync per call (the reference syncs at :316 anyway)."""
+    for name, b in (('batch_protein', batch_protein), ('batch_ligand', batch_ligand)):
+        if b.numel() > 1 and not bool((b[1:] >= b[:-1]).all()):
+            raise ValueError(f'{name} must be sorted by graph id (PyG batch vectors are); got an unsorted vector')
+    if ligand_v.numel():
+        lo, hi = int(ligand_v.min()), int(ligand_v.max())
+        if lo < 0 or hi >= num_classes:
+            raise ValueError(f'ligand_v must be in [0, {num_classes}); got values in [{lo}, {hi}]')
+
+
 # ------------------------------------------------------------------------------------------ parameter holders
 class _Offsets(nn.Module):
     """Holds the ``offset`` buffer of GaussianSmearing (models/common.py:7-19, fixed_offset=True)."""
@@ -113,6 +130,11 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
             _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x)
             for _ in range(num_layers)])
         self._owner = None       # set by ScorePosNet3D: the module that owns the packed native weights
+
+    def __getstate__(self):
+        state = dict(super().__getstate__()) if hasattr(nn.Module, '__getstate__') else self.__dict__.copy()
+        state['_owner'] = None           # a weakref: not picklable; the owning ScorePosNet3D re-binds it
+        return state
 
     def forward(self, h, x, mask_ligand, batch, return_all=False, fix_x=False):
         """models/uni_transformer.py:301-328 -> {'x', 'h'[, 'all_x', 'all_h']}; with num_blocks == 1 the lists hold the
@@ -257,6 +279,27 @@ class ScorePosNet3D(nn.Module):
         self._native_model = None
         self._native_key = None
 
+    # ------------------------------------------------------------------------------------------ copy / pickle
+    def __getstate__(self):
+        """The native handle (a ctypes pointer into libtargetdiff_hip.so) is per process and rebuilt on first use:
+        drop it so that copy.deepcopy / pickle / torch.save(model) work after a forward has run."""
+        state = dict(super().__getstate__()) if hasattr(nn.Module, '__getstate__') else self.__dict__.copy()
+        state['_native_model'] = None
+        state['_native_key'] = None
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        import weakref
+        self.refine_net._owner = weakref.ref(self)       # re-bind: the copy's refine_net must pack the copy's weights
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        return new
+
     # ------------------------------------------------------------------------------------------ native handle
     def _param_fingerprint(self, device):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -285,6 +328,7 @@ class ScorePosNet3D(nn.Module):
         network when time_emb_dim == 0, as in the reference."""
         native = self._native(protein_pos.device)
         B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
+        _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, self.num_classes)
         pptr = native.graph_ptr(batch_protein.contiguous(), B)
         lptr = native.graph_ptr(batch_ligand.contiguous(), B)
         lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
@@ -346,7 +390,7 @@ class ScorePosNet3D(nn.Module):
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                          num_steps=None, center_pos_mode=None, pos_only=False, max_graph_nodes=0,
-                         noise_source=None):
+                         noise_source=None, use_session=True):
         """Ancestral sampling loop (models/molopt_score_model.py:633-703).
 
         Differences from the reference are confined to *where* things run, not what is computed: no
@@ -354,10 +398,11 @@ class ScorePosNet3D(nn.Module):
         accumulated in device buffers and copied to the host once at the end (same returned lists of CPU
         tensors, positions de-centred).  ``noise_source(step, name, like)`` may inject the Gaussian /
         uniform draws (parity tests); by default torch.randn_like / rand_like are used in the reference's
-        order."""
+        order.  ``use_session=False`` evaluates the stateless td_model_forward at every step (no static-protein
+        caching); the two are bit-identical (tests/test_gpu_long_parity.py)."""
         sampler = self.begin_sampling(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
                                       batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source,
-                                      pos_only=pos_only)
+                                      use_session=use_session, pos_only=pos_only)
         while not sampler.done:
             sampler.step()
         return sampler.finish()
@@ -370,8 +415,11 @@ class ReverseSampler:
     def __init__(self, model, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                  num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True, pos_only=False):
         self.pos_only = bool(pos_only)
-        if center_pos_mode not in ('protein', 'none', None):
-            raise NotImplementedError(center_pos_mode)
+        if center_pos_mode not in ('protein', 'none'):
+            # center_pos (models/molopt_score_model.py:110-120) raises for anything else -- including the signature
+            # default None, which would otherwise sample un-centred (off-distribution) without a word
+            raise NotImplementedError(f'center_pos_mode={center_pos_mode!r}: pass \'protein\' (configs/sampling.yml) or \'none\'')
+        _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, model.num_classes)
         dev = protein_pos.device
         self.native = native = model._native(dev)
         T = model.num_timesteps

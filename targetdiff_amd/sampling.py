@@ -9,6 +9,7 @@ here) -- ``Batch.from_data_list([data.clone()] * n)`` (:42) is replaced by ``wor
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -49,9 +50,15 @@ def unbatch_v_traj(ligand_v_traj, n_data, ligand_cum_atoms):
 
 def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cuda:0', num_steps=None,
                             pos_only=False, center_pos_mode='protein', sample_num_atoms='prior',
-                            atom_num_sampler=None, ligand_num_atoms=None, generator=None):
-    """Returns (pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj, time_list)."""
+                            atom_num_sampler=None, ligand_num_atoms=None, generator=None, noise_source=None):
+    """Returns (pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj, time_list).
+
+    Extra keyword arguments (not in the reference signature; all optional): ``atom_num_sampler`` / ``ligand_num_atoms``
+    replace the size prior's lookup table, ``generator`` seeds the initial draws, and ``noise_source(batch_index, step,
+    name, like)`` injects every Gaussian / uniform draw (``step == -1``: the initial positions / types of :60-70; ``step
+    >= 0``: the sampler's per-step draws) -- the parity tests use it to replay the reference's draws."""
     pocket = _as_pocket(data)
+    pocket_dev = None
     all_pos, all_v, all_pos_traj, all_v_traj, all_v0_traj, all_vt_traj, time_list = [], [], [], [], [], [], []
     num_batch = int(np.ceil(num_samples / batch_size))
     current_i = 0
@@ -73,8 +80,12 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
             sizes = [int(len(ref_lig))] * n_data
         else:
             raise ValueError(sample_num_atoms)
-        batch = workloads.pack_samples(pocket, n_data, sizes).to(device)
-        init_pos, init_v = workloads.init_ligand(batch, model.num_classes, generator=generator)   # :60-70
+        if pocket_dev is None:
+            pocket_dev = workloads.DevicePocket(pocket, device)       # one H2D copy of the pocket for all batches
+        batch = workloads.pack_samples_device(pocket_dev, n_data, sizes)                          # :42
+        src0 = None if noise_source is None else (lambda name, like, _i=i: noise_source(_i, -1, name, like))
+        init_pos, init_v = workloads.init_ligand(batch, model.num_classes, generator=generator, draw=src0,
+                                                 types=not pos_only)                               # :60-70
         if pos_only:                                                                              # :66-67
             full = getattr(data, 'ligand_atom_feature_full', None)
             if full is None:
@@ -87,7 +98,9 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
             protein_pos=batch.protein_pos, protein_v=batch.protein_atom_feature.float(),
             batch_protein=batch.protein_element_batch, init_ligand_pos=init_pos, init_ligand_v=init_v,
             batch_ligand=batch.ligand_element_batch, num_steps=num_steps, pos_only=pos_only,
-            center_pos_mode=center_pos_mode, max_graph_nodes=pocket.num_atoms + max(sizes))
+            center_pos_mode=center_pos_mode, max_graph_nodes=pocket.num_atoms + max(sizes),
+            **({} if noise_source is None else
+               {'noise_source': (lambda st, name, like, _i=i: noise_source(_i, st, name, like))}))
         cum = np.cumsum([0] + sizes)
         pos = r['pos'].cpu().numpy().astype(np.float64)
         all_pos += [pos[cum[k]:cum[k + 1]] for k in range(n_data)]                           # :87-90
@@ -96,22 +109,49 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
         v = r['v'].cpu().numpy()
         all_v += [v[cum[k]:cum[k + 1]] for k in range(n_data)]                               # :102-103
         all_v_traj += unbatch_v_traj(r['v_traj'], n_data, cum)
-        all_v0_traj += unbatch_v_traj(r['v0_traj'], n_data, cum)      # empty lists (pos_only) raise here, as in the reference
-        all_vt_traj += unbatch_v_traj(r['vt_traj'], n_data, cum)
+        if not pos_only:                                                                     # :108-112
+            all_v0_traj += unbatch_v_traj(r['v0_traj'], n_data, cum)
+            all_vt_traj += unbatch_v_traj(r['vt_traj'], n_data, cum)
         time_list.append(time.time() - t1)
         current_i += n_data
     return all_pos, all_v, all_pos_traj, all_v_traj, all_v0_traj, all_vt_traj, time_list
 
 
 # ------------------------------------------------------------------------------------------ multi-GPU
-def run_sharded(model, pockets, num_samples, rank=0, world_size=1, start_idx=0, **kwargs):
-    """Pocket-level data parallelism: pocket i is sampled by rank i % world_size
-    (scripts/batch_sample_diffusion.sh:15-20).  No data-path collective exists on this path; the caller
-    may gather the per-rank result metadata (see ``gather_metadata``)."""
-    results = {}
-    for idx in workloads.partition_pockets(len(pockets), world_size, rank, start_idx):
-        results[idx] = sample_diffusion_ligand(model, pockets[idx], num_samples, **kwargs)
-    return results
+def run_sharded(model, pockets, num_samples, rank=0, world_size=1, start_idx=0, result_path=None, skip_existing=True,
+                keep_results=None, on_pocket=None, **kwargs):
+    """Pocket-level data parallelism: pocket i is sampled by rank i % world_size, from ``start_idx`` on
+    (scripts/batch_sample_diffusion.sh:13-20).  No data-path collective exists on this path; the caller may gather the
+    per-rank result metadata (see ``gather_metadata``).
+
+    ``result_path``: write ``result_{i}.pt`` per pocket in the reference layout (scripts/sample_diffusion.py:175-188)
+    from a background thread, and -- ``skip_existing`` -- skip pockets whose file is already there (idempotent re-runs;
+    the reference resumes by hand through START_IDX).  Returns {pocket index: 7-tuple} for the pockets sampled in this
+    call (``keep_results=False`` drops the tuples once written and returns {index: None}: a test set's trajectories are
+    gigabytes).  ``on_pocket(index, seconds, skipped)`` is called after every pocket."""
+    import time as _time
+    from . import results as _results
+    keep = (result_path is None) if keep_results is None else keep_results
+    out = {}
+    writer = _results.AsyncResultWriter() if result_path is not None else None
+    try:
+        for idx in workloads.partition_pockets(len(pockets), world_size, rank, start_idx):
+            path = _results.result_file(result_path, idx) if result_path is not None else None
+            if path is not None and skip_existing and os.path.exists(path):
+                if on_pocket:
+                    on_pocket(idx, 0.0, True)
+                continue
+            t0 = _time.time()
+            res = sample_diffusion_ligand(model, pockets[idx], num_samples, **kwargs)
+            if writer is not None:
+                writer.submit(path, _results.result_dict(pockets[idx], res))
+            out[idx] = res if keep else None
+            if on_pocket:
+                on_pocket(idx, _time.time() - t0, False)
+    finally:
+        if writer is not None:
+            writer.close()
+    return out
 
 
 def gather_metadata(local: dict, group=None):

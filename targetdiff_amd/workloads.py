@@ -100,6 +100,19 @@ def synthetic_pocket(seed: int, n_atoms: int = 300, r_in: float = 4.0, r_out: fl
     return Pocket((pts + shift).astype(np.float32), featurize_protein(elem, aa, bb), f'synthetic_{seed}')
 
 
+def synthetic_test_set(n_pockets: int = 100, seed: int = 4000):
+    """Stand-in for the CrossDocked test split of BASELINE config 4 (the dataset is absent):
+    ``n_pockets`` synthetic pockets with 250-600 atoms (seeded), shell radius grown with the atom count so that the
+    density stays at the real pocket's ~0.03 atoms / A^3."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n_pockets):
+        n = int(rng.randint(250, 601))
+        r_out = float((4.0 ** 3 + n / (4.0 / 3.0 * np.pi * 0.027)) ** (1.0 / 3.0))
+        out.append(synthetic_pocket(seed + 1 + i, n, 4.0, r_out))
+    return out
+
+
 @dataclass
 class PackedBatch:
     """The ragged pack the sampler consumes (``Batch.from_data_list`` attributes the driver reads)."""
@@ -135,10 +148,35 @@ def pack_samples(pockets, samples_per_pocket, ligand_num_atoms) -> PackedBatch:
     return PackedBatch(torch.cat(pos), torch.cat(feat), torch.cat(bp), bl, ligand_num_atoms, g)
 
 
-def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, generator=None, spread: float = 1.0):
+class DevicePocket:
+    """One pocket resident on the device: the only host -> device copy the driver makes per pocket."""
+
+    def __init__(self, pocket: Pocket, device):
+        self.num_atoms = pocket.num_atoms
+        self.pos = torch.from_numpy(pocket.pos).to(device)
+        self.feat = torch.from_numpy(pocket.feat).to(device)
+        self.name = pocket.name
+
+
+def pack_samples_device(pocket: DevicePocket, n: int, ligand_num_atoms) -> PackedBatch:
+    """``Batch.from_data_list([data.clone() for _ in range(n)], follow_batch=FOLLOW_BATCH).to(device)``
+    (scripts/sample_diffusion.py:42) without the n host-side clones and the n-fold H2D copy: the replicas are laid out
+    on the device from the single resident pocket (same attribute values as :func:`pack_samples`)."""
+    dev = pocket.pos.device
+    sizes = [int(v) for v in ligand_num_atoms]
+    assert len(sizes) == n, (len(sizes), n)
+    ids = torch.arange(n, device=dev)
+    bp = ids.repeat_interleave(pocket.num_atoms)
+    bl = ids.repeat_interleave(torch.tensor(sizes, device=dev), output_size=sum(sizes))
+    return PackedBatch(pocket.pos.repeat(n, 1), pocket.feat.repeat(n, 1), bp, bl, sizes, n)
+
+
+def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, generator=None, spread: float = 1.0, draw=None,
+                types: bool = True):
     """scripts/sample_diffusion.py:60-70: positions = protein centroid + N(0, I); types = arg-max of Gumbel
     noise over uniform logits (models/molopt_score_model.py:160-166).  `spread` != 1 scales the noise (benchmarks use
-    it to emulate the geometry of a later, spread-out ligand; the reference's initial state is spread = 1)."""
+    it to emulate the geometry of a later, spread-out ligand; the reference's initial state is spread = 1).
+    ``draw(name, like)`` may supply the Gaussian ('noise') / uniform draws (parity tests)."""
     dev = batch.protein_pos.device
     B = batch.num_graphs
     if dev.type == 'cuda':
@@ -152,8 +190,16 @@ def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, gener
         cen = s / c
     center = cen[batch.ligand_element_batch]
     n = center.shape[0]
-    pos = center + spread * torch.randn(n, 3, generator=generator, device=dev)
-    u = torch.rand(n, num_classes, generator=generator, device=dev)
+    if draw is not None:
+        pos = center + spread * draw('noise', center)
+    else:
+        pos = center + spread * torch.randn(n, 3, generator=generator, device=dev)
+    if not types:               # pos_only: the driver takes the types from the data and draws no uniforms (:66-67)
+        return pos, None
+    if draw is not None:
+        u = draw('uniform', torch.empty(n, num_classes, dtype=torch.float32, device=dev))
+    else:
+        u = torch.rand(n, num_classes, generator=generator, device=dev)
     v = (-torch.log(-torch.log(u + 1e-30) + 1e-30)).argmax(dim=-1)
     return pos, v
 

@@ -1,0 +1,366 @@
+"""Parity of the HIP path on the BASELINE configurations the first fixture set did not reach (round-2 goldens, all from the
+real reference: oracle/make_golden_r2.py).  Needs an MI355X: ``-m gpu``.
+
+  * BASELINE config 1 in full: 1h36 x 4 samples, 100 steps -- free-running and teacher-forced;
+  * a complete 1000-step trajectory (crosses t < 10, ends with the noiseless t = 0 step);
+  * a C5-shaped forward (1000-atom pocket, > 704 nodes per graph, a 150-atom ligand) through td_model_forward and the session;
+  * sampling session == stateless forward over 300 steps, bit for bit;
+  * the batching driver ``sample_diffusion_ligand`` value by value, incl. its pos_only branch.
+
+Tolerances (fp32, stated once): atom types and neighbour indices bit-exact; free-running trajectories |dx| <= 5e-5 A;
+teacher-forced single steps |dx| <= 2e-5 A, |d log-prob| <= 2e-4.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pocket_1h36
+
+pytestmark = pytest.mark.gpu
+
+TOL_TRAJ = 5e-5
+TOL_STEP = 2e-5
+TOL_LOGP = 2e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no HIP device')
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def model(state_dict):
+    from oracle import weights
+    from targetdiff_amd.models import ScorePosNet3D
+    dev = _dev()
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    assert not m.load_state_dict(state_dict, strict=False).unexpected_keys
+    return m.to(dev).eval()
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def _free_run(model, batch, init_pos, init_v, steps, base, dev, **kw):
+    from oracle import draws
+    b = batch.to(dev)
+    return model.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                                  init_pos.to(dev), init_v.to(dev), b.ligand_element_batch, num_steps=steps,
+                                  center_pos_mode='protein', noise_source=draws.Source(base, dev), **kw)
+
+
+def _one_step(model, batch, pos_in, v_in, t, step, base, dev):
+    """One teacher-forced reverse step at timestep ``t`` from the reference's own state (un-centred positions), with the
+    draws the reference used at loop index ``step``; every call goes through the C ABI."""
+    from oracle import draws
+    b = batch.to(dev)
+    nat = model._native(dev)
+    B = b.num_graphs
+    pptr, lptr = nat.graph_ptr(b.protein_element_batch, B), nat.graph_ptr(b.ligand_element_batch, B)
+    ppos, lpos = b.protein_pos.clone(), pos_in.to(dev).clone().float()
+    off = nat.center_pos(ppos, pptr, lpos, lptr)
+    lv = v_in.to(dev).long()
+    preds = nat.model_forward(ppos, b.protein_atom_feature.float(), pptr, lpos, lv, lptr, want_final_h=False)
+    src = draws.Source(base, dev)
+    t32 = torch.full((B,), t, dtype=torch.int32, device=dev)
+    C = model.num_classes
+    log_v0 = torch.empty(lpos.shape[0], C, device=dev)
+    log_post = torch.empty_like(log_v0)
+    pos_next, v_next = nat.posterior_step(t32, lptr, lpos, lv, preds['pred_ligand_pos'], preds['pred_ligand_v'],
+                                          src.noise(step, lpos.shape), src.uniform(step, (lpos.shape[0], C)),
+                                          log_v0=log_v0, log_post=log_post)
+    return pos_next + off[b.ligand_element_batch], v_next, log_v0, log_post
+
+
+def _check_trajectory(r, g, steps, what):
+    pos = torch.stack(r['pos_traj']).numpy()
+    v = torch.stack(r['v_traj']).numpy()
+    same_v = (v == g['v_traj'].astype(np.int64)).all(axis=1)
+    dx = np.abs(pos.astype(np.float64) - g['pos_traj'].astype(np.float64)).reshape(steps, -1).max(axis=1)
+    first_flip = int(np.argmin(same_v)) if not same_v.all() else None
+    print(f'{what}: max |dx| over {steps} steps = {dx.max():.3e} (step {int(dx.argmax())}), last step {dx[-1]:.3e}, '
+          f'first type flip: {first_flip}')
+    assert first_flip is None, f'{what}: atom types differ from the reference at step {first_flip}'
+    assert dx.max() <= TOL_TRAJ, f'{what}: |dx| = {dx.max():.3e} at step {int(dx.argmax())}'
+    assert np.array_equal(r['v'].cpu().numpy(), g['v'].astype(np.int64))
+    assert _maxdiff(r['pos'], g['pos']) <= TOL_TRAJ
+    for j, s in enumerate(g['kept_steps']):
+        assert _maxdiff(r['v0_traj'][int(s)], g['v0_traj'][j]) <= TOL_LOGP, (what, 'v0', int(s))
+        # log-posteriors of impossible classes sit near log(1e-30): compare in probability space there
+        a, b = r['vt_traj'][int(s)].double().numpy(), g['vt_traj'][j].astype(np.float64)
+        live = b > -20.0
+        assert np.max(np.abs(a[live] - b[live])) <= TOL_LOGP, (what, 'vt', int(s))
+        assert np.max(np.abs(np.exp(a) - np.exp(b))) <= 1e-6, (what, 'vt prob', int(s))
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 1 in full
+def test_c1_full_100_steps_vs_reference(model):
+    """1h36 x 4 samples, num_steps = 100 (t = 999 .. 900): the reference's own run with the counter draws."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    g = load_golden('c1_full.npz')
+    pocket, _ = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 4, g['sizes'])
+    r = _free_run(model, batch, torch.from_numpy(g['init_ligand_pos']), torch.from_numpy(g['init_ligand_v'].astype(np.int64)),
+                  100, int(g['draws_base']), dev)
+    _check_trajectory(r, g, 100, 'C1 (session)')
+    r2 = _free_run(model, batch, torch.from_numpy(g['init_ligand_pos']), torch.from_numpy(g['init_ligand_v'].astype(np.int64)),
+                   100, int(g['draws_base']), dev, use_session=False)
+    _check_trajectory(r2, g, 100, 'C1 (stateless)')
+
+
+def test_c1_teacher_forced_steps_vs_reference(model):
+    """Single steps started from the reference's recorded state, so that a (legitimate) neighbour or type flip earlier in a
+    free-running trajectory could not mask a defect: 12 steps spread over t = 998 .. 900."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    g = load_golden('c1_full.npz')
+    pocket, _ = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 4, g['sizes'])
+    worst = 0.0
+    for s in (1, 2, 10, 20, 30, 40, 50, 60, 70, 80, 90, 99):
+        pos, v, _, _ = _one_step(model, batch, torch.from_numpy(g['pos_traj'][s - 1]),
+                                 torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s, int(g['draws_base']), dev)
+        assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s}'
+        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
+    print(f'C1 teacher-forced: max |dx| = {worst:.3e}')
+    assert worst <= TOL_STEP
+
+
+# ------------------------------------------------------------------------------------------ a complete 1000-step run
+def _small_batch():
+    from oracle.make_golden import small_batch
+    return small_batch()[0]
+
+
+def test_1000_step_trajectory_vs_reference(model):
+    """The whole reverse process on the 147-node batch: 1000 steps of the reference's own loop, t = 999 .. 0."""
+    dev = _dev()
+    g = load_golden('sample_small_1000.npz')
+    batch = _small_batch()
+    init = torch.from_numpy(g['init_ligand_pos']), torch.from_numpy(g['init_ligand_v'].astype(np.int64))
+    r = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev)
+    _check_trajectory(r, g, 1000, '1000 steps (session)')
+    r2 = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev, use_session=False)
+    _check_trajectory(r2, g, 1000, '1000 steps (stateless)')
+    # the two HIP paths agree with each other bit for bit over the whole run
+    assert torch.equal(torch.stack(r['pos_traj']), torch.stack(r2['pos_traj']))
+    assert torch.equal(torch.stack(r['v_traj']), torch.stack(r2['v_traj']))
+
+
+def test_late_steps_teacher_forced_vs_reference(model):
+    """t < 10: c0[t] -> 1, the model output is no longer damped by the posterior; and the noiseless t = 0 step."""
+    dev = _dev()
+    g = load_golden('sample_small_1000.npz')
+    batch = _small_batch()
+    kept = {int(s): j for j, s in enumerate(g['kept_steps'])}
+    worst = 0.0
+    for s in (500, 900, 980, 990, 991, 992, 993, 994, 995, 996, 997, 998, 999):
+        pos, v, log_v0, log_post = _one_step(model, batch, torch.from_numpy(g['pos_traj'][s - 1]),
+                                             torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s,
+                                             int(g['draws_base']), dev)
+        assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s} (t = {999 - s})'
+        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
+        if s in kept:
+            assert _maxdiff(log_v0, g['v0_traj'][kept[s]]) <= TOL_LOGP
+    print(f'late steps teacher-forced: max |dx| = {worst:.3e}')
+    assert worst <= TOL_STEP
+
+
+# ------------------------------------------------------------------------------------------ C5 shape
+def test_forward_c5_shape_vs_reference_golden(model):
+    """1000-atom pocket x 2 with ligands of 150 and 30 atoms: graphs of 1150 / 1030 nodes (multi-pass k-NN search) and
+    more than 128 ligand atoms in one graph (the session's extra merge passes), through both entry points."""
+    from oracle.make_golden_r2 import C5_POCKET, C5_SIZES
+    from targetdiff_amd import capi, workloads
+    dev = _dev()
+    g = load_golden('forward_c5.npz')
+    pocket = workloads.synthetic_pocket(**C5_POCKET)
+    b = workloads.pack_samples(pocket, 2, C5_SIZES).to(dev)
+    nat = model._native(dev)
+    ppos = torch.from_numpy(g['protein_pos_centred']).to(dev)
+    lpos = torch.from_numpy(g['ligand_pos']).to(dev)
+    lv = torch.from_numpy(g['ligand_v'].astype(np.int64)).to(dev)
+    pptr, lptr = nat.graph_ptr(b.protein_element_batch, 2), nat.graph_ptr(b.ligand_element_batch, 2)
+    pv = b.protein_atom_feature.float()
+    preds = nat.model_forward(ppos, pv, pptr, lpos, lv, lptr, max_graph_nodes=1150)
+    assert _maxdiff(preds['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_STEP
+    assert _maxdiff(preds['pred_ligand_v'], g['pred_ligand_v']) <= 2e-4
+    assert _maxdiff(preds['final_ligand_h'], g['final_ligand_h']) <= 2e-4
+    assert _maxdiff(preds['final_h'][::16], g['final_h_sample']) <= 2e-4
+    # neighbour table on the composed coordinates (protein rows first inside each graph)
+    x = torch.cat([ppos[:1000], lpos[:150], ppos[1000:], lpos[150:]])
+    node_ptr = torch.tensor([0, 1150, 2180], dtype=torch.int32, device=dev)
+    nbr = nat.knn(x.contiguous(), node_ptr, max_graph_nodes=1150).cpu().numpy()
+    assert np.array_equal(nbr, g['nbr'].astype(np.int32))
+    # unknown size hint (0) and the session take other kernel instantiations; all agree
+    preds0 = nat.model_forward(ppos, pv, pptr, lpos, lv, lptr, max_graph_nodes=0)
+    assert torch.equal(preds0['pred_ligand_pos'], preds['pred_ligand_pos'])
+    sess = capi.NativeSession(nat, ppos, pv, pptr, lptr, lpos.shape[0], 1150)
+    ps = sess.forward(lpos, lv)
+    assert torch.equal(ps['pred_ligand_pos'], preds['pred_ligand_pos'])
+    assert torch.equal(ps['pred_ligand_v'], preds['pred_ligand_v'])
+    assert torch.equal(ps['final_ligand_h'], preds['final_ligand_h'])
+
+
+# ------------------------------------------------------------------------------------------ session == stateless, long
+def test_session_equals_stateless_300_steps(model):
+    """1h36 x 12 samples, 300 steps with injected draws: the static-protein session (merged k-NN, cached gate / layer-0
+    rows, receptive-field pruning) and the stateless forward produce the same bits at every step."""
+    from oracle import draws
+    from targetdiff_amd import workloads
+    dev = _dev()
+    pocket, sizes = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 12, sizes[:12])
+    g = torch.Generator().manual_seed(3)
+    lpos, lv = workloads.init_ligand(batch, generator=g)
+    out = []
+    for use_session in (True, False):
+        r = _free_run(model, batch, lpos, lv, 300, 4100, dev, use_session=use_session)
+        out.append(r)
+    for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
+        assert torch.equal(torch.stack(out[0][key]), torch.stack(out[1][key])), key
+    spread = float(out[0]['pos'].std(dim=0).mean())
+    print(f'session == stateless over 300 steps; final ligand cloud std {spread:.2f} A')
+
+
+# ------------------------------------------------------------------------------------------ the driver, value by value
+def _unpack(g, prefix, axis):
+    cat, n = g[prefix + '_cat'], g[prefix + '_n']
+    cuts = np.cumsum(n)[:-1]
+    return np.split(cat, cuts, axis=axis)
+
+
+def test_driver_values_vs_reference(model):
+    """scripts/sample_diffusion.py:31-116 run by the reference itself (5 samples in batches of 2, 4 steps, prior sizes)
+    against targetdiff_amd.sampling.sample_diffusion_ligand under the same draws: every element of the 7-tuple."""
+    from oracle import draws
+    from oracle.make_golden_r2 import DRIVER_POCKET
+    from targetdiff_amd import sampling, workloads
+    dev = _dev()
+    g = load_golden('driver_small.npz')
+    steps = int(g['steps'])
+    pocket = workloads.synthetic_pocket(**DRIVER_POCKET)
+    src = draws.Source(3100, dev)
+    # the reference's n-th randn_like / rand_like call: per sample batch one initial draw, then one per step
+    noise_source = lambda bi, st, name, like: src(bi * (steps + 1) + st + 1, name, like)
+    res = sampling.sample_diffusion_ligand(model, pocket, 5, batch_size=2, device=dev, num_steps=steps,
+                                           center_pos_mode='protein', ligand_num_atoms=[int(v) for v in g['pos_n']],
+                                           noise_source=noise_source)
+    pos, v, pos_traj, v_traj, v0_traj, vt_traj, times = res
+    assert len(times) == 3 and len(pos) == 5
+    for k, (a, b) in enumerate(zip(pos, _unpack(g, 'pos', 0))):
+        assert a.dtype == np.float64 and a.shape == b.shape
+        assert np.max(np.abs(a - b)) <= TOL_TRAJ, ('pos', k)
+    for a, b in zip(v, _unpack(g, 'v', 0)):
+        assert np.array_equal(a, b.astype(np.int64))
+    for a, b in zip(pos_traj, _unpack(g, 'pos_traj', 1)):
+        assert a.dtype == np.float64 and a.shape == b.shape and np.max(np.abs(a - b)) <= TOL_TRAJ
+    for a, b in zip(v_traj, _unpack(g, 'v_traj', 1)):
+        assert np.array_equal(a, b.astype(np.int64))
+    for a, b in zip(v0_traj, _unpack(g, 'v0_traj', 1)):
+        assert a.shape == b.shape and np.max(np.abs(a - b)) <= TOL_LOGP
+    for a, b in zip(vt_traj, _unpack(g, 'vt_traj', 1)):
+        assert np.max(np.abs(np.exp(a.astype(np.float64)) - np.exp(b.astype(np.float64)))) <= 1e-6
+
+
+def test_driver_pos_only_vs_reference(model):
+    """pos_only=True / sample_num_atoms='ref' (:54-56, :66-67, :108-112): types frozen, v0 / vt lists stay empty."""
+    from oracle import draws
+    from oracle.make_golden_r2 import driver_data
+    from targetdiff_amd import sampling
+    dev = _dev()
+    g = load_golden('driver_small.npz')
+    d = driver_data(ref_ligand_atoms=9)
+    data = types.SimpleNamespace(protein_pos=d.protein_pos, protein_atom_feature=d.protein_atom_feature,
+                                 ligand_element=d.ligand_element, ligand_atom_feature_full=d.ligand_atom_feature_full)
+    src = draws.Source(3200, dev)
+    calls = {'uniform': 0}
+
+    def noise_source(bi, st, name, like):
+        if name == 'uniform':           # the reference draws no uniforms on this branch: neither may we consume any
+            calls['uniform'] += 1
+        return src(bi * 4 + st + 1, name, like)
+    res = sampling.sample_diffusion_ligand(model, data, 3, batch_size=2, device=dev, num_steps=3, pos_only=True,
+                                           center_pos_mode='protein', sample_num_atoms='ref', noise_source=noise_source)
+    pos, v, pos_traj, v_traj, v0_traj, vt_traj, _ = res
+    assert v0_traj == [] and vt_traj == []
+    for a, b in zip(pos, _unpack(g, 'po_pos', 0)):
+        assert np.max(np.abs(a - b)) <= TOL_TRAJ
+    for a, b in zip(v, _unpack(g, 'po_v', 0)):
+        assert np.array_equal(a, b.astype(np.int64))
+    for a, b in zip(pos_traj, _unpack(g, 'po_pos_traj', 1)):
+        assert np.max(np.abs(a - b)) <= TOL_TRAJ
+    for a, b in zip(v_traj, _unpack(g, 'po_v_traj', 1)):
+        assert np.array_equal(a, b.astype(np.int64))
+
+
+# ------------------------------------------------------------------------------------------ API behaviour
+def test_center_pos_mode_none_raises_like_the_reference(model):
+    dev = _dev()
+    batch = _small_batch().to(dev)
+    lpos = torch.zeros(22, 3, device=dev)
+    lv = torch.zeros(22, dtype=torch.long, device=dev)
+    with pytest.raises(NotImplementedError):
+        model.sample_diffusion(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch, lpos, lv,
+                               batch.ligand_element_batch, num_steps=1)
+
+
+def test_unsorted_batch_and_bad_types_are_refused(model):
+    dev = _dev()
+    batch = _small_batch().to(dev)
+    lpos = torch.zeros(22, 3, device=dev)
+    lv = torch.zeros(22, dtype=torch.long, device=dev)
+    args = (batch.protein_pos, batch.protein_atom_feature.float())
+    with pytest.raises(ValueError, match='sorted'):
+        model(*args, batch.protein_element_batch.flip(0), lpos, lv, batch.ligand_element_batch)
+    with pytest.raises(ValueError, match='ligand_v'):
+        model(*args, batch.protein_element_batch, lpos, lv + 13, batch.ligand_element_batch)
+
+
+def test_model_copy_after_first_use(model):
+    """copy.deepcopy / pickle after a forward has created the native handle; the copy packs its own weights."""
+    import copy
+    dev = _dev()
+    batch = _small_batch().to(dev)
+    g = torch.Generator().manual_seed(1)
+    lpos = torch.randn(22, 3, generator=g).to(dev)
+    lv = torch.randint(0, 13, (22,), generator=g).to(dev)
+    call = lambda m: m(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch, lpos, lv,
+                       batch.ligand_element_batch)['pred_ligand_pos']
+    ref = call(model)
+    m2 = copy.deepcopy(model)
+    assert m2._native_model is None and m2.refine_net._owner() is m2
+    assert torch.equal(call(m2), ref)
+    with torch.no_grad():
+        m2.v_inference[0].weight.mul_(2.0)            # diverge the copy: the original must not see it
+        m2.refine_net.base_block[0].x2h_layers[0].hq_func.net[0].weight.mul_(1.5)
+    assert not torch.equal(call(m2), ref)
+    assert torch.equal(call(model), ref)
+
+
+def test_non_current_device_is_honoured(model):
+    """--device cuda:1 with the current device left at 0: needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one visible GPU')
+    import copy
+    dev1 = torch.device('cuda:1')
+    torch.cuda.set_device(0)
+    m1 = copy.deepcopy(model).to(dev1)
+    batch = _small_batch()
+    g = torch.Generator().manual_seed(1)
+    lpos, lv = torch.randn(22, 3, generator=g), torch.randint(0, 13, (22,), generator=g)
+    outs = []
+    for m, d in ((model, _dev()), (m1, dev1)):
+        b = batch.to(d)
+        r = m.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(d), lv.to(d),
+                               b.ligand_element_batch, num_steps=2, center_pos_mode='protein',
+                               noise_source=lambda s, n, like: torch.full_like(like, 0.25))
+        outs.append(r['pos'].cpu())
+    assert torch.equal(outs[0], outs[1])

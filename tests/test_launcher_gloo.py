@@ -1,0 +1,57 @@
+"""The multi-GPU launch path on CPU: targetdiff_amd.launch.spawn_ranks starts 2 ranks (the way `bench.py --gpus N` and
+`tools/batch_sample.py --gpus N` start N), each rank runs tools/batch_sample.py's main with the gloo backend and a
+stand-in model, writes result_{i}.pt files in the reference layout and joins the metadata gather."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from targetdiff_amd import launch, results
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, extra=()):
+    argv = [sys.executable, os.path.join(HERE, '_gloo_batch_worker.py'), '--pockets', 'synthetic:5', '--result_path',
+            str(tmp_path), '--num_samples', '3', '--num_steps', '2', '--batch_size', '2', '--ligand_atoms', '4',
+            '--device', 'cpu', *extra]
+    rc = launch.spawn_ranks(argv, 2, timeout=300)
+    assert rc == 0
+    with open(os.path.join(str(tmp_path), 'summary.json')) as f:
+        return json.load(f)
+
+
+def test_two_ranks_write_reference_layout_results_and_resume(tmp_path):
+    s = _run(tmp_path)
+    assert s['world_size'] == 2 and s['pockets_sampled'] == 5 and s['ligands'] == 15
+    per_rank = {m['rank']: sorted(p['pocket'] for p in m['pockets']) for m in s['per_rank']}
+    assert per_rank == {0: [0, 2, 4], 1: [1, 3]}                        # scripts/batch_sample_diffusion.sh:15-17
+    for i in range(5):
+        r = torch.load(results.result_file(str(tmp_path), i), weights_only=False)
+        # the keys scripts/evaluate_diffusion.py:70-76 reads
+        assert set(r) == {'data', 'pred_ligand_pos', 'pred_ligand_v', 'pred_ligand_pos_traj', 'pred_ligand_v_traj', 'time'}
+        assert len(r['pred_ligand_pos']) == 3 and r['pred_ligand_pos'][0].shape == (4, 3)
+        assert r['pred_ligand_pos'][0].dtype == np.float64
+        assert r['pred_ligand_pos_traj'][0].shape == (2, 4, 3) and r['pred_ligand_v_traj'][0].shape == (2, 4)
+        assert len(r['time']) == 2                                       # two sample batches (2 + 1)
+    assert not [f for f in os.listdir(str(tmp_path)) if '.tmp.' in f]
+    # a re-run finds every file and samples nothing; after removing one file only that pocket is sampled again
+    s2 = _run(tmp_path)
+    assert s2['pockets_sampled'] == 0 and s2['pockets_skipped'] == 5
+    os.remove(results.result_file(str(tmp_path), 3))
+    s3 = _run(tmp_path)
+    assert s3['pockets_sampled'] == 1 and s3['pockets_skipped'] == 4
+    # START_IDX (scripts/batch_sample_diffusion.sh:13,15)
+    os.remove(results.result_file(str(tmp_path), 0))
+    s4 = _run(tmp_path, ('--start_idx', '2'))
+    assert s4['pockets_sampled'] == 0 and s4['pockets_skipped'] == 3
+    assert not os.path.exists(results.result_file(str(tmp_path), 0))
+
+
+def test_rank_environment_matches_torchrun():
+    env = launch.rank_env(3, 8, 29511, base={})
+    assert env['RANK'] == '3' and env['LOCAL_RANK'] == '3' and env['WORLD_SIZE'] == '8'
+    assert env['MASTER_ADDR'] == '127.0.0.1' and env['MASTER_PORT'] == '29511'
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

@@ -92,3 +92,29 @@ def test_egnn_fresh_inputs(ref_model):
         want = net(h, x, mask, batch)
     got = R.egnn_forward(esd, h, x, mask, batch, num_layers=4)
     assert _maxdiff(got['x'], want['x']) < 2e-5 and _maxdiff(got['h'], want['h']) < 5e-5
+
+
+def test_mirror_loads_the_full_reference_state_dict_strict():
+    """All 384 entries of the real reference model's state_dict (learnable tensors, the 15 frozen schedule Parameters,
+    Lt_history / Lt_count, the unused init_h_emb_layer) load into the mirror with strict=True, as
+    scripts/sample_diffusion.py:163 loads a checkpoint -- and the schedule constants the mirror builds itself are the
+    reference's, bit for bit."""
+    from oracle import reference_loader, shims, weights
+    from targetdiff_amd.models import ScorePosNet3D
+    ref = reference_loader.load()
+    torch.manual_seed(123)
+    ref_model = ref.ScorePosNet3D(shims.EasyDict(weights.DEFAULT_MODEL_CONFIG), weights.PROTEIN_FEATURE_DIM,
+                                  weights.LIGAND_FEATURE_DIM)
+    ref_sd = ref_model.state_dict()
+    assert len(ref_sd) == 384
+    mirror = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), weights.PROTEIN_FEATURE_DIM, weights.LIGAND_FEATURE_DIM)
+    own = {k: v.clone() for k, v in mirror.state_dict().items()}
+    assert list(own) == list(ref_sd)                                    # same keys, same order
+    frozen = [k for k, p in ref_model.named_parameters() if not p.requires_grad]
+    assert len(frozen) == 15
+    for k in frozen:
+        assert torch.equal(own[k], ref_sd[k]), k
+    res = mirror.load_state_dict(ref_sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in mirror.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
