@@ -200,10 +200,22 @@ def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows):
     return float(f)
 
 
-def build_model(dev):
-    model = ScorePosNet3D(MODEL_CONFIG, workloads.PROTEIN_FEATURE_DIM, workloads.NUM_LIGAND_CLASSES)
+def build_model(dev, args=None):
+    cfg = dict(MODEL_CONFIG)
+    if args is not None:
+        cfg.update(knn=args.knn, cutoff_mode=args.cutoff_mode, r=args.radius, max_num_neighbors=args.cap)
+    model = ScorePosNet3D(cfg, workloads.PROTEIN_FEATURE_DIM, workloads.NUM_LIGAND_CLASSES)
     model.load_state_dict(seeded_state_dict(model), strict=False)
-    return model.to(dev).eval()
+    model = model.to(dev).eval()
+    if args is not None and args.fp32_node_gemms:
+        model._native(dev).set_option('node_proj_split', 0)
+    return model
+
+
+def graph_desc(args):
+    if args.cutoff_mode == 'radius':
+        return f'radius {args.radius} A, fan-out cap {args.cap}'
+    return f'{args.cutoff_mode} k = {args.knn}'
 
 
 def full_run(model, pocket, sizes, dev, steps=1000):
@@ -317,6 +329,11 @@ def main():
     ap.add_argument('--initial-state', action='store_true',
                     help='after the timed region, also time 10 steps from the sampler\'s initial state N(0, I)')
     ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
+    ap.add_argument('--knn', type=int, default=32, help='fan-in of the k-NN / hybrid graph (C5 sweep: 16, 32, 48, 64)')
+    ap.add_argument('--cutoff-mode', default='knn', choices=['knn', 'hybrid', 'radius'])
+    ap.add_argument('--radius', type=float, default=6.0, help='cut-off (A) of --cutoff-mode radius')
+    ap.add_argument('--cap', type=int, default=32, help='fan-out cap of --cutoff-mode radius (C5 sweep)')
+    ap.add_argument('--fp32-node-gemms', action='store_true', help='node-side GEMMs on fp32 MFMA instead of the exact bf16 x 3 split')
     args = ap.parse_args()
     # `--gpus N` without a launcher: become the launcher (N ranks of this same command line), exit with their status
     launch.self_spawn_if_needed(args.gpus)
@@ -339,7 +356,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    model = build_model(dev)
+    model = build_model(dev, args)
+    default_graph = args.cutoff_mode == 'knn' and args.knn == 32
     if args.workload == 'c4':
         out = run_c4(args, model, dev, rank, world, fence)
         if rank == 0:
@@ -396,18 +414,26 @@ def main():
         rows_per_launch = (n_dirty + (n_fwd or 0) + full_layers * n_all + sum(tail)) / n_layers
         session_rows = {'nodes': n_all, 'layer0_rows': n_dirty, 'layer1_rows': n_fwd, 'receptive_field_levels': levels}
 
+    # general graphs: a dst row is ceil(fan-in / 32) chunks of 32 slots; the first layer and the head-shaped products run per
+    # chunk, the 128 x 128 output product of the value pass once per row (the key pass rebuilds U_i per chunk)
+    fan_in = args.cap if args.cutoff_mode == 'radius' else args.knn
+    cpn = (fan_in + 31) // 32
+    flop_key = cpn * KEY_PASS_FLOP_EXECUTED
+    flop_val = cpn * (KEY_PASS_FLOP_EXECUTED - 2 * 128 * 128) + 2 * 128 * 128
+
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]
         if not p['launches']:
             return None
         ms = p['ms'] / p['launches']
-        achieved = KEY_PASS_FLOP_EXECUTED * rows_per_launch / (ms * 1e-3) / 1e12
+        per_row = KEY_PASS_FLOP_EXECUTED if default_graph else (flop_key if cls == 'x2h_k' else flop_val)
+        achieved = per_row * rows_per_launch / (ms * 1e-3) / 1e12
         # HBM traffic of the same kernel: PMC counters cannot be read in-process, so this is the figure of the COMMITTED
         # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- static, see traffic_source
         traffic, source = None, None
         tpath = os.path.join(ROOT, 'profiles', traffic_file)
-        if os.path.exists(tpath) and args.workload == 'c2' and sampler.session is not None:
+        if os.path.exists(tpath) and args.workload == 'c2' and sampler.session is not None and default_graph:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
@@ -422,12 +448,15 @@ def main():
                 'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
                 'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}
 
-    roofline = pass_roofline('x2h_v', 'edge_value16_kernel (x2h value pass)', 'traffic_x2h_value.json')
+    vk, kk = ('edge_value16_kernel', 'edge_key16_kernel<false, 16, 0>') if default_graph else ('edge_value16_ragged_kernel', 'edge_logits16_kernel<16, 0>')
+    roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
-        roofline['key_pass'] = pass_roofline('x2h_k', 'edge_key16_kernel<false, 16, 0> (x2h key pass)', 'traffic_x2h_key.json')
+        roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
     # whole step: FLOPs the launched kernels execute (from the row lists) against the fp32 peak, next to SURVEY 8d's algorithmic
     # figures (which count work the session provably does not need to do: fractions above 1 there only say the eliminations are real)
-    f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows)
+    f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows if default_graph else None)
+    if not default_graph:       # per-chunk work scales with the chunks per row (uniform for k-NN / radius; hybrid: protein rows)
+        f_exec *= cpn
     whole_step = {'executed_flop': f_exec, 'executed_tflops': f_exec / sec_per_step / 1e12,
                   'executed_frac_of_fp32_peak': f_exec / sec_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                   'f_alg_flop': F_ALG_PER_NODE * n_nodes, 'f_alg_tflops': F_ALG_PER_NODE * n_nodes / sec_per_step / 1e12,
@@ -444,7 +473,9 @@ def main():
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets')
         + '; k-NN rule (d2 association, ties -> lower index) is the project\'s: torch_cluster is not in the reference tree, '
           'parity-unpinned upstream)',
-        'config': {'workload': desc, 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes, 'edges_per_gpu': 32 * n_nodes, 'graphs_per_gpu': graphs,
+        'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
+                   'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
+                   'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
     }
@@ -474,7 +505,7 @@ def main():
                     print(f'  {k:10s} {v["ms"] / args.steps:9.3f} ms/step  ({v["launches"] // args.steps} launches/step)',
                           file=sys.stderr)
         # a complete run the driver's own clock can witness: outside the timed region, the 20-step line above is unchanged
-        if world == 1 and args.workload == 'c2' and not args.no_full_run and not args.no_session:
+        if world == 1 and args.workload == 'c2' and not args.no_full_run and not args.no_session and default_graph:
             out['full_run'] = full_run(model, pockets[0], sizes, dev)
         if world == 1 and not args.no_cpu_baseline:
             if args.cpu_full:

@@ -7,8 +7,10 @@
  * cites it.  All pointers named d_* are DEVICE pointers (HIP), caller-owned; outputs are
  * caller-allocated; `stream` is a hipStream_t passed as void*.  Every function returns TD_OK (0) or a
  * negative TD_E* code; td_last_error() gives the message for the calling thread.  No exceptions cross
- * the ABI, no hidden global state besides the per-thread error string; a td_model is immutable after
- * creation and may be shared by streams/threads, a workspace must not be shared by concurrent calls.
+ * the ABI.  Process-wide state: the per-thread error string, the td_profile_* timers (measurement only) and a per-kernel,
+ * per-device "dynamic LDS size configured" bit; every switch lives in the td_model handle (td_model_set_option), nothing is
+ * read from the environment.  A td_model may be shared by streams/threads of its device; a workspace or a session must
+ * not be shared by concurrent calls.
  *
  * Packed-graph convention (what compose_context produces, models/common.py:120-137): the batch holds B
  * graphs stored contiguously; inside a graph the protein atoms come first, then the ligand atoms.
@@ -29,25 +31,41 @@ extern "C" {
 #define TD_ENOMEM (-2)      /* workspace too small or allocation failure */
 #define TD_EHIP (-3)        /* HIP runtime error (message in td_last_error) */
 
-#define TD_ABI_VERSION 1
+#define TD_ABI_VERSION 2
 
 typedef struct td_model td_model;
 
 /* Model hyper-parameters (configs/training.yml:9-42, read from the checkpoint's config at
- * scripts/sample_diffusion.py:158-162).  The HIP kernels are specialised for the live configuration
- * (hidden 128, 16 heads, k = 32, 20 Gaussians, 4 edge types, uni_o2, knn graph, global edge gate);
- * td_model_create returns TD_EINVAL for anything else. */
+ * scripts/sample_diffusion.py:158-162).  The HIP kernels are specialised for the live architecture (hidden 128, 16 heads,
+ * 20 Gaussians, 4 edge types, uni_o2, global edge gate); td_model_create returns TD_EINVAL for anything else.  The graph
+ * construction of models/uni_transformer.py:276-286 is a run-time choice:
+ *   TD_CUTOFF_KNN     knn_graph(x, k = knn), any 1 <= knn <= 64; knn = 32 (the live configuration) takes the fast path in
+ *                     which one dst row is exactly one 32-row MFMA tile and the sampling session caches the static protein;
+ *   TD_CUTOFF_HYBRID  batch_hybrid_edge_connection(add_p_index=True) (models/common.py:165-212): a ligand atom sees every
+ *                     other ligand atom of its graph and its knn nearest protein atoms, a protein atom its knn nearest nodes;
+ *   TD_CUTOFF_RADIUS  radius graph with a fan-out cap: the first max_num_neighbors nodes j != i of the graph (index order)
+ *                     with |x_i - x_j|^2 < radius^2.  The reference's own radius mode is dead code (:278 reads an attribute
+ *                     that is never assigned); the rule is this project's (oracle/shims.py).
+ * Rows wider or narrower than 32 run as chunks of 32 slots through ragged (CSR-segment) variants of the edge kernels. */
+#define TD_CUTOFF_KNN 0
+#define TD_CUTOFF_HYBRID 1
+#define TD_CUTOFF_RADIUS 2
+#define TD_MAX_FANIN 64         /* largest knn / max_num_neighbors */
+
 typedef struct td_config {
     int32_t hidden_dim;          /* 128 */
     int32_t n_heads;             /* 16 */
-    int32_t knn;                 /* 32 */
+    int32_t knn;                 /* 32 (1 .. 64) */
     int32_t num_layers;          /* 9 (any >= 1) */
     int32_t num_r_gaussian;      /* 20 */
     int32_t edge_feat_dim;       /* 4 */
     int32_t protein_feat_dim;    /* 27 (<= 32) */
     int32_t ligand_num_classes;  /* 13 (<= 16) */
     int32_t num_timesteps;       /* 1000 */
-    int32_t reserved[7];
+    int32_t cutoff_mode;         /* TD_CUTOFF_* (0 = knn) */
+    float radius;                /* TD_CUTOFF_RADIUS: cut-off in Angstrom */
+    int32_t max_num_neighbors;   /* TD_CUTOFF_RADIUS: fan-out cap (1 .. 64) */
+    int32_t reserved[4];
 } td_config;
 
 /* ---- library ------------------------------------------------------------------------------------ */
@@ -66,6 +84,16 @@ int td_model_create(const td_config *cfg, const float *host_weights, size_t num_
                     const float *host_schedules, size_t num_schedule_floats, td_model **out);
 void td_model_destroy(td_model *m);
 size_t td_model_num_weights(const td_config *cfg);      /* expected length of the flat blob */
+/* Per-model switches (stored in the handle: per device, nothing is read from the environment).  Set them before the model
+ * is used; not to be changed while a call is in flight.
+ *   "node_proj_split"        1 (default): the node-side 128 x 128 GEMMs run on v_mfma_f32_32x32x16_bf16 with both operands
+ *                            split exactly into three bf16 pieces (an fp32 significand = 3 x 8 bits; 6 of the 9 piece products,
+ *                            fp32 accumulation): fp32-equivalent results, 0 = plain fp32 MFMA
+ *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
+ *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with
+ *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only */
+int td_model_set_option(td_model *m, const char *name, int32_t value);
+int td_model_get_option(const td_model *m, const char *name, int32_t *value);
 
 /* ---- workspace ---------------------------------------------------------------------------------- */
 /* Bytes of scratch td_refine_forward / td_model_forward need for a batch of N nodes (N_l of them ligand)
@@ -79,15 +107,24 @@ int td_graph_ptr(const int64_t *d_batch, int64_t N, int64_t B, int32_t *d_ptr, v
 /* ---- kNN graph (replaces: torch_geometric.nn.knn_graph(x, k, batch, flow='source_to_target') at
  *      models/uni_transformer.py:280).  out_nbr [N, k] int32: row i = the k nearest same-graph nodes of
  *      node i, ascending by (d2, index), d2 = (dx*dx + dy*dy) + dz*dz in fp32 without FMA contraction;
- *      -1 padded when the graph has fewer than k+1 nodes.  `max_graph_nodes` is a performance hint
+ *      -1 padded when the graph has fewer than k+1 nodes.  1 <= k <= 64.  `max_graph_nodes` is a performance hint
  *      (0 = unknown). */
 int td_knn(const float *d_x /*[N,3]*/, const int32_t *d_node_ptr /*[B+1]*/, int64_t N, int64_t B, int32_t k,
            int32_t max_graph_nodes, int32_t *d_out_nbr, void *stream);
 
+/* ---- the model's graph on a composed batch (replaces: UniTransformerO2TwoUpdateGeneral._connect_edge,
+ *      models/uni_transformer.py:276-286, for the model's cutoff_mode).  d_out_nbr [N, width] int32, -1 padded: the
+ *      in-neighbours (edge sources) of node i.  kNN: ascending (d2, index).  hybrid ligand rows: the other ligand atoms
+ *      (ascending index), then the knn nearest protein atoms (ascending (d2, index)).  radius: ascending index.  Entries
+ *      beyond `width` are dropped.  Needs compose_context order (protein rows first in every graph). */
+int td_graph_build(const td_model *m, const float *d_x, const uint8_t *d_mask_ligand, const int32_t *d_node_ptr, int64_t N,
+                   int64_t B, int32_t max_graph_nodes, int32_t *d_out_nbr, int32_t width, void *stream);
+
 /* ---- backbone (replaces: refine_net(h, x, mask_ligand, batch, return_all=False, fix_x) ->
  *      {'x','h'}, UniTransformerO2TwoUpdateGeneral.forward, models/uni_transformer.py:301-328).
  *      d_h [N,128] f32, d_x [N,3] f32, d_mask_ligand [N] uint8, d_node_ptr [B+1] int32.
- *      d_out_nbr ([N,k] int32) and d_out_ew ([N,k] f32, the global edge gate of :312-316) may be NULL. */
+ *      d_out_nbr ([N,32] int32) and d_out_ew ([N,32] f32, the global edge gate of :312-316) may be NULL; they exist for
+ *      the default k = 32 kNN graph only (other graphs: td_graph_build). */
 int td_refine_forward(const td_model *m, const float *d_h, const float *d_x, const uint8_t *d_mask_ligand,
                       const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t fix_x, int32_t max_graph_nodes,
                       float *d_out_h, float *d_out_x, int32_t *d_out_nbr, float *d_out_ew,
@@ -200,10 +237,6 @@ int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
  *      projections of the 340-wide first Linear (h_i part incl. bias), d_q [N,128] = MLP_q(h). */
 int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N, float *d_P,
                         float *d_q, void *stream);
-
-/* ---- test hook: while d_buf != NULL, x2h key-pass launches run an instrumented variant in which lane 0 of every wave
- *      of workgroup 0 stores clock64() stamps: d_buf[(wave * nodes + node_no) * 8 + stamp] (int64). */
-int td_debug_edge_timing(int64_t *d_buf, int32_t nodes);
 
 /* ---- test hook: one wave evaluates the cross-lane reduction helpers on 64 inputs; out[6][64] =
  *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */

@@ -10,6 +10,7 @@ Long trajectories and the other BASELINE.json configurations the first fixture s
                       ends with the noiseless t = 0 step.
   forward_c5          one denoiser forward on a C5-shaped pack: a 1000-atom synthetic pocket x 2 samples, one ligand of
                       150 atoms (graphs of > 704 nodes: multi-pass kNN; > 128 ligand atoms per graph).
+  forward_c3          one forward on the 32 synthetic pockets of BASELINE config 3, one sample each.
   driver_small        the batching driver scripts/sample_diffusion.py:31-116 itself (`sample_diffusion_ligand`), run through
                       the Batch shim on a small pocket: 5 samples in batches of 2, 4 steps, prior sizes; and its pos_only
                       / sample_num_atoms='ref' branch.
@@ -125,6 +126,25 @@ def gen_forward_c5(ref, model):
     print('forward_c5: N =', N)
 
 
+def c3_pockets():
+    """The 32 synthetic pockets of BASELINE config 3 (same seeds as bench.py --workload c3, rank 0)."""
+    return [workloads.synthetic_pocket(1000 + p, 300) for p in range(32)]
+
+
+def gen_forward_c3(ref, model):
+    """One reference forward on the C3 pockets, one sample each (32 graphs, 25 ligand atoms): graphs are independent, so the
+    GPU test embeds these 32 ligand states into the full 32 x 100 pack and must reproduce the reference rows there."""
+    pockets = c3_pockets()
+    b = workloads.pack_samples(pockets, 1, [25] * 32)
+    g = torch.Generator().manual_seed(SEED + 14)
+    lpos, lv = workloads.init_ligand(b, generator=g, spread=2.0)
+    ppos, lpos_c, preds, inter = ref_forward_with_intermediates(ref, model, b, lpos, lv)
+    _save(os.path.join(GOLDEN_DIR, 'forward_c3.npz'), ligand_pos_uncentred=lpos.numpy(), ligand_pos=lpos_c.numpy(),
+          ligand_v=lv.numpy().astype(np.int8), pred_ligand_pos=preds['pred_ligand_pos'].numpy(),
+          pred_ligand_v=preds['pred_ligand_v'].numpy(), final_ligand_h=preds['final_ligand_h'].numpy())
+    print('forward_c3: N =', ppos.shape[0] + lpos_c.shape[0])
+
+
 DRIVER_POCKET = dict(seed=301, n_atoms=70, r_in=3.0, r_out=9.0)
 
 
@@ -238,7 +258,7 @@ def gen_graph_variants(ref, model):
     gen_graph_variant(ref, 'forward_1h36x2_hybrid', dict(cutoff_mode='hybrid'), b2, lpos2, lv2, False)
 
 
-GENERATORS = {'c1_full': gen_c1_full, 'sample_small_1000': gen_sample_small_1000, 'forward_c5': gen_forward_c5,
+GENERATORS = {'forward_c3': gen_forward_c3, 'c1_full': gen_c1_full, 'sample_small_1000': gen_sample_small_1000, 'forward_c5': gen_forward_c5,
               'driver_small': gen_driver_small, 'graph_variants': gen_graph_variants}
 
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .shims import knn_neighbours
+from .shims import hybrid_neighbours, knn_neighbours, radius_neighbours
 from .weights import DEFAULT_MODEL_CONFIG
 
 
@@ -134,13 +134,22 @@ def refine_forward(sd, cfg, h, x, mask_ligand, batch, fix_x=False, dtype=torch.f
     ``collect``: optional dict filled with intermediates (nbr, e_w, per-layer h/x) for stage-wise parity.
     """
     cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
-    assert cfg['num_blocks'] == 1 and cfg['cutoff_mode'] == 'knn' and cfg['ew_net_type'] == 'global'
-    k, heads, H = cfg['knn'], cfg['n_heads'], cfg['hidden_dim']
+    assert cfg['num_blocks'] == 1 and cfg['ew_net_type'] == 'global'
+    heads, H = cfg['n_heads'], cfg['hidden_dim']
     dh = H // heads
     h = h.to(dtype)
     x = x.to(dtype)
     N = h.shape[0]
-    nbr = knn_neighbours(x.float(), k, batch)                       # :307 -> :280 (fp32 compare by contract)
+    # :307 -> _connect_edge :276-286 (fp32 compare by contract); the dense table is -1 padded to its widest row
+    if cfg['cutoff_mode'] == 'knn':
+        nbr = knn_neighbours(x.float(), cfg['knn'], batch)                                      # :280
+    elif cfg['cutoff_mode'] == 'hybrid':
+        nbr = hybrid_neighbours(x.float(), cfg['knn'], mask_ligand, batch)                      # :281-283
+    elif cfg['cutoff_mode'] == 'radius':
+        nbr = radius_neighbours(x.float(), cfg.get('r', cfg['r_max']), batch, cfg.get('max_num_neighbors', 32))   # :277-278
+    else:
+        raise ValueError(cfg['cutoff_mode'])
+    k = nbr.shape[1]                                                # table width (= every row's in-degree for kNN)
     valid = nbr >= 0
     etype = edge_types(nbr, mask_ligand)                            # :311
     nb = nbr.clamp(min=0)

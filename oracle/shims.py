@@ -130,6 +130,80 @@ def knn_neighbours(x: torch.Tensor, k: int, batch: torch.Tensor | None = None) -
     return out
 
 
+def _d2_matrix(xq: torch.Tensor, xc: torch.Tensor) -> torch.Tensor:
+    """[nq, nc] squared distances under the project's rule: (dx*dx + dy*dy) + dz*dz in fp32, separate mul / add."""
+    xq, xc = xq.to(torch.float32), xc.to(torch.float32)
+    dx = xc[None, :, 0] - xq[:, None, 0]
+    dy = xc[None, :, 1] - xq[:, None, 1]
+    dz = xc[None, :, 2] - xq[:, None, 2]
+    return (dx * dx + dy * dy) + dz * dz
+
+
+def hybrid_neighbours(x: torch.Tensor, k: int, mask_ligand: torch.Tensor, batch: torch.Tensor) -> torch.Tensor:
+    """Dense in-neighbour table [N, width] (-1 padded) of ``batch_hybrid_edge_connection(x, k, mask_ligand, batch,
+    add_p_index=True)`` (models/common.py:165-212, dispatched at models/uni_transformer.py:281-283):
+
+    * a protein atom: its k nearest nodes of the graph (protein or ligand) -- the knn_graph rows restricted to protein dst
+      (:197-204);
+    * a ligand atom: every other ligand atom of the graph (:166-171), then its k nearest protein atoms (:173-181).
+
+    The reference picks the protein neighbours with ``torch.topk`` on ``torch.norm`` distances (tie order and the
+    rounding of the norm are unspecified); the project's rule is the kNN one: ascending (d2, index) with the fp32 d2 above.
+    The reference's edge ORDER is irrelevant to its scatter ops, so parity is on the neighbour SETS (tests)."""
+    N = x.size(0)
+    mask_ligand = mask_ligand.bool()
+    rows = [None] * N
+    counts = torch.bincount(batch)
+    start = 0
+    for n in counts.tolist():
+        idx = torch.arange(start, start + n)
+        lig = idx[mask_ligand[idx]]
+        prot = idx[~mask_ligand[idx]]
+        if len(prot):
+            d2 = _d2_matrix(x[prot], x[idx])
+            d2[torch.arange(len(prot)), prot - start] = float('inf')          # prot is a prefix of idx in compose order
+            kk = min(k, n - 1)
+            order = torch.sort(d2, dim=1, stable=True).indices[:, :kk] + start
+            for r, i in enumerate(prot.tolist()):
+                rows[i] = order[r].tolist()
+        if len(lig):
+            kp = min(k, len(prot))
+            near = torch.sort(_d2_matrix(x[lig], x[prot]), dim=1, stable=True).indices[:, :kp] if kp else None
+            for r, i in enumerate(lig.tolist()):
+                rows[i] = [j for j in lig.tolist() if j != i] + (prot[near[r]].tolist() if kp else [])
+        start += n
+    width = max((len(r) for r in rows), default=0)
+    out = torch.full((N, max(width, 1)), -1, dtype=torch.long)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+    return out
+
+
+def radius_neighbours(x: torch.Tensor, r: float, batch: torch.Tensor, max_num_neighbors: int = 32) -> torch.Tensor:
+    """Dense in-neighbour table [N, max_num_neighbors] (-1 padded) of the radius graph with a fan-out cap.
+
+    The reference cannot run this mode (models/uni_transformer.py:278 reads ``self.r``, never assigned), so there is no
+    reference behaviour; the rule is this project's, after the published semantics of torch_cluster's ``radius_graph``
+    (first hits in index order, not nearest first): the first ``max_num_neighbors`` nodes j != i of the same graph, in
+    ascending index order, with d2(i, j) < r * r (fp32 d2 as above, r * r rounded to fp32, strict).  (torch_cluster 1.6.0
+    searches max_num_neighbors + 1 hits including i itself and drops i afterwards, which returns one edge more for nodes
+    whose first hits all precede them; that artefact is not reproduced.)"""
+    N = x.size(0)
+    out = torch.full((N, max_num_neighbors), -1, dtype=torch.long)
+    r2 = torch.tensor(r, dtype=torch.float32) * torch.tensor(r, dtype=torch.float32)
+    counts = torch.bincount(batch)
+    start = 0
+    for n in counts.tolist():
+        d2 = _d2_matrix(x[start:start + n], x[start:start + n])
+        hit = d2 < r2
+        hit.fill_diagonal_(False)
+        for li in range(n):
+            js = torch.nonzero(hit[li]).squeeze(1)[:max_num_neighbors] + start
+            out[start + li, :len(js)] = js
+        start += n
+    return out
+
+
 def knn_graph(x, k, batch=None, loop=False, flow='source_to_target', cosine=False, num_workers=1):
     """edge_index [2, E]: row 0 = source (neighbour), row 1 = target (query); grouped by target ascending,
     ascending distance inside a group (torch_geometric.nn.knn_graph, flow='source_to_target')."""

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libtargetdiff_hip.so')
-SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'edge.hip', 'edge_fast.hip', 'edge16.hip', 'misc.hip', 'likelihood.hip', 'egnn.hip']
+SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'gate.hip', 'edge16.hip', 'misc.hip', 'likelihood.hip', 'egnn.hip']
 ARCH = 'gfx950'
 # NB: the kNN distance uses __fmul_rn/__fadd_rn explicitly (td_dist2), so the default fp contraction is safe.
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function']

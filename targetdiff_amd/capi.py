@@ -25,7 +25,13 @@ KNN = 32
 class TdConfig(ctypes.Structure):
     _fields_ = [('hidden_dim', c_int32), ('n_heads', c_int32), ('knn', c_int32), ('num_layers', c_int32),
                 ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
-                ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('reserved', c_int32 * 7)]
+                ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('cutoff_mode', c_int32), ('radius', c_float),
+                ('max_num_neighbors', c_int32), ('reserved', c_int32 * 4)]
+
+
+CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
+MAX_FANIN = 64
+ABI_VERSION = 2
 
 
 # every symbol include/targetdiff_hip.h declares: (restype, argtypes)
@@ -37,6 +43,9 @@ SIGNATURES = {
                                   POINTER(c_void_p)]),
     'td_model_destroy': (None, [_P]),
     'td_model_num_weights': (c_size_t, [POINTER(TdConfig)]),
+    'td_model_set_option': (c_int32, [_P, c_char_p, c_int32]),
+    'td_model_get_option': (c_int32, [_P, c_char_p, POINTER(c_int32)]),
+    'td_graph_build': (c_int32, [_P, _P, _P, _P, c_int64, c_int64, c_int32, _P, c_int32, _P]),
     'td_workspace_bytes': (c_size_t, [_P, c_int64, c_int64, c_int64]),
     'td_graph_ptr': (c_int32, [_P, c_int64, c_int64, _P, _P]),
     'td_knn': (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P]),
@@ -62,7 +71,6 @@ SIGNATURES = {
     'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
-    'td_debug_edge_timing': (c_int32, [_P, c_int32]),
     'td_profile_begin': (c_int32, [ctypes.c_uint32]),
     'td_profile_end': (c_int32, [POINTER(c_float), POINTER(c_int32), c_int32]),
 }
@@ -101,6 +109,9 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.td_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'{path} has ABI version {lib.td_abi_version()}, this binding needs {ABI_VERSION}: rebuild it '
+                           '(python -m targetdiff_amd.build)')
     _lib = lib
     return lib
 
@@ -194,10 +205,17 @@ class NativeModel:
         if not torch.cuda.is_available():
             raise RuntimeError('no HIP device visible: targetdiff_amd needs an MI355X (gfx950); there is no CPU path')
         self.device = _canonical_device(device)
+        mode = cfg.get('cutoff_mode', 'knn')
+        if mode not in CUTOFF_MODES:
+            raise ValueError(f'cutoff_mode must be one of {sorted(CUTOFF_MODES)}, got {mode!r}')
         self.cfg = TdConfig(hidden_dim=cfg['hidden_dim'], n_heads=cfg['n_heads'], knn=cfg['knn'],
                             num_layers=cfg['num_layers'], num_r_gaussian=cfg['num_r_gaussian'],
                             edge_feat_dim=cfg['edge_feat_dim'], protein_feat_dim=cfg['protein_feat_dim'],
-                            ligand_num_classes=cfg['ligand_num_classes'], num_timesteps=cfg['num_timesteps'])
+                            ligand_num_classes=cfg['ligand_num_classes'], num_timesteps=cfg['num_timesteps'],
+                            cutoff_mode=CUTOFF_MODES[mode], radius=float(cfg.get('radius', 0.0)),
+                            max_num_neighbors=int(cfg.get('max_num_neighbors', 32)))
+        self.cutoff_mode, self.k = mode, int(cfg['knn'])
+        self.default_graph = mode == 'knn' and self.k == KNN       # the fixed-32 fast path (and the caching session)
         self.num_classes = int(cfg['ligand_num_classes'])
         blob = flatten_state_dict(state_dict, cfg['num_layers'])
         expect = self.lib.td_model_num_weights(ctypes.byref(self.cfg))
@@ -222,6 +240,29 @@ class NativeModel:
             self.lib.td_model_destroy(h)
 
     # ------------------------------------------------------------------------------------------
+    @_device_bound
+    def set_option(self, name: str, value: int):
+        """Per-model switch (td_model_set_option): 'node_proj_split', 'h2x_fused', 'session_hop_levels',
+        'session_forward_reach'.  Stored in the native handle; nothing is read from the environment."""
+        _check(self.lib.td_model_set_option(self.handle, name.encode(), int(value)), 'td_model_set_option')
+
+    def get_option(self, name: str) -> int:
+        v = c_int32()
+        _check(self.lib.td_model_get_option(self.handle, name.encode(), ctypes.byref(v)), 'td_model_get_option')
+        return int(v.value)
+
+    @_device_bound
+    def graph_build(self, x: torch.Tensor, mask_ligand: torch.Tensor, node_ptr: torch.Tensor, width: int,
+                    max_graph_nodes: int = 0) -> torch.Tensor:
+        """The model's graph (its cutoff_mode) on a composed batch as a dense [N, width] table of in-neighbours, -1 padded."""
+        N = x.shape[0]
+        out = torch.empty(N, width, dtype=torch.int32, device=x.device)
+        mask_u8 = mask_ligand.to(torch.uint8).contiguous()
+        _check(self.lib.td_graph_build(self.handle, _ptr(x, torch.float32, 'x'), _ptr(mask_u8), _ptr(node_ptr, torch.int32, 'node_ptr'),
+                                       N, node_ptr.numel() - 1, max_graph_nodes, _ptr(out), width, _stream(self.device)),
+               'td_graph_build')
+        return out
+
     def workspace(self, N: int, B: int, Nl: int) -> torch.Tensor:
         need = int(self.lib.td_workspace_bytes(self.handle, N, B, Nl))
         if self._ws is None or self._ws.numel() < need:
@@ -248,6 +289,8 @@ class NativeModel:
         N, B = h.shape[0], node_ptr.numel() - 1
         out_h = torch.empty_like(h)
         out_x = torch.empty_like(x)
+        if want_graph and not self.default_graph:
+            raise ValueError('want_graph: the dense [N, 32] graph / gate outputs exist for the k = 32 kNN graph only (graph_build)')
         nbr = torch.empty(N, KNN, dtype=torch.int32, device=h.device) if want_graph else None
         ew = torch.empty(N, KNN, dtype=torch.float32, device=h.device) if want_graph else None
         ws = self.workspace(N, B, 0)

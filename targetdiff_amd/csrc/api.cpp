@@ -110,10 +110,17 @@ size_t mlp_floats(int in, int hid, int out) { return (size_t)hid * in + 3 * (siz
 int kv_in(const td_config &c) { return 2 * c.hidden_dim + c.edge_feat_dim + 4 * c.num_r_gaussian; }
 
 bool config_supported(const td_config &c) {
-    return c.hidden_dim == TD_H && c.n_heads == TD_HEADS && c.knn == TD_K && c.num_r_gaussian == TD_NG &&
+    const bool graph_ok = (c.cutoff_mode == TD_CUTOFF_KNN && c.knn >= 1 && c.knn <= TD_MAX_FANIN) ||
+                          (c.cutoff_mode == TD_CUTOFF_HYBRID && c.knn >= 1 && c.knn <= TD_MAX_FANIN) ||
+                          (c.cutoff_mode == TD_CUTOFF_RADIUS && c.radius > 0.f && c.max_num_neighbors >= 1 &&
+                           c.max_num_neighbors <= TD_MAX_FANIN);
+    return c.hidden_dim == TD_H && c.n_heads == TD_HEADS && graph_ok && c.num_r_gaussian == TD_NG &&
            c.edge_feat_dim == 4 && c.num_layers >= 1 && c.protein_feat_dim >= 1 && c.protein_feat_dim <= 32 &&
            c.ligand_num_classes >= 1 && c.ligand_num_classes <= TD_MAXC && c.num_timesteps >= 1;
 }
+
+// the graph every kernel's fast path is specialised for: exactly 32 in-edges per node, one MFMA tile per dst row
+bool default_graph(const td_config &c) { return c.cutoff_mode == TD_CUTOFF_KNN && c.knn == TD_K; }
 
 // Packed-buffer builder: collects tensors into one host vector; pointers are fixed up after the upload.
 struct Packer {
@@ -330,9 +337,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     if (!cfg || !host_weights || !out) { td_set_error("td_model_create: null argument"); return TD_EINVAL; }
     const td_config &c = *cfg;
     if (!config_supported(c)) {
-        td_set_error("td_model_create: unsupported configuration (need hidden 128, 16 heads, knn 32, 20 gaussians, "
-                     "edge_feat_dim 4; got %d/%d/%d/%d/%d)", c.hidden_dim, c.n_heads, c.knn, c.num_r_gaussian,
-                     c.edge_feat_dim);
+        td_set_error("td_model_create: unsupported configuration (need hidden 128, 16 heads, 20 gaussians, edge_feat_dim 4, "
+                     "knn / max_num_neighbors in 1..%d, cutoff_mode knn|hybrid|radius; got %d/%d/%d/%d, knn %d, cutoff_mode %d, "
+                     "radius %g, max_num_neighbors %d)", TD_MAX_FANIN, c.hidden_dim, c.n_heads, c.num_r_gaussian,
+                     c.edge_feat_dim, c.knn, c.cutoff_mode, (double)c.radius, c.max_num_neighbors);
         return TD_EINVAL;
     }
     if (num_weights != td_model_num_weights(cfg)) {
@@ -424,7 +432,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
     auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt}; };
     auto node = [&](const NodeOff &o) {
-        return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3};
+        return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
+                           m->opt.node_proj_split != 0};
     };
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
@@ -444,6 +453,30 @@ extern "C" void td_model_destroy(td_model *m) {
     if (m->blob) (void)hipFree(m->blob);
     delete[] m->layers;
     delete m;
+}
+
+extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value) {
+    if (!m || !name) { td_set_error("td_model_set_option: null argument"); return TD_EINVAL; }
+    if (strcmp(name, "h2x_fused") == 0) m->opt.h2x_fused = value != 0;
+    else if (strcmp(name, "node_proj_split") == 0) {
+        m->opt.node_proj_split = value != 0;
+        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+    } else if (strcmp(name, "session_hop_levels") == 0) {
+        if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }
+        m->opt.session_hop_levels = value;
+    } else if (strcmp(name, "session_forward_reach") == 0) m->opt.session_forward_reach = value != 0;
+    else { td_set_error("td_model_set_option: unknown option '%s'", name); return TD_EINVAL; }
+    return TD_OK;
+}
+
+extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t *value) {
+    if (!m || !name || !value) { td_set_error("td_model_get_option: null argument"); return TD_EINVAL; }
+    if (strcmp(name, "h2x_fused") == 0) *value = m->opt.h2x_fused;
+    else if (strcmp(name, "node_proj_split") == 0) *value = m->opt.node_proj_split;
+    else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
+    else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
+    else { td_set_error("td_model_get_option: unknown option '%s'", name); return TD_EINVAL; }
+    return TD_OK;
 }
 
 // ------------------------------------------------------------------------------------------ workspace
@@ -478,36 +511,13 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     return w;
 }
 
-// TD_EDGE_IMPL selects the key / value kernels: "fast16" (default; edge16.hip, re-associated passes on 16x16x4 tiles),
-// "fast32" (edge_fast.hip, the same passes on 32x32x2 tiles) or "plain" (edge.hip, per-edge k and v vectors
-// materialised).  The alternatives exist for A/B timing and as cross-checks (tests: test_alternative_kernel_paths_agree).
-int edge_impl() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TD_EDGE_IMPL");
-        v = !e ? 2 : (strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "fast32") == 0 ? 1 : 2));
-    }
-    return v;
-}
-bool fast_edges() { return edge_impl() != 0; }
 int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
              const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
-    return edge_impl() == 1 ? td_launch_edge_key(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s)
-                            : td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s);
+    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s);
 }
 int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, hipStream_t s) {
-    return edge_impl() == 1 ? td_launch_edge_value(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s)
-                            : td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s);
-}
-
-bool h2x_fused() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TD_H2X_FUSED");
-        v = (edge_impl() == 2 && !(e && e[0] == '0')) ? 1 : 0;
-    }
-    return v == 1;
+    return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
@@ -521,22 +531,19 @@ int h2x_project(const TdLayer &L, Workspace &w, float *h, int64_t N, int64_t Nl,
 }
 
 // attention over the ligand atoms' edges and the coordinate update xc -> xn
-int h2x_attend(const TdLayer &L, Workspace &w, float *h, int64_t Nl, float4 *xc, float4 *xn, float *P, float *q,
+int h2x_attend(const td_model *m, const TdLayer &L, Workspace &w, int64_t Nl, float4 *xc, float4 *xn, float *P, float *q,
                float *alpha, hipStream_t s) {
     int rc;
-    if (h2x_fused()) {
+    if (m->opt.h2x_fused) {
         ProfScope ps(PC_H2X_K, s);
         return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, s);
     }
     {
         ProfScope ps(PC_H2X_K, s);
-        if (fast_edges()) rc = key_pass(L.xk, L, xc, w.nbr, w.ew, P, q, w.lig_node, nullptr, Nl, alpha, s);
-        else rc = td_launch_edge_pass(2, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, h, alpha, s);
-        if (rc != TD_OK) return rc;
+        if ((rc = key_pass(L.xk, L, xc, w.nbr, w.ew, P, q, w.lig_node, nullptr, Nl, alpha, s)) != TD_OK) return rc;
     }
     ProfScope ps(PC_H2X_V, s);
-    if (edge_impl() == 2) return td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, P, w.lig_node, Nl, alpha, s);
-    return td_launch_edge_pass(3, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, h, alpha, s);
+    return td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, P, w.lig_node, Nl, alpha, s);
 }
 
 // kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
@@ -556,7 +563,6 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
                  const FwdReach *fwd = nullptr) {
     int rc;
     const int Lc = m->cfg.num_layers;
-    if (!fast_edges()) hop_levels = 0;
     // row list of receptive-field level k (1-based); nullptr = every row
     auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
     auto level_count = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_count + (k - 1) : nullptr; };
@@ -577,21 +583,16 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         if (!(l == 0 && layer0_x2h_done)) {
             const int e = Lc - 1 - l;
             const int32_t *rws = l > 0 ? level_rows(e + 1) : nullptr, *cnt = l > 0 ? level_count(e + 1) : nullptr;
-            const bool use_fwd = fwd && l == 1 && !rws && fast_edges();
+            const bool use_fwd = fwd && l == 1 && !rws;
             if (use_fwd) { rws = fwd->rows; cnt = fwd->counts; }
             if (!proj_done) {
                 ProfScope ps(PC_NODE, s);
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
             proj_done = false;
-            if (fast_edges()) {
-                { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
-                { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
-                if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
-            } else {
-                { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_pass(0, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
-                { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_pass(1, L, xc, nullptr, w.nbr, w.ew, w.P, w.q, nullptr, N, h, w.alpha, s)) != TD_OK) return rc; }
-            }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
+            if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
         if (l + 1 < Lc) {
@@ -604,10 +605,154 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         } else {
             if ((rc = h2x_project(L, w, h, N, Nl, w.Px, w.qx, level_rows(1), level_count(1), s)) != TD_OK) return rc;
         }
-        if ((rc = h2x_attend(L, w, h, Nl, xc, xn, w.Px, w.qx, w.alpha, s)) != TD_OK) return rc;
+        if ((rc = h2x_attend(m, L, w, Nl, xc, xn, w.Px, w.qx, w.alpha, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
     }
     *x_final = xc;
+    return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------ general graphs
+// Layout of the chunked neighbour table of one batch (graph.hip "general graphs") plus the chunk-indexed buffers.  The
+// layout depends only on the per-graph atom counts, so a sampling session builds it once; a stateless call builds and
+// frees one per call (one host round trip for the counts -- these are the non-default graph modes).
+struct GraphPlan {
+    int mode = 0, k = 0, cpn_p = 1;
+    float radius = 0.f;
+    int64_t N = 0, Np = 0, Nl = 0, B = 0, NC = 0, NCl = 0;
+    char *block = nullptr;
+    int32_t *cptr = nullptr, *chunk_node = nullptr, *lig_chunks = nullptr, *cnbr = nullptr, *prot_node = nullptr, *pptr = nullptr, *meta = nullptr;
+    float *ew = nullptr, *alpha = nullptr;
+};
+
+void plan_destroy(GraphPlan &p, hipStream_t s) {
+    if (p.block) (void)hipFreeAsync(p.block, s);
+    p.block = nullptr;
+}
+
+// host_pptr / host_lptr: [B+1] prefix offsets of the protein / ligand atoms (host copies)
+int plan_create(const td_config &c, const int32_t *host_pptr, const int32_t *host_lptr, int64_t B, hipStream_t s, GraphPlan *out) {
+    GraphPlan p;
+    p.mode = c.cutoff_mode;
+    p.k = c.cutoff_mode == TD_CUTOFF_RADIUS ? c.max_num_neighbors : c.knn;
+    p.radius = c.radius;
+    p.cpn_p = (p.k + TD_K - 1) / TD_K;
+    p.B = B;
+    p.Np = host_pptr[B]; p.Nl = host_lptr[B]; p.N = p.Np + p.Nl;
+    std::vector<int32_t> meta((size_t)3 * (B + 1));
+    int32_t *g_cbase = meta.data(), *g_cl = g_cbase + (B + 1), *g_lbase = g_cl + (B + 1);
+    int64_t nc = 0, ncl = 0;
+    for (int64_t g = 0; g < B; ++g) {
+        const int np = host_pptr[g + 1] - host_pptr[g], nl = host_lptr[g + 1] - host_lptr[g];
+        int cl = p.cpn_p;
+        if (p.mode == TD_CUTOFF_HYBRID) { cl = (nl - 1 + p.k + TD_K - 1) / TD_K; if (cl < 1) cl = 1; }
+        g_cbase[g] = (int32_t)nc; g_cl[g] = cl; g_lbase[g] = (int32_t)ncl;
+        nc += (int64_t)np * p.cpn_p + (int64_t)nl * cl;
+        ncl += (int64_t)nl * cl;
+    }
+    g_cbase[B] = (int32_t)nc; g_cl[B] = 0; g_lbase[B] = (int32_t)ncl;
+    if (nc > 0x7fffffff / TD_K) { td_set_error("graph plan: %lld chunks overflow the 32-bit slot index", (long long)nc); return TD_EINVAL; }
+    p.NC = nc; p.NCl = ncl;
+    size_t off = 0;
+    auto reserve = [&](size_t n) { size_t o = off; off += align_up(n ? n : 4); return o; };
+    const size_t o_cptr = reserve((size_t)(p.N + 1) * 4), o_cn = reserve((size_t)nc * 4), o_lc = reserve((size_t)ncl * 4),
+                 o_nbr = reserve((size_t)nc * TD_K * 4), o_ew = reserve((size_t)nc * TD_K * 4),
+                 o_al = reserve((size_t)nc * TD_HEADS * TD_K * 4), o_pn = reserve((size_t)p.Np * 4),
+                 o_pp = reserve((size_t)(B + 1) * 4), o_meta = reserve(meta.size() * 4);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p.block), off, s);
+    if (e != hipSuccess) { td_set_error("graph plan: hipMallocAsync(%zu) failed: %s", off, hipGetErrorString(e)); return TD_ENOMEM; }
+    char *b = p.block;
+    p.cptr = reinterpret_cast<int32_t *>(b + o_cptr); p.chunk_node = reinterpret_cast<int32_t *>(b + o_cn);
+    p.lig_chunks = reinterpret_cast<int32_t *>(b + o_lc); p.cnbr = reinterpret_cast<int32_t *>(b + o_nbr);
+    p.ew = reinterpret_cast<float *>(b + o_ew); p.alpha = reinterpret_cast<float *>(b + o_al);
+    p.prot_node = reinterpret_cast<int32_t *>(b + o_pn); p.pptr = reinterpret_cast<int32_t *>(b + o_pp);
+    p.meta = reinterpret_cast<int32_t *>(b + o_meta);
+    // the small per-graph tables: synchronous copies (the source vectors die with this frame)
+    TD_CHECK_HIP(hipMemcpyAsync(b + o_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s));
+    TD_CHECK_HIP(hipMemcpyAsync(p.pptr, host_pptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
+    TD_CHECK_HIP(hipStreamSynchronize(s));
+    *out = p;
+    return TD_OK;
+}
+
+// cptr / chunk_node / lig_chunks from the per-graph tables (needs node_ptr and gid of the composed batch)
+int plan_layout(GraphPlan &p, const int32_t *node_ptr, const int32_t *gid, hipStream_t s) {
+    const int32_t *meta = p.meta;
+    return td_launch_layout(node_ptr, p.pptr, gid, meta, meta + (p.B + 1), meta + 2 * (p.B + 1), p.cpn_p, p.N, p.cptr,
+                            p.chunk_node, p.lig_chunks, (int32_t)p.NC, s);
+}
+
+// graph + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch with a general graph: every layer on every row
+// (the row-list pruning of the sampling session is specific to the default graph).
+int run_backbone_general(const td_model *m, GraphPlan &p, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x,
+                         int max_graph_nodes, float4 **x_final, hipStream_t s) {
+    int rc;
+    {
+        ProfScope ps(PC_KNN, s);
+        if ((rc = td_launch_graph_general(p.mode, w.x4a, w.node_ptr, p.pptr, w.gid, p.prot_node, p.Np, w.lig_node, Nl, N, p.k,
+                                          p.radius, max_graph_nodes, p.cptr, p.cnbr, p.NC, s)) != TD_OK) return rc;
+    }
+    {
+        ProfScope ps(PC_GATE, s);
+        if ((rc = td_launch_gate(m->gate, w.x4a, p.cnbr, p.NC, nullptr, nullptr, p.ew, s, p.chunk_node)) != TD_OK) return rc;
+    }
+    float4 *xc = w.x4a, *xn = w.x4b;
+    const bool do_h2x = !fix_x && Nl > 0;
+    if (do_h2x) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < m->cfg.num_layers; ++l) {
+        const TdLayer &L = m->layers[l];
+        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_logits16(0, L.hk, L, xc, p.cnbr, w.P, w.q, p.chunk_node, nullptr, p.NC, p.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value16_ragged(L.hv, L, xc, p.cnbr, p.ew, w.P, p.cptr, nullptr, N, h, p.alpha, s)) != TD_OK) return rc; }
+        if (!do_h2x) continue;
+        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.Px, w.qx, s, nullptr, w.lig_node, Nl, 0x15)) != TD_OK) return rc; }
+        { ProfScope ps(PC_H2X_K, s); if ((rc = td_launch_edge_logits16(1, L.xk, L, xc, p.cnbr, w.Px, w.qx, p.chunk_node, p.lig_chunks, p.NCl, p.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_H2X_V, s); if ((rc = td_launch_edge_xv16_ragged(L.xv, L, xc, xn, p.cnbr, p.ew, w.Px, p.cptr, w.lig_node, Nl, p.alpha, s)) != TD_OK) return rc; }
+        float4 *t = xc; xc = xn; xn = t;
+    }
+    *x_final = xc;
+    return TD_OK;
+}
+
+// Plan of a composed batch given as (mask_ligand, node_ptr) -- the refine_net seam: per-graph protein / ligand counts and
+// the protein row list are derived on the host (one round trip; compose_context order = protein rows first is required).
+int plan_from_mask(const td_config &c, const uint8_t *d_mask, const int32_t *d_node_ptr, int64_t N, int64_t B, hipStream_t s,
+                   GraphPlan *out, int64_t *nl_out) {
+    std::vector<uint8_t> mask((size_t)N);
+    std::vector<int32_t> nptr((size_t)B + 1);
+    TD_CHECK_HIP(hipMemcpyAsync(mask.data(), d_mask, (size_t)N, hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipMemcpyAsync(nptr.data(), d_node_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> hp((size_t)B + 1, 0), hl((size_t)B + 1, 0), prot;
+    prot.reserve((size_t)N);
+    for (int64_t g = 0; g < B; ++g) {
+        int np = 0, nl = 0;
+        for (int i = nptr[g]; i < nptr[g + 1]; ++i) {
+            if (mask[(size_t)i]) ++nl;
+            else {
+                if (nl) { td_set_error("general graphs need compose_context order (protein rows first inside every graph)"); return TD_EINVAL; }
+                ++np;
+                prot.push_back(i);
+            }
+        }
+        hp[g + 1] = hp[g] + np; hl[g + 1] = hl[g] + nl;
+    }
+    int rc = plan_create(c, hp.data(), hl.data(), B, s, out);
+    if (rc != TD_OK) return rc;
+    if (!prot.empty()) {
+        TD_CHECK_HIP(hipMemcpyAsync(out->prot_node, prot.data(), prot.size() * 4, hipMemcpyHostToDevice, s));
+        TD_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    *nl_out = hl[B];
+    return TD_OK;
+}
+
+// host copies of two [B+1] device arrays (one synchronisation)
+int fetch_ptrs(const int32_t *d_a, const int32_t *d_b, int64_t B, std::vector<int32_t> &a, std::vector<int32_t> &b, hipStream_t s) {
+    a.resize((size_t)B + 1); b.resize((size_t)B + 1);
+    TD_CHECK_HIP(hipMemcpyAsync(a.data(), d_a, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipMemcpyAsync(b.data(), d_b, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s));
+    TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }
 }  // namespace
@@ -625,7 +770,7 @@ extern "C" int td_graph_ptr(const int64_t *d_batch, int64_t N, int64_t B, int32_
 
 extern "C" int td_knn(const float *d_x, const int32_t *d_node_ptr, int64_t N, int64_t B, int32_t k,
                       int32_t max_graph_nodes, int32_t *d_out_nbr, void *stream) {
-    if (k != TD_K) { td_set_error("td_knn: only k = %d is built (got %d)", TD_K, k); return TD_EINVAL; }
+    if (k < 1 || k > TD_MAX_FANIN) { td_set_error("td_knn: k must be in 1..%d (got %d)", TD_MAX_FANIN, k); return TD_EINVAL; }
     if (N < 0 || B < 0 || (N > 0 && (!d_x || !d_node_ptr || !d_out_nbr))) { td_set_error("td_knn: bad argument"); return TD_EINVAL; }
     if (N == 0) return TD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -638,9 +783,59 @@ extern "C" int td_knn(const float *d_x, const int32_t *d_node_ptr, int64_t N, in
     // the ligand flag (.w) is irrelevant for the search: pack with an all-zero mask (gid is zero-filled scratch)
     int rc = td_launch_pack_x(d_x, reinterpret_cast<const uint8_t *>(gid), N, x4, s);
     if (rc == TD_OK) rc = td_launch_node_gid(d_node_ptr, N, B, gid, s);
-    if (rc == TD_OK) rc = td_launch_knn(x4, d_node_ptr, gid, N, max_graph_nodes, d_out_nbr, s);
+    if (rc == TD_OK && k == TD_K) rc = td_launch_knn(x4, d_node_ptr, gid, N, max_graph_nodes, d_out_nbr, s);
+    else if (rc == TD_OK) {
+        // any other k: through the chunked table of the general-graph path (every node counts as "protein": one row kind)
+        td_config c = {};
+        c.cutoff_mode = TD_CUTOFF_KNN; c.knn = k;
+        std::vector<int32_t> hp((size_t)B + 1), hl((size_t)B + 1, 0);
+        hipError_t e = hipMemcpyAsync(hp.data(), d_node_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        GraphPlan p;
+        if (e != hipSuccess) { td_set_error("td_knn: %s", hipGetErrorString(e)); rc = TD_EHIP; }
+        else rc = plan_create(c, hp.data(), hl.data(), B, s, &p);
+        if (rc == TD_OK) {
+            rc = plan_layout(p, d_node_ptr, gid, s);
+            if (rc == TD_OK) rc = td_launch_graph_general(TD_CUTOFF_KNN, x4, d_node_ptr, p.pptr, gid, nullptr, 0, nullptr, 0, N, k, 0.f,
+                                                          max_graph_nodes, p.cptr, p.cnbr, p.NC, s);
+            if (rc == TD_OK) rc = td_launch_slots_to_dense(p.cptr, p.cnbr, N, k, d_out_nbr, s);
+            plan_destroy(p, s);
+        }
+    }
     (void)hipFreeAsync(x4, s);
     (void)hipFreeAsync(gid, s);
+    return rc;
+}
+
+extern "C" int td_graph_build(const td_model *m, const float *d_x, const uint8_t *d_mask_ligand, const int32_t *d_node_ptr,
+                              int64_t N, int64_t B, int32_t max_graph_nodes, int32_t *d_out_nbr, int32_t width, void *stream) {
+    if (!m || N < 0 || B < 0 || width < 1 || (N > 0 && (!d_x || !d_mask_ligand || !d_node_ptr || !d_out_nbr))) {
+        td_set_error("td_graph_build: bad argument");
+        return TD_EINVAL;
+    }
+    if (N == 0) return TD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float4 *x4 = nullptr;
+    int32_t *gid = nullptr, *lig = nullptr;
+    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&x4), (size_t)N * sizeof(float4), s));
+    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&gid), (size_t)N * sizeof(int32_t), s));
+    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&lig), (size_t)(N + 1) * sizeof(int32_t), s));
+    int rc = td_launch_pack_x(d_x, d_mask_ligand, N, x4, s);
+    if (rc == TD_OK) rc = td_launch_node_gid(d_node_ptr, N, B, gid, s);
+    if (rc == TD_OK) rc = td_launch_ligand_list(d_mask_ligand, N, lig, lig + N, s);
+    GraphPlan p;
+    int64_t nl = 0;
+    if (rc == TD_OK) rc = plan_from_mask(m->cfg, d_mask_ligand, d_node_ptr, N, B, s, &p, &nl);
+    if (rc == TD_OK) {
+        rc = plan_layout(p, d_node_ptr, gid, s);
+        if (rc == TD_OK) rc = td_launch_graph_general(p.mode, x4, d_node_ptr, p.pptr, gid, p.prot_node, p.Np, lig, nl, N, p.k, p.radius,
+                                                      max_graph_nodes, p.cptr, p.cnbr, p.NC, s);
+        if (rc == TD_OK) rc = td_launch_slots_to_dense(p.cptr, p.cnbr, N, width, d_out_nbr, s);
+        plan_destroy(p, s);
+    }
+    (void)hipFreeAsync(x4, s);
+    (void)hipFreeAsync(gid, s);
+    (void)hipFreeAsync(lig, s);
     return rc;
 }
 
@@ -674,6 +869,18 @@ extern "C" int td_refine_forward(const td_model *m, const float *d_h, const floa
     }
     if (d_out_h != d_h) TD_CHECK_HIP(hipMemcpyAsync(d_out_h, d_h, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
     float4 *xf = nullptr;
+    if (!default_graph(m->cfg)) {
+        if (d_out_nbr || d_out_ew) { td_set_error("td_refine_forward: graph / gate outputs exist for the k = 32 kNN graph only (use td_graph_build)"); return TD_EINVAL; }
+        GraphPlan p;
+        int64_t nl_all = 0;
+        if ((rc = plan_from_mask(m->cfg, d_mask_ligand, w.node_ptr, N, B, s, &p, &nl_all)) != TD_OK) return rc;
+        if (fix_x && nl_all > 0 && (rc = td_launch_ligand_list(d_mask_ligand, N, w.lig_node, w.lig_node + N, s)) != TD_OK) { plan_destroy(p, s); return rc; }
+        rc = plan_layout(p, w.node_ptr, w.gid, s);
+        if (rc == TD_OK) rc = run_backbone_general(m, p, w, d_out_h, N, nl_all, fix_x, max_graph_nodes, &xf, s);
+        if (rc == TD_OK) rc = td_launch_unpack_x(xf, N, d_out_x, s);
+        plan_destroy(p, s);
+        return rc;
+    }
     if ((rc = run_backbone(m, w, d_out_h, N, nl, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
     if ((rc = td_launch_unpack_x(xf, N, d_out_x, s)) != TD_OK) return rc;
     if (d_out_nbr) TD_CHECK_HIP(hipMemcpyAsync(d_out_nbr, w.nbr, (size_t)N * TD_K * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
@@ -703,6 +910,27 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc;
     float *h = d_final_h ? d_final_h : w.h;
+    if (!default_graph(m->cfg)) {
+        std::vector<int32_t> hp, hl;
+        if ((rc = fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s)) != TD_OK) return rc;
+        GraphPlan p;
+        if ((rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &p)) != TD_OK) return rc;
+        float4 *xg = nullptr;
+        {
+            ProfScope ps(PC_COMPOSE, s);
+            rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v, d_ligand_ptr, N_l, B,
+                                   h, w.x4a, w.node_ptr, w.gid, w.lig_node, p.prot_node, s);
+        }
+        if (rc == TD_OK) rc = plan_layout(p, w.node_ptr, w.gid, s);
+        if (rc == TD_OK) rc = run_backbone_general(m, p, w, h, N, N_l, fix_x, max_graph_nodes, &xg, s);
+        if (rc == TD_OK) {
+            ProfScope ps(PC_HEAD, s);
+            rc = td_launch_head(m->head, h, xg, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
+                                d_final_ligand_h, s);
+        }
+        plan_destroy(p, s);
+        return rc;
+    }
     {
         ProfScope ps(PC_COMPOSE, s);
         if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
@@ -827,7 +1055,7 @@ extern "C" int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t ed
     for (int l = 0; l < num_layers; ++l) {
         const Off &o = off[(size_t)l];
         TdEgnnLayer &L = m->layers[l];
-        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
         L.W2f = D + o.W2f; L.Wxf = D + o.Wxf; L.vec = D + o.vec; L.nodeB = D + o.nodeB; L.nb1 = D + o.nb1; L.nb2 = D + o.nb2;
     }
     *out = m;
@@ -981,11 +1209,6 @@ extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *
     return td_launch_reductions(d_in64, d_out6x64, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int td_debug_edge_timing(int64_t *d_buf, int32_t nodes) {
-    td_set_edge_timing(reinterpret_cast<long long *>(d_buf), nodes);
-    return TD_OK;
-}
-
 // ------------------------------------------------------------------------------------------ sampling session
 // State of one ScorePosNet3D.sample_diffusion call (models/molopt_score_model.py:633-703).  Everything that depends
 // only on the protein is loop-invariant there (protein_pos, protein_v, batch_protein are passed unchanged to every
@@ -1006,6 +1229,8 @@ struct td_session {
     int32_t *fwd_rows, *fwd_rest, *fwd_counts;
     bool use_fwd;
     uint8_t *clean;
+    bool general;                // non-default graph (k != 32, hybrid, radius): no static-protein caching, only the layout is kept
+    GraphPlan plan;
 };
 
 extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
@@ -1020,6 +1245,40 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     td_session *S = new (std::nothrow) td_session();
     if (!S) { td_set_error("td_session_create: out of host memory"); return TD_ENOMEM; }
     S->m = m; S->N = N; S->Np = N_p; S->Nl = N_l; S->B = B; S->max_graph_nodes = max_graph_nodes;
+    S->general = !default_graph(m->cfg);
+    if (S->general) {
+        // general graphs: the session keeps the embedded protein rows and the chunk layout; every step runs every row
+        const size_t ws = carve(nullptr, N, B, N_l).bytes;
+        size_t total = ws;
+        const size_t o_h0 = total; total += align_up((size_t)N * TD_H * 4);
+        const size_t o_pp = total; total += align_up((size_t)(B + 1) * 4);
+        const size_t o_lp = total; total += align_up((size_t)(B + 1) * 4);
+        const size_t o_tl = total; total += align_up((size_t)N_l * 12);
+        const size_t o_tv = total; total += align_up((size_t)N_l * 8);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), total);
+        if (e != hipSuccess) { td_set_error("td_session_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); delete S; return TD_ENOMEM; }
+        char *b = S->block;
+        S->w = carve(b, N, B, N_l);
+        S->h0 = reinterpret_cast<float *>(b + o_h0);
+        S->pptr = reinterpret_cast<int32_t *>(b + o_pp);
+        S->lptr = reinterpret_cast<int32_t *>(b + o_lp);
+        auto failg = [&](int rc) { plan_destroy(S->plan, s); (void)hipFree(S->block); delete S; return rc; };
+        int rc;
+        std::vector<int32_t> hp, hl;
+        if ((rc = fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s)) != TD_OK) return failg(rc);
+        if ((rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) return failg(rc);
+        hipError_t e2 = hipMemcpyAsync(S->pptr, d_protein_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(b + o_tl, 0, (size_t)N_l * 12, s);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(b + o_tv, 0, (size_t)N_l * 8, s);
+        if (e2 != hipSuccess) { td_set_error("td_session_create: %s", hipGetErrorString(e2)); return failg(TD_EHIP); }
+        if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, reinterpret_cast<float *>(b + o_tl),
+                                    reinterpret_cast<int64_t *>(b + o_tv), S->lptr, N_l, B, S->h0, S->w.x4a, S->w.node_ptr, S->w.gid,
+                                    S->w.lig_node, S->plan.prot_node, s)) != TD_OK) return failg(rc);
+        if ((rc = plan_layout(S->plan, S->w.node_ptr, S->w.gid, s)) != TD_OK) return failg(rc);
+        *out = S;
+        return TD_OK;
+    }
     // ---- one device block: [workspace | session-static buffers]
     const size_t ws_bytes = carve(nullptr, N, B, N_l).bytes;
     size_t off = ws_bytes;
@@ -1053,10 +1312,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->fwd_rows = reinterpret_cast<int32_t *>(b + o_frows);
     S->fwd_rest = reinterpret_cast<int32_t *>(b + o_frest);
     S->fwd_counts = reinterpret_cast<int32_t *>(b + o_fcnt);
-    {
-        const char *e = getenv("TD_SESSION_FORWARD_REACH");
-        S->use_fwd = !(e && e[0] == '0') && m->cfg.num_layers >= 2 && fast_edges();
-    }
+    S->use_fwd = m->opt.session_forward_reach && m->cfg.num_layers >= 2;
     S->P0 = reinterpret_cast<float *>(b + o_P0);
     S->q0 = reinterpret_cast<float *>(b + o_q0);
     S->clean = reinterpret_cast<uint8_t *>(b + o_clean);
@@ -1065,9 +1321,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->hop_rows = reinterpret_cast<int32_t *>(b + o_hop);
     S->hop_count = reinterpret_cast<int32_t *>(b + o_hcnt);
     {
-        // receptive-field levels tracked per step (each prunes one more layer from the end); TD_HOP_LEVELS caps it
-        const char *e = getenv("TD_SESSION_HOP_LEVELS");
-        int lv = e ? atoi(e) : TD_HOP_LEVELS;
+        // receptive-field levels tracked per step (each prunes one more layer from the end)
+        int lv = m->opt.session_hop_levels;
         if (lv < 1) lv = 1;
         if (lv > TD_HOP_LEVELS) lv = TD_HOP_LEVELS;
         if (lv > m->cfg.num_layers) lv = m->cfg.num_layers;
@@ -1112,6 +1367,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
 
 extern "C" void td_session_destroy(td_session *S) {
     if (!S) return;
+    if (S->general) plan_destroy(S->plan, nullptr);
     if (S->block) (void)hipFree(S->block);
     delete S;
 }
@@ -1128,6 +1384,18 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     Workspace &w = S->w;
     const int64_t N = S->N, Nl = S->Nl, Np = S->Np;
     int rc;
+    if (S->general) {
+        {
+            ProfScope ps(PC_COMPOSE, s);
+            TD_CHECK_HIP(hipMemcpyAsync(w.h, S->h0, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
+        }
+        float4 *xg = nullptr;
+        if ((rc = run_backbone_general(m, S->plan, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s)) != TD_OK) return rc;
+        ProfScope ps(PC_HEAD, s);
+        return td_launch_head(m->head, w.h, xg, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
+                              d_final_ligand_h, s);
+    }
     {
         ProfScope ps(PC_COMPOSE, s);
         if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
@@ -1166,6 +1434,11 @@ extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_
     if (!S || !host_counts || n_counts < 2) { td_set_error("td_session_row_counts: bad argument"); return TD_EINVAL; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     host_counts[0] = (int32_t)S->N;
+    if (S->general) {            // every layer runs on every row
+        host_counts[1] = (int32_t)S->N;
+        for (int k = 2; k < n_counts; ++k) host_counts[k] = -1;
+        return TD_OK;
+    }
     TD_CHECK_HIP(hipMemcpyAsync(host_counts + 1, S->dirty_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     for (int k = 2; k < n_counts; ++k) host_counts[k] = -1;
     const int room = n_counts - 2 < TD_HOP_LEVELS ? n_counts - 2 : TD_HOP_LEVELS;

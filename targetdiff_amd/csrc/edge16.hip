@@ -40,6 +40,9 @@ struct Args16 {
     const float *offsets;
     float coeff;
     int p_off;
+    // general graphs (ragged kernels only): the in-edges of node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha
+    const int32_t *chunk_node;
+    const int32_t *cptr;
 };
 
 __device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end) {
@@ -88,23 +91,24 @@ struct RowIn16 {
     float pit[8];          // dst-side projection P_i: hidden 16hb + lo
 };
 
-// neighbour indices of row i (the only load the gathers depend on)
-__device__ __forceinline__ void td_row_index16(const Args16 &a, int64_t i, int lane, RowIn16 &r) {
+// neighbour indices of chunk c of dst node i (the only load the gathers depend on); c == i on the default k = 32 graph
+__device__ __forceinline__ void td_row_index16(const Args16 &a, int64_t i, int64_t c, int lane, RowIn16 &r) {
     const int lo = lane & 15;
     r.xi = a.x4[i];
-    r.j[0] = a.nbr[i * TD_K + lo];
-    r.j[1] = a.nbr[i * TD_K + 16 + lo];
+    r.j[0] = a.nbr[c * TD_K + lo];
+    r.j[1] = a.nbr[c * TD_K + 16 + lo];
 }
 
 // gathers: neighbour positions, neighbour-side projections straight into the accumulators, dst-side projection
 template <bool LOAD_EW>
-__device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int lane, RowIn16 &r, floatx4_t (&acc)[2][8]) {
+__device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int64_t c, int lane, RowIn16 &r,
+                                                floatx4_t (&acc)[2][8]) {
     const int lo = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
         const int jj = r.j[eb] >= 0 ? r.j[eb] : (int)i;
         r.xj[eb] = a.x4[jj];
-        if (LOAD_EW) r.ew[eb] = a.ew[i * TD_K + 16 * eb + lo];
+        if (LOAD_EW) r.ew[eb] = a.ew[c * TD_K + 16 * eb + lo];
         // neighbour-side projection P_j, 16 bytes per hidden block: hidden 16hb + 4g .. + 3
         const float *pj = a.P + (size_t)jj * (4 * TD_H) + a.p_off + TD_H + 4 * g;
 #pragma unroll
@@ -206,10 +210,11 @@ template <bool LOAD_EW>
 __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
                                                  const float *__restrict__ GAM, const float *__restrict__ BET,
                                                  const float (&offk)[E16_STEPS], int64_t i, int lane,
-                                                 floatx4_t (&acc)[2][8], Edge2 &ed) {
+                                                 floatx4_t (&acc)[2][8], Edge2 &ed, int64_t c = -1) {
     RowIn16 r;
-    td_row_index16(a, i, lane, r);
-    td_row_gather16<LOAD_EW>(a, i, lane, r, acc);
+    if (c < 0) c = i;
+    td_row_index16(a, i, c, lane, r);
+    td_row_gather16<LOAD_EW>(a, i, c, lane, r, acc);
     td_first_layer_compute16<LOAD_EW>(a, Rt, GAM, BET, offk, r, lane, acc, ed);
 }
 
@@ -504,8 +509,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     float al[8], hres0 = 0.f, hres1 = 0.f;
     if (it < end) {
         i = row_id(it);
-        td_row_index16(a, i, lane, rin);
-        td_row_gather16<false>(a, i, lane, rin, acc);
+        td_row_index16(a, i, i, lane, rin);
+        td_row_gather16<false>(a, i, i, lane, rin, acc);
         load_side(i, al, hres0, hres1);
     }
     for (; it < end; it += V16_WAVES) {
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         RowIn16 rnext;
         if (more) {
             inext = row_id(it + V16_WAVES);
-            td_row_index16(a, inext, lane, rnext);
+            td_row_index16(a, inext, inext, lane, rnext);
         }
         Edge2 ed;
         td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         const int64_t icur = i;
         const float hcur0 = hres0, hcur1 = hres1;
         if (more) {
-            td_row_gather16<false>(a, inext, lane, rnext, acc);
+            td_row_gather16<false>(a, inext, inext, lane, rnext, acc);
             load_side(inext, al, hres0, hres1);
             rin = rnext;
             i = inext;
@@ -582,6 +587,264 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     }
 }
 
+// ================================================================================================ general graphs
+// Rows that are not exactly 32 wide (k-NN with k != 32, `hybrid`, radius with a fan-out cap): the in-edges of node i are
+// the chunks cptr[i] .. cptr[i+1]-1 of 32 slots (-1 padded; graph.hip).  The per-chunk arithmetic is the one above; what
+// changes is the softmax over ALL slots of a node, so the passes split differently:
+//   * edge_logits16_kernel   one wave per chunk: first layer -> z, logits = z . U_i, scaled logits to alpha[c] (-inf on pads)
+//   * edge_value16_ragged    one wave per node: max / sum of its logits, then per chunk alpha = softmax * gate,
+//                            Zbar += alpha^T z across the chunks, one output product W2v . Zbar, residual
+//   * edge_xv16_ragged       one wave per ligand node: same statistics, delta_x accumulated over the chunks
+// (scatter_softmax / scatter_sum over arbitrary segments, models/uni_transformer.py:73,78,135,139).
+template <int WAVES, int STAGE>
+__global__ __launch_bounds__(WAVES * 64) void edge_logits16_kernel(Args16 a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
+    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    td_stage_tables16<WAVES>(lds, a.mlp, E16_WQ_FLOATS / 4, tid);
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
+        const int64_t c = a.rows ? (int64_t)a.rows[it] : it;
+        const int64_t i = a.chunk_node[c];
+        floatx4_t acc[2][8];
+        Edge2 ed;
+        td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+        floatx4_t lg[2];
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
+                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
+                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+            dst[0] = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+            dst[16] = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+        }
+    }
+}
+
+__global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_ragged_kernel(Args16 a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float4 *Wv = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    float *TB = lds + E16_R_FLOATS + V16_W_FLOATS + wid * V16_WAVE_FLOATS;
+    float *SB = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
+    float *B2 = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
+    const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
+    {
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, V16_WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), V16_W_FLOATS / 4, tid,
+                       V16_WAVES * 64);
+        if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
+        else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
+        else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
+    }
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+    // the 8 logits a lane owns in a chunk: head lo, slots 8g .. 8g + 7 (the A-operand layout of the aggregation product)
+    auto load8 = [&](const float *base, int64_t c, float (&v)[8]) {
+        const float *ap = base + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
+        const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    };
+    for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        const int c0 = a.cptr[i], c1 = a.cptr[i + 1];
+        float xs[8];
+        float m = -INFINITY;
+        for (int c = c0; c < c1; ++c) {
+            load8(a.alpha, c, xs);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) m = fmaxf(m, xs[s]);
+        }
+        m = td_max_groups(m);
+        if (m == -INFINITY) m = 0.f;
+        float den = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            load8(a.alpha, c, xs);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) den += __expf(xs[s] - m);
+        }
+        den = td_sum_groups(den);
+        const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
+        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
+
+        floatx4_t zb[8];
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+        float asum = 0.f;
+        for (int c = c0; c < c1; ++c) {
+            RowIn16 rin;
+            floatx4_t acc[2][8];
+            Edge2 ed;
+            td_row_index16(a, i, c, lane, rin);
+            td_row_gather16<false>(a, i, c, lane, rin, acc);
+            td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+            float al[8];
+            load8(a.alpha, c, xs);
+            {
+                const float *ep = a.ew + (size_t)c * TD_K + 8 * g;        // gate of slots 8g .. 8g + 7 (0 on pads)
+                const float4 e0 = *reinterpret_cast<const float4 *>(ep), e1 = *reinterpret_cast<const float4 *>(ep + 4);
+                const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    al[s] = (__expf(xs[s] - m) * inv) * ev[s];
+                    asum += al[s];
+                }
+            }
+            auto flip_store = [&](int hb) {
+                float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb)
+                    *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                        make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+            };
+            flip_store(0);
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                if (hb + 1 < 8) flip_store(hb + 1);
+                const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+                float bv[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
+            }
+        }
+        const float ssum = td_sum_groups(asum);
+        if (lane < TD_HEADS) SB[lane] = ssum;
+        float *ZB = TB;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((g >> 1) == ph) {
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
+            }
+            const int n = 64 * ph + lane;
+            const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
+            float o = B2[n] * SB[8 * ph + (lane >> 3)];
+#pragma unroll 8
+            for (int kq = 0; kq < 32; ++kq) {
+                const float4 w = Wv[kq * TD_H + n];
+                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
+                o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
+            }
+            a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(XV16_WAVES * 64) void edge_xv16_ragged_kernel(Args16 a) {
+    constexpr int WAVES = XV16_WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
+    const float *Wx = lds + E16_R_FLOATS;                     // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
+    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    td_stage_tables16<WAVES>(lds, a.mlp, 8 * 4 * 64 / 4, tid);
+    float offk[E16_STEPS];
+#pragma unroll
+    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    const float b2 = a.mlp.b2[lo];
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        const int c0 = a.cptr[i], c1 = a.cptr[i + 1];
+        // softmax statistics of heads 4g .. 4g + 3 over every slot of the node
+        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, inv[4];
+        for (int c = c0; c < c1; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                m[r] = fmaxf(m[r], fmaxf(ap[0], ap[16]));
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            m[r] = td_max16(m[r]);
+            if (m[r] == -INFINITY) m[r] = 0.f;
+            inv[r] = 0.f;
+        }
+        for (int c = c0; c < c1; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                inv[r] += __expf(ap[0] - m[r]) + __expf(ap[16] - m[r]);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sm = td_sum16(inv[r]);
+            inv[r] = sm > 0.f ? __frcp_rn(sm) : 0.f;
+        }
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        float4 xi_keep = a.x4[i];
+        for (int c = c0; c < c1; ++c) {
+            floatx4_t acc[2][8];
+            Edge2 ed;
+            td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+            floatx4_t xv[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = Wx[(hb * 4 + r) * 64 + lane];
+                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
+                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                }
+            const float ew0 = a.ew[(size_t)c * TD_K + lo], ew1 = a.ew[(size_t)c * TD_K + 16 + lo];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bias = __shfl(b2, 4 * g + r);
+                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    const float al = (__expf(ap[16 * eb] - m[r]) * inv[r]) * (eb == 0 ? ew0 : ew1);
+                    const float wgt = ed.valid[eb] ? al * (xv[eb][r] + bias) : 0.f;
+                    sx = fmaf(wgt, ed.rel[eb][0], sx);
+                    sy = fmaf(wgt, ed.rel[eb][1], sy);
+                    sz = fmaf(wgt, ed.rel[eb][2], sz);
+                }
+            }
+        }
+        sx = td_sum64(sx) * (1.0f / TD_HEADS);
+        sy = td_sum64(sy) * (1.0f / TD_HEADS);
+        sz = td_sum64(sz) * (1.0f / TD_HEADS);
+        if (lane == 0) a.x4_out[i] = make_float4(xi_keep.x + sx, xi_keep.y + sy, xi_keep.z + sz, xi_keep.w);
+    }
+}
+
 // ================================================================================================ launchers
 static int grid16(int64_t count, int waves) {
     int64_t g = (count + waves - 1) / waves;
@@ -594,17 +857,11 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                          float *alpha, hipStream_t s) {
     if (count == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        attr_set = true;
-    }
-    Args16 a;
+    int rc_lds;
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 0>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     if (rows && !count_ptr)      // h2x key pass (ligand row list of known length)
@@ -619,13 +876,9 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
                         const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s) {
     if (count == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        attr_set = true;
-    }
-    Args16 a;
+    int rc_lds;
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    Args16 a = {};
     a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
@@ -638,13 +891,9 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            hipStream_t s) {
     if (count == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_value16_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)V16_LDS_BYTES));
-        attr_set = true;
-    }
-    Args16 a;
+    int rc_lds;
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_value16_kernel), V16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
@@ -658,18 +907,62 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
                          int64_t count, hipStream_t s) {
     if (count == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edge_h2x16_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)K16_LDS_BYTES));
-        attr_set = true;
-    }
-    ArgsH2x ar;
+    int rc_lds;
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_h2x16_kernel), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    ArgsH2x ar = {};
     Args16 &a = ar.a;
     a.x4 = x4_in; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = nullptr; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     ar.mlp_v = mlp_v;
     edge_h2x16_kernel<<<dim3(grid16(count, H2X16_WAVES)), dim3(H2X16_WAVES * 64), K16_LDS_BYTES, s>>>(ar);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ---- general graphs: chunk-indexed nbr / ew / alpha (see the ragged kernels above) --------------------------------
+#define TD_LDS_ONCE(fn, bytes) do { static TdLdsOnce once; int _rc = td_set_lds(once, reinterpret_cast<const void *>(fn), bytes); if (_rc != TD_OK) return _rc; } while (0)
+
+// stage 0: x2h keys, 1: h2x keys.  `chunks`: optional list of chunk ids (count = its length), else all NC chunks.
+int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr,
+                            const float *P, const float *q, const int32_t *chunk_node, const int32_t *chunks, int64_t count,
+                            float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    Args16 a = {};
+    a.x4 = x4; a.nbr = cnbr; a.P = P; a.q = q; a.rows = chunks; a.alpha = alpha; a.count = count; a.mlp = mlp;
+    a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0; a.chunk_node = chunk_node;
+    if (stage == 0) {
+        TD_LDS_ONCE((edge_logits16_kernel<K16_WAVES, 0>), K16_LDS_BYTES);
+        edge_logits16_kernel<K16_WAVES, 0><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    } else {
+        TD_LDS_ONCE((edge_logits16_kernel<K16_WAVES, 1>), K16_LDS_BYTES);
+        edge_logits16_kernel<K16_WAVES, 1><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    }
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+int td_launch_edge_value16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr, const float *ew,
+                                  const float *P, const int32_t *cptr, const int32_t *rows, int64_t count, float *h,
+                                  const float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    TD_LDS_ONCE((edge_value16_ragged_kernel), V16_LDS_BYTES);
+    Args16 a = {};
+    a.x4 = x4; a.nbr = cnbr; a.ew = ew; a.P = P; a.rows = rows; a.h = h; a.alpha = const_cast<float *>(alpha); a.count = count;
+    a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr;
+    edge_value16_ragged_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+int td_launch_edge_xv16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *cnbr,
+                               const float *ew, const float *P, const int32_t *cptr, const int32_t *rows, int64_t count,
+                               const float *alpha, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    TD_LDS_ONCE((edge_xv16_ragged_kernel), K16_LDS_BYTES);
+    Args16 a = {};
+    a.x4 = x4_in; a.nbr = cnbr; a.ew = ew; a.P = P; a.rows = rows; a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out;
+    a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr;
+    edge_xv16_ragged_kernel<<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

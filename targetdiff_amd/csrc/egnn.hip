@@ -188,11 +188,10 @@ __global__ __launch_bounds__(EG_WAVES * 64) void egnn_edge_kernel(TdEgnnLayer L,
 int td_launch_egnn_edge(const TdEgnnLayer &L, const float4 *x4, float4 *x4_out, const int32_t *nbr, const float *P, float *mi,
                         int64_t N, hipStream_t s) {
     if (N == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(egnn_edge_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EG_LDS_BYTES));
-        attr_set = true;
+    {
+        static TdLdsOnce once;
+        int rc = td_set_lds(once, reinterpret_cast<const void *>(egnn_edge_kernel), EG_LDS_BYTES);
+        if (rc != TD_OK) return rc;
     }
     int64_t g = (N + EG_WAVES - 1) / EG_WAVES;
     if (g > 256) g = 256;

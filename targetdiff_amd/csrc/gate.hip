@@ -1,0 +1,93 @@
+// Global edge gate e_w = sigmoid(MLP(20 -> 128 -> 1)(GaussianSmearing(dist)))   (gfx950, fp32 MFMA 32x32x2)
+//   models/uni_transformer.py:312-316 (edge_pred_layer on the step-start distances, reused by all layers),
+//   models/common.py:24-26 (Gaussians), :60-80 (Linear -> LayerNorm -> ReLU -> Linear).
+// One wave per 32-slot row of the neighbour table (a dst node on the default k = 32 graph, a chunk of a dst node's
+// in-edges on general graphs: chunk_node != nullptr), all 128 hidden units as 4 N tiles.  Pure register kernel.
+#include "td_device.h"
+#include "td_internal.h"
+
+// ------------------------------------------------------------------------------------------ edge gate
+// One wave per dst node, all 128 hidden units (4 N-tiles).  Pure register kernel: no LDS, no barriers.
+__global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float4 *__restrict__ x4,
+                                                        const int32_t *__restrict__ nbr, int64_t N,
+                                                        const int32_t *__restrict__ rows,
+                                                        const int32_t *__restrict__ count_ptr,
+                                                        const int32_t *__restrict__ chunk_node, float *__restrict__ ew) {
+    if (count_ptr) N = *count_ptr;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, hi = lane >> 5;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+
+    float4 R[TD_SLOT_STEPS];
+    const float4 *Rp = reinterpret_cast<const float4 *>(g.R);
+#pragma unroll
+    for (int s = 0; s < TD_SLOT_STEPS; ++s) R[s] = Rp[s * 64 + lane];
+    float b0[4], gam[4], bet[4], w3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        b0[t] = g.b0[32 * t + c]; gam[t] = g.gamma[32 * t + c]; bet[t] = g.beta[32 * t + c]; w3[t] = g.w3[32 * t + c];
+    }
+    float offk[TD_SLOT_STEPS];
+#pragma unroll
+    for (int s = 0; s < TD_SLOT_STEPS; ++s) {
+        const int k = td_kmap(s, hi);
+        offk[s] = k < TD_NG ? g.offsets[k] : 0.f;
+    }
+
+    for (int64_t it = wave0; it < N; it += nwaves) {
+        const int64_t row_id = rows ? (int64_t)rows[it] : it;            // row of nbr / ew
+        const int64_t i = chunk_node ? (int64_t)chunk_node[row_id] : row_id;   // its dst node
+        const int j = nbr[row_id * TD_K + c];
+        const bool valid = j >= 0;
+        const float4 xi = x4[i];
+        const float4 xj = x4[valid ? j : i];
+        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        floatx16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = b0[t];
+#pragma unroll
+        for (int s = 0; s < TD_SLOT_STEPS; ++s) {
+            const int k = td_kmap(s, hi);
+            const float u = d - offk[s];
+            const float av = k < TD_NG ? expf(g.coeff * u * u) : 0.f;
+            acc[0] = td_mfma(av, R[s].x, acc[0]);
+            acc[1] = td_mfma(av, R[s].y, acc[1]);
+            acc[2] = td_mfma(av, R[s].z, acc[2]);
+            acc[3] = td_mfma(av, R[s].w, acc[3]);
+        }
+        float outv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s1 = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+            const float mean = td_sum32(s1) * (1.0f / TD_H);
+            const float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
+            const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            float part = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f) * w3[0];
+            part += fmaxf(d1 * rstd * gam[1] + bet[1], 0.f) * w3[1];
+            part += fmaxf(d2 * rstd * gam[2] + bet[2], 0.f) * w3[2];
+            part += fmaxf(d3 * rstd * gam[3] + bet[3], 0.f) * w3[3];
+            const float logit = td_sum32(part) + g.b3;
+            if (c == r) outv = 1.0f / (1.0f + expf(-logit));
+        }
+        // lane (c < 16, hi) holds the gate of edge row erow(c, hi)
+        const int row = td_erow(c & 15, hi);
+        const int jrow = __shfl(j, row);
+        if (c < 16) ew[row_id * TD_K + row] = jrow >= 0 ? outv : 0.f;
+    }
+}
+
+int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
+                   const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node) {
+    if (N == 0) return TD_OK;
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    edge_gate_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, x4, nbr, N, rows, count_ptr, chunk_node, ew);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+

@@ -570,3 +570,190 @@ int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t 
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
+
+// ================================================================================================ general graphs
+// Chunked neighbour table for graphs whose rows are not exactly 32 wide (k-NN with k != 32, `hybrid`, radius with a
+// fan-out cap; models/uni_transformer.py:276-286): the in-edges of node i occupy the chunks cptr[i] .. cptr[i+1]-1 of 32
+// slots each (-1 padded), i.e. a flat slot array of length 32 * chunks starting at slot 32 * cptr[i].  A chunk is what one
+// wave of the edge kernels processes (one 32-row MFMA tile); chunk_node[c] is its dst node.  The default graph (k = 32)
+// is the special case chunk == node.
+__global__ void layout_kernel(const int32_t *__restrict__ node_ptr, const int32_t *__restrict__ pptr,
+                              const int32_t *__restrict__ gid, const int32_t *__restrict__ g_cbase,
+                              const int32_t *__restrict__ g_cl, const int32_t *__restrict__ g_lbase, int cpn_p, int64_t N,
+                              int32_t *__restrict__ cptr, int32_t *__restrict__ chunk_node, int32_t *__restrict__ lig_chunks,
+                              int32_t total_chunks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    if (i == N) { cptr[N] = total_chunks; return; }
+    const int g = gid[i];
+    const int li = (int)i - node_ptr[g], np = pptr[g + 1] - pptr[g];
+    int c0, cnt;
+    if (li < np) { c0 = g_cbase[g] + li * cpn_p; cnt = cpn_p; }
+    else { c0 = g_cbase[g] + np * cpn_p + (li - np) * g_cl[g]; cnt = g_cl[g]; }
+    cptr[i] = c0;
+    for (int t = 0; t < cnt; ++t) chunk_node[c0 + t] = (int32_t)i;
+    if (li >= np)
+        for (int t = 0; t < cnt; ++t) lig_chunks[g_lbase[g] + (li - np) * cnt + t] = c0 + t;
+}
+
+int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *g_cbase,
+                     const int32_t *g_cl, const int32_t *g_lbase, int cpn_p, int64_t N, int32_t *cptr, int32_t *chunk_node,
+                     int32_t *lig_chunks, int32_t total_chunks, hipStream_t s) {
+    layout_kernel<<<dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, s>>>(node_ptr, pptr, gid, g_cbase, g_cl, g_lbase, cpn_p, N,
+                                                                             cptr, chunk_node, lig_chunks, total_chunks);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// k nearest same-graph nodes for any k <= 64, written into the node's slot array (ascending (d2, index), like knn_kernel).
+// PROT_ONLY: candidates are the protein atoms of the graph only and the winners go to slots slot0 .. slot0 + k - 1 where
+// slot0 = (number of ligand atoms of the graph) - 1: the protein half of a hybrid ligand row.
+template <int CH, bool PROT_ONLY>
+__global__ __launch_bounds__(256) void knn_general_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
+                                                          const int32_t *__restrict__ pptr, const int32_t *__restrict__ gid,
+                                                          const int32_t *__restrict__ rows, int64_t count, int k,
+                                                          const int32_t *__restrict__ cptr, int32_t *__restrict__ cnbr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= count) return;
+    const int64_t i = rows ? (int64_t)rows[qi] : qi;
+    const int g = gid[i];
+    const int beg = ptr[g];
+    const int np = pptr[g + 1] - pptr[g];
+    const int end = PROT_ONLY ? beg + np : ptr[g + 1];
+    const int slot0 = PROT_ONLY ? (ptr[g + 1] - beg - np) - 1 : 0;
+    const float4 xi = x4[i];
+    unsigned long long best = TD_KEY_MAX;    // lanes 0..k-1: current r-th smallest key
+    for (int base = beg; base < end; base += 64 * CH) {
+        unsigned long long key[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int j = base + lane + 64 * u;
+            key[u] = TD_KEY_MAX;
+            if (j < end && j != (int)i) {
+                const float4 xj = x4[j];
+                const float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+                key[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+            }
+        }
+        unsigned long long carry = best, out = TD_KEY_MAX;
+        for (int r = 0; r < k; ++r) {
+            unsigned long long lmin = carry;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) lmin = key[u] < lmin ? key[u] : lmin;
+            const unsigned long long wmin = td_wave_min_u64(lmin);
+            if (wmin != TD_KEY_MAX) {
+                if (carry == wmin) carry = TD_KEY_MAX;
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (key[u] == wmin) key[u] = TD_KEY_MAX;
+            }
+            if (lane == r) out = wmin;
+        }
+        best = out;
+    }
+    if (lane < k && best != TD_KEY_MAX) cnbr[(int64_t)cptr[i] * TD_K + slot0 + lane] = (int32_t)(unsigned)(best & 0xffffffffull);
+}
+
+// ligand half of a hybrid ligand row (models/common.py:166-171): every other ligand atom of the graph, ascending index
+__global__ void hybrid_ligand_kernel(const int32_t *__restrict__ ptr, const int32_t *__restrict__ pptr,
+                                     const int32_t *__restrict__ gid, const int32_t *__restrict__ lig_node, int64_t Nl,
+                                     const int32_t *__restrict__ cptr, int32_t *__restrict__ cnbr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= Nl) return;
+    const int i = lig_node[qi];
+    const int g = gid[i];
+    const int lbeg = ptr[g] + (pptr[g + 1] - pptr[g]), lend = ptr[g + 1];
+    int32_t *row = cnbr + (int64_t)cptr[i] * TD_K;
+    for (int s = lane; s < lend - lbeg - 1; s += 64) {
+        const int j = lbeg + s;
+        row[s] = j >= i ? j + 1 : j;
+    }
+}
+
+// radius graph with a fan-out cap (rule: oracle/shims.py radius_neighbours): the first `cap` nodes j != i of the same
+// graph, in index order, with d2 = (dx*dx + dy*dy) + dz*dz < r*r (fp32, strict)
+__global__ __launch_bounds__(256) void radius_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
+                                                     const int32_t *__restrict__ gid, int64_t N, float r2, int cap,
+                                                     const int32_t *__restrict__ cptr, int32_t *__restrict__ cnbr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int g = gid[i];
+    const int beg = ptr[g], end = ptr[g + 1];
+    const float4 xi = x4[i];
+    int32_t *row = cnbr + (int64_t)cptr[i] * TD_K;
+    int cnt = 0;
+    for (int base = beg; base < end && cnt < cap; base += 64) {
+        const int j = base + lane;
+        bool hit = false;
+        if (j < end && j != (int)i) {
+            const float4 xj = x4[j];
+            hit = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z) < r2;
+        }
+        const unsigned long long m = __ballot(hit);
+        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (hit && rank < cap) row[rank] = j;
+        cnt += __popcll(m);
+    }
+}
+
+template <bool PROT_ONLY>
+static int launch_knn_general(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                              const int32_t *rows, int64_t count, int k, int max_graph_nodes, const int32_t *cptr,
+                              int32_t *cnbr, hipStream_t s) {
+    if (count == 0) return TD_OK;
+    dim3 grid((unsigned)((count + 3) / 4)), block(256);
+    if (max_graph_nodes > 0 && max_graph_nodes <= 384)
+        knn_general_kernel<6, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+    else if (max_graph_nodes <= 704)
+        knn_general_kernel<11, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+    else
+        knn_general_kernel<17, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// Fill the chunk table of a general graph.  mode 0: k-NN (any k <= 64) on every row; 1: hybrid (protein rows: k-NN over
+// the whole graph; ligand rows: the other ligand atoms + the k nearest protein atoms); 2: radius r with fan-out cap.
+int td_launch_graph_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                            const int32_t *prot_node, int64_t Np, const int32_t *lig_node, int64_t Nl, int64_t N, int k,
+                            float radius, int max_graph_nodes, const int32_t *cptr, int32_t *cnbr, int64_t NC, hipStream_t s) {
+    TD_CHECK_HIP(hipMemsetAsync(cnbr, 0xff, (size_t)NC * TD_K * sizeof(int32_t), s));
+    int rc = TD_OK;
+    if (mode == 0) {
+        rc = launch_knn_general<false>(x4, node_ptr, pptr, gid, nullptr, N, k, max_graph_nodes, cptr, cnbr, s);
+    } else if (mode == 1) {
+        rc = launch_knn_general<false>(x4, node_ptr, pptr, gid, prot_node, Np, k, max_graph_nodes, cptr, cnbr, s);
+        if (rc == TD_OK && Nl > 0) {
+            hybrid_ligand_kernel<<<dim3((unsigned)((Nl + 3) / 4)), dim3(256), 0, s>>>(node_ptr, pptr, gid, lig_node, Nl, cptr, cnbr);
+            TD_CHECK_HIP(hipGetLastError());
+            rc = launch_knn_general<true>(x4, node_ptr, pptr, gid, lig_node, Nl, k, max_graph_nodes, cptr, cnbr, s);
+        }
+    } else {
+        if (N > 0) {
+            radius_kernel<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, gid, N, radius * radius, k, cptr, cnbr);
+            TD_CHECK_HIP(hipGetLastError());
+        }
+    }
+    return rc;
+}
+
+// dense [N][width] view (-1 padded) of the chunked table: what td_knn (k != 32) and td_graph_build hand out
+__global__ void slots_to_dense_kernel(const int32_t *__restrict__ cptr, const int32_t *__restrict__ cnbr, int64_t N, int width,
+                                      int32_t *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * width) return;
+    const int64_t i = t / width;
+    const int c = (int)(t - i * width);
+    const int slots = (cptr[i + 1] - cptr[i]) * TD_K;
+    out[t] = c < slots ? cnbr[(int64_t)cptr[i] * TD_K + c] : -1;
+}
+
+int td_launch_slots_to_dense(const int32_t *cptr, const int32_t *cnbr, int64_t N, int width, int32_t *out, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    slots_to_dense_kernel<<<dim3((unsigned)((N * width + 255) / 256)), dim3(256), 0, s>>>(cptr, cnbr, N, width, out);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

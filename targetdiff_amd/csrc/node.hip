@@ -11,7 +11,6 @@
 // tile) and all 128 output columns (4 N-tiles -> 64 accumulator VGPRs).  A operands (the 32 x 128 h tile)
 // stay in registers for all six GEMMs; B operands (pre-packed fragment order) are staged through LDS in 16 KiB
 // chunks shared by the workgroup's 4 waves (gemm128_lds).
-#include <cstdlib>
 
 #include "td_device.h"
 #include "td_internal.h"
@@ -300,28 +299,21 @@ static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const i
     return g.blocks;
 }
 
-static bool np_split() {          // TD_NODE_PROJ_SPLIT=1: bf16 x 3 operand splitting (experimental, off by default)
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TD_NODE_PROJ_SPLIT");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
+static TdLdsOnce g_np_lds, g_nps_lds, g_egnn_node_lds;
 
 static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, unsigned y, unsigned threads, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_LDS_BYTES));
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(node_proj_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NPS_LDS_BYTES));
-        attr_set = true;
+    int rc;
+    // bf16 x 3 operand split (exact: an fp32 significand is three 8-bit pieces; fp32 accumulation) when every stage of the
+    // launch carries the pre-split weights and the model option asks for it
+    bool split = true;
+    for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.use_split && a.seg[i].st.projB3 != nullptr;
+    if (split) {
+        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_kernel<true>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_kernel<true><<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
+    } else {
+        if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel<false>), NP_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_kernel<false><<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
     }
-    bool split = np_split();
-    for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.projB3 != nullptr;
-    if (split) node_proj_kernel<true><<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
-    else node_proj_kernel<false><<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -429,12 +421,8 @@ __global__ __launch_bounds__(256, 2) void egnn_node_kernel(const float4 *__restr
 
 int td_launch_egnn_node(const TdEgnnLayer &L, const float *mi, float *h, int64_t N, hipStream_t s) {
     if (N == 0) return TD_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(egnn_node_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_LDS_BYTES));
-        attr_set = true;
-    }
+    int rc;
+    if ((rc = td_set_lds(g_egnn_node_lds, reinterpret_cast<const void *>(egnn_node_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
     egnn_node_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), NP_LDS_BYTES, s>>>(
         reinterpret_cast<const float4 *>(L.nodeB), L.nb1, L.nb2, mi, h, N);
     TD_CHECK_HIP(hipGetLastError());

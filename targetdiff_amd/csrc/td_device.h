@@ -75,6 +75,13 @@ __device__ __forceinline__ float td_sum_rows16(float v) {
     return a + b;
 }
 
+// maximum over the four rows of 16 lanes (lanes lo, lo + 16, lo + 32, lo + 48), result in all four
+__device__ __forceinline__ float td_max_groups(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return td_max_halves(fmaxf(a, b));
+}
+
 // Sum over the 32 lanes of a half-wave (lanes with equal l >> 5), result in every lane of the half.  All VALU.
 __device__ __forceinline__ float td_sum32(float v) {
     v = td_sum8(v);

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/targetdiff_hip.h"
 
 // ---- compile-time shape of the live configuration (configs/training.yml:9-42) ----------------------
@@ -27,6 +29,21 @@ void td_set_error(const char *fmt, ...);
             return TD_EHIP;                                                                      \
         }                                                                                        \
     } while (0)
+
+// Dynamic-LDS opt-in of a kernel, once per device (not per process: a second GPU used from the same process needs its
+// own hipFuncSetAttribute) and safe against concurrent first launches.
+struct TdLdsOnce {
+    std::atomic<unsigned long long> mask{0};
+};
+inline int td_set_lds(TdLdsOnce &once, const void *fn, size_t bytes) {
+    int dev = 0;
+    TD_CHECK_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (once.mask.load(std::memory_order_acquire) & bit) return TD_OK;
+    TD_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    once.mask.fetch_or(bit, std::memory_order_release);
+    return TD_OK;
+}
 
 // ---- packed weights (device pointers) ---------------------------------------------------------------
 // One edge MLP (hk/hv/xk/xv: Linear(340,128) -> LN -> ReLU -> Linear(128,out)), re-packed:
@@ -52,6 +69,7 @@ struct TdNodeStage {
     const float *q3Bias;   // [128]
     const float *projB3;   // optional: the same 5 matrices as bf16 piece triples [mat][8 kstep][3 piece][64 lane][4 ntile] x 8 bf16
     const float *q3B3;     // optional: q.net.3 likewise (nullptr: the fp32 path is the only one)
+    bool use_split;        // run the GEMMs on the exact 3-way bf16 operand split (model option "node_proj_split")
 };
 
 struct TdLayer {
@@ -98,8 +116,18 @@ struct TdSchedules {       // [T] each
     const float *abar;     // alphas_cumprod of the position schedule; nullptr when the model was created without it
 };
 
+// Per-model switches (td_model_set_option; defaults = the shipped configuration).  They live in the model, i.e. per device
+// and per handle -- nothing is read from the environment.
+struct TdOptions {
+    int h2x_fused = 1;             // one launch for the h2x stage's key + value halves (0: two launches, alpha through memory)
+    int node_proj_split = 1;       // node-side GEMMs on exact bf16 x 3 operand pieces with fp32 accumulation (0: fp32 MFMA)
+    int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
+    int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
+};
+
 struct td_model {
     td_config cfg;
+    TdOptions opt;
     float *blob;           // one device allocation holding every packed tensor
     size_t blob_floats;
     TdEmbed emb;
@@ -150,22 +178,9 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
                              const int32_t *lig_rows, int64_t Nl, float *Px, float *qx, const TdNodeStage &nx,
                              const int32_t *rows, const int32_t *count_ptr, float *P, float *q, const float *h, int64_t N,
                              hipStream_t s);
-// edge.hip
+// gate.hip -- rows: optional row list; chunk_node: dst node of every row of nbr / ew on general graphs (nullptr: row == node)
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
-                   const int32_t *count_ptr, float *ew, hipStream_t s);
-// mode: 0 x2h key pass, 1 x2h value pass (updates h), 2 h2x key pass, 3 h2x value pass (writes x4_out)
-int td_launch_edge_pass(int mode, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
-                        const float *ew, const float *P, const float *q, const int32_t *lig_node, int64_t count,
-                        float *h, float *alpha, hipStream_t s);
-void td_set_edge_timing(long long *buf, int nodes);
-// edge_fast.hip
-// rows / count_ptr: optional list of dst nodes and its device-side length (count = upper bound for the launch shape)
-int td_launch_edge_key(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
-                       const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                       float *alpha, hipStream_t s);
-int td_launch_edge_value(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
-                         const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
-                         hipStream_t s);
+                   const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node = nullptr);
 // edge16.hip (16x16x4 MFMA variants of the two passes; default)
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
@@ -178,6 +193,24 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            hipStream_t s);
+// edge16.hip, general graphs (chunked neighbour table, see graph.hip)
+int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr,
+                            const float *P, const float *q, const int32_t *chunk_node, const int32_t *chunks, int64_t count,
+                            float *alpha, hipStream_t s);
+int td_launch_edge_value16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr, const float *ew,
+                                  const float *P, const int32_t *cptr, const int32_t *rows, int64_t count, float *h,
+                                  const float *alpha, hipStream_t s);
+int td_launch_edge_xv16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *cnbr,
+                               const float *ew, const float *P, const int32_t *cptr, const int32_t *rows, int64_t count,
+                               const float *alpha, hipStream_t s);
+// graph.hip, general graphs
+int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *g_cbase,
+                     const int32_t *g_cl, const int32_t *g_lbase, int cpn_p, int64_t N, int32_t *cptr, int32_t *chunk_node,
+                     int32_t *lig_chunks, int32_t total_chunks, hipStream_t s);
+int td_launch_graph_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                            const int32_t *prot_node, int64_t Np, const int32_t *lig_node, int64_t Nl, int64_t N, int k,
+                            float radius, int max_graph_nodes, const int32_t *cptr, int32_t *cnbr, int64_t NC, hipStream_t s);
+int td_launch_slots_to_dense(const int32_t *cptr, const int32_t *cnbr, int64_t N, int width, int32_t *out, hipStream_t s);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,
                    int classes, float *pred_pos, float *pred_v, float *lig_h, hipStream_t s);

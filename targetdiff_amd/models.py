@@ -103,20 +103,26 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
     def __init__(self, num_blocks, num_layers, hidden_dim, n_heads=1, k=32, num_r_gaussian=50, edge_feat_dim=0,
                  num_node_types=8, act_fn='relu', norm=True, cutoff_mode='radius', ew_net_type='r',
                  num_init_x2h=1, num_init_h2x=0, num_x2h=1, num_h2x=1, r_max=10., x2h_out_fc=True,
-                 sync_twoup=False):
+                 sync_twoup=False, r=None, max_num_neighbors=32):
         super().__init__()
         unsupported = []
         if num_blocks != 1: unsupported.append(f'num_blocks={num_blocks}')
-        if cutoff_mode != 'knn': unsupported.append(f'cutoff_mode={cutoff_mode!r}')
+        if cutoff_mode not in capi.CUTOFF_MODES: unsupported.append(f'cutoff_mode={cutoff_mode!r}')
         if ew_net_type != 'global': unsupported.append(f'ew_net_type={ew_net_type!r}')
         if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
         if num_x2h != 1 or num_h2x != 1: unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x}')
         if x2h_out_fc or sync_twoup: unsupported.append(f'x2h_out_fc={x2h_out_fc}/sync_twoup={sync_twoup}')
-        if (hidden_dim, n_heads, k, num_r_gaussian, edge_feat_dim) != (128, 16, 32, 20, 4):
-            unsupported.append(f'shape {(hidden_dim, n_heads, k, num_r_gaussian, edge_feat_dim)}')
+        if (hidden_dim, n_heads, num_r_gaussian, edge_feat_dim) != (128, 16, 20, 4):
+            unsupported.append(f'shape {(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim)}')
+        if not 1 <= k <= capi.MAX_FANIN: unsupported.append(f'knn={k} (1..{capi.MAX_FANIN})')
         if unsupported:
-            raise NotImplementedError('libtargetdiff_hip.so is built for the live configuration of '
+            raise NotImplementedError('libtargetdiff_hip.so is built for the live architecture of '
                                       'configs/training.yml:9-42; unsupported: ' + ', '.join(unsupported))
+        # graph construction (:276-286) is a run-time choice: knn (any k <= 64; k = 32 is the live configuration and the
+        # fast path), hybrid (models/common.py:165-212), radius (dead code in the reference: `self.r` is never assigned,
+        # :278 -- here r defaults to r_max and the fan-out is capped at max_num_neighbors, torch_geometric's default 32)
+        self.r = float(r if r is not None else r_max)
+        self.max_num_neighbors = int(max_num_neighbors)
         self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
         self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
         self.cutoff_mode, self.ew_net_type = cutoff_mode, ew_net_type
@@ -167,7 +173,7 @@ def get_refine_net(refine_net_type, config):
         k=g('knn'), edge_feat_dim=g('edge_feat_dim'), num_r_gaussian=g('num_r_gaussian'),
         num_node_types=g('num_node_types'), act_fn=g('act_fn'), norm=g('norm'), cutoff_mode=g('cutoff_mode'),
         ew_net_type=g('ew_net_type'), num_x2h=g('num_x2h'), num_h2x=g('num_h2x'), r_max=g('r_max'),
-        x2h_out_fc=g('x2h_out_fc'), sync_twoup=g('sync_twoup'))
+        x2h_out_fc=g('x2h_out_fc'), sync_twoup=g('sync_twoup'), r=g('r'), max_num_neighbors=g('max_num_neighbors', 32))
 
 
 # ------------------------------------------------------------------------------------------ schedules
@@ -315,7 +321,8 @@ class ScorePosNet3D(nn.Module):
             cfg = dict(hidden_dim=rn.hidden_dim, n_heads=rn.n_heads, knn=rn.k, num_layers=rn.num_layers,
                        num_r_gaussian=rn.num_r_gaussian, edge_feat_dim=rn.edge_feat_dim,
                        protein_feat_dim=self.protein_atom_feature_dim, ligand_num_classes=self.num_classes,
-                       num_timesteps=self.num_timesteps)
+                       num_timesteps=self.num_timesteps, cutoff_mode=rn.cutoff_mode, radius=rn.r,
+                       max_num_neighbors=rn.max_num_neighbors)
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             self._native_model = capi.NativeModel(cfg, self.state_dict(), sched, device=device)
             self._native_key = key

@@ -364,3 +364,38 @@ def test_non_current_device_is_honoured(model):
                                noise_source=lambda s, n, like: torch.full_like(like, 0.25))
         outs.append(r['pos'].cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------ C3 at full size
+def test_c3_full_size_pack_reproduces_reference_golden(model):
+    """BASELINE config 3 at its full size (32 pockets x 100 samples, N = 1.04 M nodes, 3200 graphs): the reference's
+    forward on one sample per pocket (graphs are independent) must come out of the full pack at the slots those samples
+    occupy -- through the stateless forward and through the session."""
+    from oracle.make_golden_r2 import c3_pockets
+    from targetdiff_amd import capi, workloads
+    dev = _dev()
+    g = load_golden('forward_c3.npz')
+    pockets = c3_pockets()
+    slot = 37                                              # sample index inside each pocket's 100 replicas
+    b = workloads.pack_samples(pockets, 100, [25] * 3200)
+    gen = torch.Generator().manual_seed(99)
+    lpos, lv = workloads.init_ligand(b, generator=gen, spread=2.0)          # un-centred filler for the other 3168 graphs
+    idx = torch.cat([torch.arange(25) + (p * 100 + slot) * 25 for p in range(32)])
+    lpos[idx] = torch.from_numpy(g['ligand_pos_uncentred'])
+    lv[idx] = torch.from_numpy(g['ligand_v'].astype(np.int64))
+    b = b.to(dev)
+    nat = model._native(dev)
+    pptr, lptr = nat.graph_ptr(b.protein_element_batch, 3200), nat.graph_ptr(b.ligand_element_batch, 3200)
+    ppos, lposd = b.protein_pos.clone(), lpos.to(dev)
+    nat.center_pos(ppos, pptr, lposd, lptr)
+    assert _maxdiff(lposd[idx.to(dev)], g['ligand_pos']) <= 1e-5
+    pv, lvd = b.protein_atom_feature.float(), lv.to(dev)
+    preds = nat.model_forward(ppos, pv, pptr, lposd, lvd, lptr, max_graph_nodes=325, want_final_h=False)
+    sel = idx.to(dev)
+    assert _maxdiff(preds['pred_ligand_pos'][sel], g['pred_ligand_pos']) <= TOL_STEP
+    assert _maxdiff(preds['pred_ligand_v'][sel], g['pred_ligand_v']) <= 2e-4
+    assert _maxdiff(preds['final_ligand_h'][sel], g['final_ligand_h']) <= 2e-4
+    sess = capi.NativeSession(nat, ppos, pv, pptr, lptr, lposd.shape[0], 325)
+    ps = sess.forward(lposd, lvd)
+    for key in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+        assert torch.equal(ps[key], preds[key]), key

@@ -445,51 +445,6 @@ def test_fails_loudly_without_device_tensors(model):
 
 
 # ------------------------------------------------------------------------------------------ alternative kernel paths
-_ALT_SCRIPT = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
-from conftest import load_golden, small_inputs
-from oracle import weights
-from targetdiff_amd.models import ScorePosNet3D
-dev = torch.device('cuda:0')
-m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
-m.load_state_dict(weights.make_state_dict(2021), strict=False)
-m = m.to(dev).eval()
-inp = small_inputs(load_golden('forward_small.npz'))
-with torch.no_grad():
-    out = m(inp['protein_pos'].to(dev), inp['protein_v'].to(dev), inp['batch_protein'].to(dev),
-            inp['ligand_pos'].to(dev), inp['ligand_v'].to(dev), inp['batch_ligand'].to(dev))
-np.savez(sys.argv[2], **{k: out[k].cpu().numpy() for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h')})
-'''
-
-
-@pytest.mark.parametrize('env,bitwise', [({'TD_H2X_FUSED': '0'}, True), ({'TD_EDGE_IMPL': 'fast32'}, False),
-                                         ({'TD_EDGE_IMPL': 'plain'}, False), ({'TD_NODE_PROJ_SPLIT': '1'}, False)])
-def test_alternative_kernel_paths_agree(model, golden_small, tmp_path, env, bitwise):
-    """The debug switches select older kernels: the unfused h2x stage must match the fused one bit for bit (same
-    arithmetic, alpha through memory instead of registers); the 32x32x2 and the materialised-k/v kernels re-associate
-    differently and must agree within the fp32 tolerance; so must the experimental node projections that split both GEMM
-    operands exactly into three bf16 pieces (6 of the 9 piece products on the bf16 matrix cores, fp32 accumulate)."""
-    import os
-    import subprocess
-    import sys
-    dev = _dev()
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out_path = str(tmp_path / 'alt.npz')
-    e = dict(os.environ)
-    e.update(env)
-    subprocess.run([sys.executable, '-c', _ALT_SCRIPT, root, out_path], check=True, env=e, timeout=600)
-    alt = np.load(out_path)
-    ref = _forward(model, small_inputs(golden_small), dev)
-    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h'):
-        a, b = alt[k], ref[k].cpu().numpy()
-        if bitwise:
-            assert np.array_equal(a, b), k
-        else:
-            assert np.max(np.abs(a - b)) < (TOL_X if k == 'pred_ligand_pos' else TOL_H), k
-
-
-# ------------------------------------------------------------------------------------------ other forward consumers
 def test_return_all_vs_reference_golden(model, golden_small):
     """forward(return_all=True) (models/molopt_score_model.py:360-367): block input and block output predictions."""
     dev = _dev()

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f'{name} declared in targetdiff_hip.h but not exported'
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
-    assert lib.td_abi_version() == 1
+    assert lib.td_abi_version() == 2
 
 
 def test_weight_blob_layout_matches_library():
@@ -47,10 +47,21 @@ def test_unsupported_config_is_rejected_not_emulated():
     dummy = (ctypes.c_float * 4)()
     rc = lib.td_model_create(ctypes.byref(cfg), dummy, 4, None, 0, ctypes.byref(h))
     assert rc == -1 and b'unsupported configuration' in lib.td_last_error()
+    # graph construction is a run-time choice (knn with k <= 64, hybrid, radius); anything else is refused by both layers
+    cfg2 = capi.TdConfig(hidden_dim=128, n_heads=16, knn=65, num_layers=9, num_r_gaussian=20, edge_feat_dim=4,
+                         protein_feat_dim=27, ligand_num_classes=13, num_timesteps=1000)
+    assert lib.td_model_create(ctypes.byref(cfg2), dummy, 4, None, 0, ctypes.byref(h)) == -1
+    cfg3 = capi.TdConfig(hidden_dim=128, n_heads=16, knn=32, num_layers=9, num_r_gaussian=20, edge_feat_dim=4,
+                         protein_feat_dim=27, ligand_num_classes=13, num_timesteps=1000, cutoff_mode=2, radius=0.0,
+                         max_num_neighbors=32)
+    assert lib.td_model_create(ctypes.byref(cfg3), dummy, 4, None, 0, ctypes.byref(h)) == -1      # radius mode needs r > 0
     from targetdiff_amd.models import ScorePosNet3D
-    bad = dict(weights.DEFAULT_MODEL_CONFIG, cutoff_mode='radius')
-    with pytest.raises(NotImplementedError):
-        ScorePosNet3D(bad, 27, 13)
+    for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='r'), dict(num_blocks=2), dict(hidden_dim=256)):
+        with pytest.raises(NotImplementedError):
+            ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **bad), 27, 13)
+    for ok in (dict(cutoff_mode='hybrid'), dict(knn=48), dict(cutoff_mode='radius', r=6.0, max_num_neighbors=16)):
+        m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **ok), 27, 13)
+        assert len(m.state_dict()) == 384             # the weights do not depend on the graph construction
 
 
 def test_model_mirror_state_dict_and_loud_failure(state_dict):

@@ -80,3 +80,61 @@ def test_restatement_forward_c5_shape(state_dict):
     assert np.max(np.abs(preds['pred_ligand_pos'].numpy() - g['pred_ligand_pos'])) < 2e-5
     assert np.max(np.abs(preds['pred_ligand_v'].numpy() - g['pred_ligand_v'])) < 2e-4
     assert np.max(np.abs(preds['final_ligand_h'].numpy() - g['final_ligand_h'])) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------ other graph constructions
+def _csr_rows(g):
+    rp, col = g['row_ptr'], g['col']
+    return [sorted(col[rp[i]:rp[i + 1]].tolist()) for i in range(len(rp) - 1)]
+
+
+def _table_rows(nbr):
+    return [sorted(int(j) for j in row if j >= 0) for row in nbr.tolist()]
+
+
+def _variant_batch(name):
+    from oracle.make_golden import small_batch
+    from oracle.make_golden_r2 import hybrid_small_batch
+    from targetdiff_amd import workloads
+    if name == 'forward_1h36x2_hybrid':
+        pocket, sizes = pocket_1h36()
+        return workloads.pack_samples(pocket, 2, sizes[:2])
+    return (hybrid_small_batch if 'hybrid' in name else small_batch)()[0]
+
+
+import pytest
+
+
+@pytest.mark.parametrize('name,cfg', [('forward_small_k16', dict(knn=16)), ('forward_small_k48', dict(knn=48)),
+                                      ('forward_small_k64', dict(knn=64)), ('forward_small_hybrid', dict(cutoff_mode='hybrid')),
+                                      ('forward_1h36x2_hybrid', dict(cutoff_mode='hybrid'))])
+def test_restatement_other_graphs_vs_reference(state_dict, name, cfg):
+    """k-NN with k != 32 and cutoff_mode='hybrid' (models/uni_transformer.py:276-286, models/common.py:165-212): the
+    reference's own edge lists (as neighbour sets) and outputs."""
+    from oracle import weights
+    g = load_golden(name + '.npz')
+    b = _variant_batch(name)
+    full = dict(weights.DEFAULT_MODEL_CONFIG, **cfg)
+    # the fixtures hold centred ligand positions; centre the protein the same way
+    ppos, _, _ = R.center_positions(b.protein_pos, torch.zeros(b.ligand_element_batch.numel(), 3), b.protein_element_batch,
+                                    b.ligand_element_batch)
+    col = {}
+    preds = R.model_forward(state_dict, full, ppos, b.protein_atom_feature.float(), b.protein_element_batch,
+                            torch.from_numpy(g['ligand_pos']), torch.from_numpy(g['ligand_v'].astype(np.int64)),
+                            b.ligand_element_batch, collect=col)
+    assert _table_rows(col['nbr']) == _csr_rows(g)
+    assert np.max(np.abs(preds['pred_ligand_pos'].numpy() - g['pred_ligand_pos'])) < 2e-5
+    assert np.max(np.abs(preds['pred_ligand_v'].numpy() - g['pred_ligand_v'])) < 2e-4
+    assert np.max(np.abs(preds['final_ligand_h'].numpy() - g['final_ligand_h'])) < 2e-4
+    assert np.max(np.abs(torch.stack(col['x_layers']).numpy() - g['x_layers'])) < 2e-5
+
+
+def test_radius_rule_known_answers():
+    """The project's radius-with-cap rule on a hand-checkable case."""
+    from oracle import shims
+    x = torch.tensor([[0., 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [0.5, 0, 0], [10, 0, 0], [10.5, 0, 0]])
+    batch = torch.tensor([0, 0, 0, 0, 0, 1, 1])
+    t = shims.radius_neighbours(x, 1.5, batch, 2)
+    assert t.tolist() == [[1, 4], [0, 2], [1, 3], [2, -1], [0, 1], [6, -1], [5, -1]]
+    t = shims.radius_neighbours(x, 1.0, batch, 4)             # strict: d = 1.0 is outside
+    assert t[0].tolist() == [4, -1, -1, -1] and t[1].tolist() == [4, -1, -1, -1] and t[5].tolist() == [6, -1, -1, -1]
