@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -o p -- \
-      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-full-run ${BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
