@@ -846,8 +846,12 @@ __global__ __launch_bounds__(XV16_WAVES * 64) void edge_xv16_ragged_kernel(Args1
 }
 
 // ================================================================================================ launchers
+// Workgroups of a row-loop kernel: one per CU (256) when there is a row per wave for all of them.  With fewer rows the
+// waves of a workgroup would queue on their SIMD's shared matrix / vector pipe while other CUs idle, so small launches
+// spread over as many workgroups as there are rows (up to one per CU) and leave part of each workgroup's waves without a row.
 static int grid16(int64_t count, int waves) {
     int64_t g = (count + waves - 1) / waves;
+    if (g < 256) g = count < 256 ? count : 256;
     if (g > 256) g = 256;
     if (g >= 8) g = (g / 8) * 8;
     return (int)(g < 1 ? 1 : g);

@@ -325,7 +325,7 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
     if (!rows2 || N2 == 0 || (mask2 & 0x1fu) == 0) { rows2 = nullptr; N2 = 0; mask2 = 0; }
     // few rows (ligand atoms only): one wave per workgroup and one independent unit per blockIdx.y, so that the launch
     // spreads over the whole chip; many rows: 4 waves share each staged B chunk and keep the A tile for all matrices
-    const bool small = N <= 16384 && !rows2 && !count_ptr;
+    const bool small = N <= TD_SMALL_BATCH_ROWS && !rows2 && !count_ptr;
     NpArgs a;
     a.nseg = 0;
     unsigned total = 0;
@@ -335,7 +335,9 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
         return np_launch(a, h, total, units, 64u, s);
     }
     if (rows2) total += np_fill(a.seg[a.nseg++], st, rows2, nullptr, N2, mask2, P, q, true, 128);
-    total += np_fill(a.seg[a.nseg++], st, rows, count_ptr, N, mat_mask, P, q, false, 128);
+    // a small batch (N bounds the device-side count) cannot fill the chip with one workgroup per 128 rows walking through
+    // all six GEMMs: one workgroup per (128 rows, matrix unit) instead -- 5x the parallelism, same arithmetic
+    total += np_fill(a.seg[a.nseg++], st, rows, count_ptr, N, mat_mask, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
     return np_launch(a, h, total, 1u, 256u, s);
 }
 
@@ -351,8 +353,8 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
     a.nseg = 0;
     unsigned total = 0;
     if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
-    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, false, 128);
-    total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, false, 128);
+    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, N <= TD_SMALL_BATCH_ROWS, 128);
+    total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
     return np_launch(a, h, total, 1u, 256u, s);
 }
 

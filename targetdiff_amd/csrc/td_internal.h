@@ -19,6 +19,7 @@ constexpr int TD_SLOTK = 24;     // K columns per source-class slot of the first
 constexpr int TD_SLOT_STEPS = TD_SLOTK / 2;   // 12 MFMA k-steps per slot
 constexpr int TD_KSTEPS = TD_H / 2;           // 64 k-steps (32x32x2) for a 128-deep contraction
 constexpr int TD_MAXC = 16;      // ligand classes padded
+constexpr int TD_SMALL_BATCH_ROWS = 16384;   // below this many rows a launch is shaped for latency (more, smaller workgroups)
 
 void td_set_error(const char *fmt, ...);
 #define TD_CHECK_HIP(expr)                                                                       \
