@@ -209,6 +209,9 @@ def build_model(dev, args=None):
     model = model.to(dev).eval()
     if args is not None and args.fp32_node_gemms:
         model._native(dev).set_option('node_proj_split', 0)
+    for kv in (args.option if args is not None else []):
+        name, value = kv.split('=')
+        model._native(dev).set_option(name, int(value))
     return model
 
 
@@ -333,6 +336,7 @@ def main():
     ap.add_argument('--cutoff-mode', default='knn', choices=['knn', 'hybrid', 'radius'])
     ap.add_argument('--radius', type=float, default=6.0, help='cut-off (A) of --cutoff-mode radius')
     ap.add_argument('--cap', type=int, default=32, help='fan-out cap of --cutoff-mode radius (C5 sweep)')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE', help='td_model_set_option (experiments)')
     ap.add_argument('--fp32-node-gemms', action='store_true', help='node-side GEMMs on fp32 MFMA instead of the exact bf16 x 3 split')
     args = ap.parse_args()
     # `--gpus N` without a launcher: become the launcher (N ranks of this same command line), exit with their status
