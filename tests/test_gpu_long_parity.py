@@ -399,3 +399,23 @@ def test_c3_full_size_pack_reproduces_reference_golden(model):
     ps = sess.forward(lposd, lvd)
     for key in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
         assert torch.equal(ps[key], preds[key]), key
+
+
+def test_overlapped_batches_equal_sequential_batches(model):
+    """overlap_batches=True advances the sample batches of a pocket together, one HIP stream each; with injected draws
+    every element of the 7-tuple is the same bits as in the sequential order."""
+    from oracle import draws
+    from targetdiff_amd import sampling, workloads
+    dev = _dev()
+    pocket = workloads.synthetic_pocket(77, 150)
+    src = draws.Source(6100, dev)
+    steps = 12
+    noise_source = lambda bi, st, name, like: src(bi * (steps + 1) + st + 1, name, like)
+    sizes = [10 + (k % 7) for k in range(22)]
+    res = [sampling.sample_diffusion_ligand(model, pocket, 22, batch_size=5, device=dev, num_steps=steps, ligand_num_atoms=sizes,
+                                            noise_source=noise_source, overlap_batches=ov) for ov in (False, True)]
+    assert len(res[0][6]) == len(res[1][6]) == 5
+    for a_list, b_list in zip(res[0][:6], res[1][:6]):
+        assert len(a_list) == len(b_list) == 22
+        for a, b in zip(a_list, b_list):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
