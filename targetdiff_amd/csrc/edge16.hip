@@ -133,7 +133,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
     const int cls = xi.w > 0.5f ? 0 : 1;
     float dist[2];
     int slot[2];
-    bool any_a = false, any_b = false;
+    bool has[2][2];        // [source class][edge block]: does any edge of the block have that source class (wave-uniform)
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
         ed.valid[eb] = r.j[eb] >= 0;
@@ -143,10 +143,10 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
         dist[eb] = sqrtf(rx * rx + ry * ry + rz * rz);
         ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
         slot[eb] = xj.w > 0.5f ? 0 : 1;
-        any_a |= ed.valid[eb] && slot[eb] == 0;
-        any_b |= ed.valid[eb] && slot[eb] == 1;
+        has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
+        has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
     }
-    const bool has_a = __ballot(any_a) != 0ull, has_b = __ballot(any_b) != 0ull;
+    const bool has_a = has[0][0] || has[0][1], has_b = has[1][0] || has[1][1];
     // dst-side projection P_i rides in the table's padding column k = 21 (k-step 5, lane group 1)
     float gv[2][E16_STEPS];
 #pragma unroll
@@ -171,6 +171,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) {
+                if (!has[sl][eb]) continue;        // no edge of this block has this source class: its B columns are all zero
                 const float bv = (ed.valid[eb] && slot[eb] == sl) ? gv[eb][s] : 0.f;   // B: g_k(d_edge) for the edge's slot
 #pragma unroll
                 for (int hb = 0; hb < 8; ++hb) acc[eb][hb] = td_mfma16(av[hb], bv, acc[eb][hb]);
