@@ -1397,17 +1397,29 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
                               d_final_ligand_h, s);
     }
     {
+        // first kernel of the step: also zeroes the row-list counters and the ligand rows' forward-reach flags
         ProfScope ps(PC_COMPOSE, s);
-        if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
+        TdStepReset rs;
+        rs.c0 = S->dirty_count; rs.n0 = 1;
+        rs.c1 = S->fwd_counts; rs.n1 = 2;
+        rs.c2 = S->hop_count; rs.n2 = TD_HOP_LEVELS;
+        rs.flags2 = S->use_fwd ? S->flags2 : nullptr;
+        if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, &rs)) != TD_OK) return rc;
     }
     {
         ProfScope ps(PC_KNN, s);
         if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
-                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, s)) != TD_OK) return rc;
+                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s)) != TD_OK) return rc;
         if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
         if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
-        if (S->use_fwd && (rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest,
-                                                        S->fwd_counts, s)) != TD_OK) return rc;
+        // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
+        // clears it; without the forward reach a memset does
+        if (S->use_fwd) {
+            if ((rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest, S->fwd_counts,
+                                              S->clean, s)) != TD_OK) return rc;
+        } else {
+            TD_CHECK_HIP(hipMemsetAsync(S->clean, 0, (size_t)N, s));
+        }
     }
     {
         ProfScope ps(PC_GATE, s);
@@ -1420,7 +1432,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
-    if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s)) != TD_OK) return rc;
+    if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;
     float4 *xf = nullptr;
     const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s};
     if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels,

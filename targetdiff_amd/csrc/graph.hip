@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
     const int32_t *__restrict__ gid, const int32_t *__restrict__ prot_rows, int64_t Np,
     const unsigned long long *__restrict__ skeys, const int32_t *__restrict__ snbr, const float *__restrict__ h0,
     const float *__restrict__ h1s, const float *__restrict__ ews, int32_t *__restrict__ nbr, float *__restrict__ h,
-    float *__restrict__ ew, uint8_t *__restrict__ clean) {
+    float *__restrict__ ew, uint8_t *__restrict__ clean, uint8_t *__restrict__ flags2) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= Np) return;
@@ -279,37 +279,67 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
     const float2 hv = *reinterpret_cast<const float2 *>((is_clean ? h1s : h0) + i * TD_H + 2 * lane);
     *reinterpret_cast<float2 *>(h + i * TD_H + 2 * lane) = hv;
     if (is_clean && lane < TD_K) ew[i * TD_K + lane] = ews[i * TD_K + lane];
-    if (lane == 0) clean[i] = is_clean ? 1 : 0;
+    if (lane == 0) {
+        clean[i] = is_clean ? 1 : 0;
+        if (flags2) flags2[i] = 0;             // forward-reach flag of this row, set later in the step
+    }
 }
 
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, hipStream_t s) {
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s) {
     if (Np == 0) return TD_OK;
     knn_merge_kernel<<<dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, pptr, gid, prot_rows, Np, skeys,
-                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean);
+                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean, flags2);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
-// dirty rows = ligand rows + protein rows whose neighbour row changed; order is irrelevant (rows are independent)
-__global__ void compact_dirty_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4, int64_t N,
-                                     int32_t *__restrict__ rows, int32_t *__restrict__ count) {
+// Slots of a block-wide compaction into up to L lists at once: one atomicAdd per block and list (a wave-level ballot per
+// list, wave totals through LDS).  flag[l] -> slot[l] = index in list l (valid where flag[l]).  blockDim.x = 256 (4 waves).
+// Order inside a list is irrelevant to the arithmetic (rows are independent); the atomics only hand out slots.
+template <int L>
+__device__ __forceinline__ void td_block_slots(const bool (&flag)[L], int32_t *__restrict__ counters, int (&slot)[L]) {
+    __shared__ int s_cnt[L][4];
+    __shared__ int s_base[L];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long m[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        m[l] = __ballot(flag[l]);
+        if (lane == 0) s_cnt[l][wave] = __popcll(m[l]);
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        const int l = threadIdx.x;
+        const int total = s_cnt[l][0] + s_cnt[l][1] + s_cnt[l][2] + s_cnt[l][3];
+        s_base[l] = total ? atomicAdd(counters + l, total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_cnt[l][w];
+        slot[l] = s_base[l] + before + __popcll(m[l] & below);
+    }
+}
+
+// dirty rows = ligand rows + protein rows whose neighbour row changed; order is irrelevant (rows are independent).
+// `count` was zeroed by the step's first kernel (ligand_update_kernel).
+__global__ __launch_bounds__(256) void compact_dirty_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4,
+                                                            int64_t N, int32_t *__restrict__ rows, int32_t *__restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool dirty = i < N && (x4[i].w > 0.5f || !clean[i]);
-    const unsigned long long m = __ballot(dirty);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0);
-    if (dirty) rows[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+    const bool flag[1] = {i < N && (x4[i].w > 0.5f || !clean[i])};
+    int slot[1];
+    td_block_slots<1>(flag, count, slot);
+    if (flag[0]) rows[slot[0]] = (int32_t)i;
 }
 
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s) {
     if (N == 0) return TD_OK;
-    TD_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     compact_dirty_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(clean, x4, N, rows, count);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
@@ -331,31 +361,28 @@ __global__ void forward_reach_kernel(const uint8_t *__restrict__ clean, const fl
     if (d) flags2[i] = 1;                                  // racing writers store the same value
 }
 
-// rows with flags != 0 -> rows_on / count[0]; the others -> rows_off / count[1]
-__global__ void compact_split_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows_on,
-                                     int32_t *__restrict__ rows_off, int32_t *__restrict__ count) {
+// rows with flags != 0 -> rows_on / count[0]; the others -> rows_off / count[1].  Last reader of the step's `clean` flags:
+// clears them (`zero_after`) for their second life as receptive-field level flags (td_launch_hop_levels).
+__global__ __launch_bounds__(256) void compact_split_kernel(const uint8_t *__restrict__ flags, int64_t N,
+                                                            int32_t *__restrict__ rows_on, int32_t *__restrict__ rows_off,
+                                                            int32_t *__restrict__ count, uint8_t *__restrict__ zero_after) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < N, on = in && flags[i];
-    const unsigned long long m = __ballot(on), z = __ballot(in && !on);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int b1 = 0, b0 = 0;
-    if (lane == 0 && m) b1 = atomicAdd(count, __popcll(m));
-    if (lane == 0 && z) b0 = atomicAdd(count + 1, __popcll(z));
-    b1 = __shfl(b1, 0);
-    b0 = __shfl(b0, 0);
-    if (on) rows_on[b1 + __popcll(m & below)] = (int32_t)i;
-    else if (in) rows_off[b0 + __popcll(z & below)] = (int32_t)i;
+    const bool flag[2] = {on, in && !on};
+    int slot[2];
+    td_block_slots<2>(flag, count, slot);
+    if (on) rows_on[slot[0]] = (int32_t)i;
+    else if (in) rows_off[slot[1]] = (int32_t)i;
+    if (in && zero_after) zero_after[i] = 0;
 }
 
+// flags2 and counts2 were zeroed earlier in the step (knn_merge_kernel / ligand_update_kernel); `clean` is cleared here.
 int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
-                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, hipStream_t s) {
+                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, uint8_t *clean_to_zero, hipStream_t s) {
     if (N == 0) return TD_OK;
-    TD_CHECK_HIP(hipMemsetAsync(flags2, 0, (size_t)N, s));
-    TD_CHECK_HIP(hipMemsetAsync(counts2, 0, 2 * sizeof(int32_t), s));
     forward_reach_kernel<<<dim3((unsigned)((N * 32 + 255) / 256)), dim3(256), 0, s>>>(clean, x4, nbr, N, flags2);
     TD_CHECK_HIP(hipGetLastError());
-    compact_split_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags2, N, rows_on, rows_off, counts2);
+    compact_split_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s>>>(flags2, N, rows_on, rows_off, counts2, clean_to_zero);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -410,30 +437,30 @@ __global__ void expand_level_kernel(const int32_t *__restrict__ nbr, int64_t N, 
 
 // all level lists in one pass: level k = rows with 0 < flags <= k
 template <int LEVELS>
-__global__ void compact_levels_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
-                                      int32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void compact_levels_kernel(const uint8_t *__restrict__ flags, int64_t N, int32_t *__restrict__ rows,
+                                                             int32_t *__restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int f = i < N ? (int)flags[i] : 0;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    bool flag[LEVELS];
 #pragma unroll
-    for (int k = 0; k < LEVELS; ++k) {
-        const bool on = f != 0 && f <= k + 1;
-        const unsigned long long m = __ballot(on);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(counts + k, __popcll(m));
-        base = __shfl(base, 0);
-        if (on) rows[(size_t)k * N + base + __popcll(m & below)] = (int32_t)i;
-    }
+    for (int k = 0; k < LEVELS; ++k) flag[k] = f != 0 && f <= k + 1;
+    int slot[LEVELS];
+    td_block_slots<LEVELS>(flag, counts, slot);
+#pragma unroll
+    for (int k = 0; k < LEVELS; ++k)
+        if (flag[k]) rows[(size_t)k * N + slot[k]] = (int32_t)i;
 }
 
 // rows: [levels][N] row lists, counts: [levels] device-side lengths
+// `zeroed`: flags and counts were already cleared earlier in the step (compact_split_kernel / ligand_update_kernel)
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
-                         int32_t *rows, int32_t *counts, int levels, hipStream_t s) {
+                         int32_t *rows, int32_t *counts, int levels, hipStream_t s, bool zeroed) {
     if (N == 0 || levels <= 0) return TD_OK;
     if (levels > TD_HOP_LEVELS) levels = TD_HOP_LEVELS;
-    TD_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)N, s));
-    TD_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)TD_HOP_LEVELS, s));
+    if (!zeroed) {
+        TD_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)N, s));
+        TD_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)TD_HOP_LEVELS, s));
+    }
     if (Nl > 0) expand_hop_kernel<<<dim3((unsigned)((Nl * 32 + 255) / 256)), dim3(256), 0, s>>>(lig_node, Nl, nullptr, nbr, 1, flags);
     TD_CHECK_HIP(hipGetLastError());
     for (int k = 2; k <= levels; ++k) {
@@ -452,11 +479,19 @@ int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr
 }
 
 // per-step refresh of the ligand rows: x4 = (pos, 1), h = Linear(one_hot(v)) ; 1
+// First kernel of a session step, so it also resets the step's bookkeeping (instead of a handful of memset launches): the
+// device-side counters of the row lists and the forward-reach flags of the ligand rows (knn_merge_kernel clears the
+// protein rows').
 __global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restrict__ lpos, const int64_t *__restrict__ lv,
                                                             const int32_t *__restrict__ lig_node, int64_t Nl, int C,
                                                             const float *__restrict__ WlT, const float *__restrict__ bl,
-                                                            float *__restrict__ h, float4 *__restrict__ x4) {
+                                                            float *__restrict__ h, float4 *__restrict__ x4, TdStepReset rs) {
     const int n = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (rs.c0 && n < rs.n0) rs.c0[n] = 0;
+        if (rs.c1 && n < rs.n1) rs.c1[n] = 0;
+        if (rs.c2 && n < rs.n2) rs.c2[n] = 0;
+    }
     const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
     const float bias = bl[n];
     for (int a = 0; a < TD_COMPOSE_ATOMS; ++a) {
@@ -466,7 +501,10 @@ __global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restr
         int v = (int)lv[at];
         v = v < 0 ? 0 : (v >= C ? C - 1 : v);
         h[p * TD_H + n] = WlT[v * TD_H + n] + bias;
-        if (n == 0) x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
+        if (n == 0) {
+            x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
+            if (rs.flags2) rs.flags2[p] = 0;
+        }
     }
 }
 
@@ -562,11 +600,12 @@ int td_launch_compose(const td_model *m, const float *ppos, const float *pv, con
 }
 
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
-                            float *h, float4 *x4, hipStream_t s) {
+                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset) {
     if (Nl == 0) return TD_OK;
     unsigned nb = (unsigned)((Nl + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
+    const TdStepReset rs = reset ? *reset : TdStepReset{};
     ligand_update_kernel<<<dim3(nb), dim3(128), 0, s>>>(lpos, lv, lig_node, Nl, m->cfg.ligand_num_classes, m->emb.WlT,
-                                                      m->emb.bl, h, x4);
+                                                      m->emb.bl, h, x4, rs);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

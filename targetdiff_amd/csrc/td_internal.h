@@ -157,18 +157,24 @@ int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, hipStream_t s);
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
 int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
-                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, hipStream_t s);
+                            int32_t *rows_on, int32_t *rows_off, int32_t *counts2, uint8_t *clean_to_zero, hipStream_t s);
 int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_t max_rows, const float *hs, float *h,
                            hipStream_t s);
 constexpr int TD_HOP_LEVELS = 4;
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
-                         int32_t *rows, int32_t *counts, int levels, hipStream_t s);
+                         int32_t *rows, int32_t *counts, int levels, hipStream_t s, bool zeroed = false);
+// bookkeeping a session step resets in its first kernel: up to three counter arrays and the ligand rows' forward-reach flags
+struct TdStepReset {
+    int32_t *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;
+    int n0 = 0, n1 = 0, n2 = 0;
+    uint8_t *flags2 = nullptr;
+};
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
-                            float *h, float4 *x4, hipStream_t s);
+                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset = nullptr);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
 // node.hip
 // rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
