@@ -229,7 +229,9 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_
 //             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
 //             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
 // STAGE only tags the instantiation (0 = x2h, 1 = h2x) so that profilers report the two stages separately.
-template <bool XV, int WAVES, int STAGE>
+// RAW = true (general graphs): `it` walks chunks, the dst node comes from chunk_node, and the scaled logits are stored as they
+//             are (-inf on pads): the softmax over all chunks of a node happens in the ragged value / xv kernels.
+template <bool XV, int WAVES, int STAGE, bool RAW = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -253,10 +255,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     td_node_range16(a.count, a.count_ptr, begin, end);
 
     for (int64_t it = begin + wid; it < end; it += WAVES) {
-        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        const int64_t c = a.rows ? (int64_t)a.rows[it] : it;          // row of nbr / ew / alpha: a node, or (RAW) a chunk
+        const int64_t i = RAW ? (int64_t)a.chunk_node[c] : c;          // its dst node
         floatx4_t acc[2][8];
         Edge2 ed;
-        td_first_layer16<!XV>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
+        td_first_layer16<!XV && !RAW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
 
         if (XV) {
             const float *Wx = lds + E16_R_FLOATS;                 // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
@@ -317,6 +320,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         for (int r = 0; r < 4; ++r) {
             const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
             const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+            if (RAW) {
+                float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                dst[0] = x0;
+                dst[16] = x1;
+                continue;
+            }
             float mx = td_max16(fmaxf(x0, x1));
             if (mx == -INFINITY) mx = 0.f;
             const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
@@ -592,58 +601,11 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 // Rows that are not exactly 32 wide (k-NN with k != 32, `hybrid`, radius with a fan-out cap): the in-edges of node i are
 // the chunks cptr[i] .. cptr[i+1]-1 of 32 slots (-1 padded; graph.hip).  The per-chunk arithmetic is the one above; what
 // changes is the softmax over ALL slots of a node, so the passes split differently:
-//   * edge_logits16_kernel   one wave per chunk: first layer -> z, logits = z . U_i, scaled logits to alpha[c] (-inf on pads)
+//   * edge_key16_kernel<RAW> one wave per chunk: first layer -> z, logits = z . U_i, scaled logits to alpha[c] (-inf on pads)
 //   * edge_value16_ragged    one wave per node: max / sum of its logits, then per chunk alpha = softmax * gate,
 //                            Zbar += alpha^T z across the chunks, one output product W2v . Zbar, residual
 //   * edge_xv16_ragged       one wave per ligand node: same statistics, delta_x accumulated over the chunks
 // (scatter_softmax / scatter_sum over arbitrary segments, models/uni_transformer.py:73,78,135,139).
-template <int WAVES, int STAGE>
-__global__ __launch_bounds__(WAVES * 64) void edge_logits16_kernel(Args16 a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
-    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int lo = lane & 15, g = lane >> 4;
-    td_stage_tables16<WAVES>(lds, a.mlp, E16_WQ_FLOATS / 4, tid);
-    float offk[E16_STEPS];
-#pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
-    __syncthreads();
-    int64_t begin, end;
-    td_node_range16(a.count, a.count_ptr, begin, end);
-    for (int64_t it = begin + wid; it < end; it += WAVES) {
-        const int64_t c = a.rows ? (int64_t)a.rows[it] : it;
-        const int64_t i = a.chunk_node[c];
-        floatx4_t acc[2][8];
-        Edge2 ed;
-        td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
-        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
-        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
-        floatx4_t lg[2];
-#pragma unroll
-        for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
-                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
-                float u = w0.x * q0.x;
-                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
-                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
-                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
-            dst[0] = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-            dst[16] = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
-        }
-    }
-}
-
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_ragged_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -675,8 +637,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_ragged_kernel(Arg
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     };
     for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
-        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-        const int c0 = a.cptr[i], c1 = a.cptr[i + 1];
+        const int64_t i = __builtin_amdgcn_readfirstlane(a.rows ? a.rows[it] : (int32_t)it);
+        const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
         float xs[8];
         float m = -INFINITY;
         for (int c = c0; c < c1; ++c) {
@@ -780,8 +742,8 @@ __global__ __launch_bounds__(XV16_WAVES * 64) void edge_xv16_ragged_kernel(Args1
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
     for (int64_t it = begin + wid; it < end; it += WAVES) {
-        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-        const int c0 = a.cptr[i], c1 = a.cptr[i + 1];
+        const int64_t i = __builtin_amdgcn_readfirstlane(a.rows ? a.rows[it] : (int32_t)it);
+        const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
         // softmax statistics of heads 4g .. 4g + 3 over every slot of the node
         float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, inv[4];
         for (int c = c0; c < c1; ++c)
@@ -936,11 +898,11 @@ int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, c
     a.x4 = x4; a.nbr = cnbr; a.P = P; a.q = q; a.rows = chunks; a.alpha = alpha; a.count = count; a.mlp = mlp;
     a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0; a.chunk_node = chunk_node;
     if (stage == 0) {
-        TD_LDS_ONCE((edge_logits16_kernel<K16_WAVES, 0>), K16_LDS_BYTES);
-        edge_logits16_kernel<K16_WAVES, 0><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+        TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 0, true>), K16_LDS_BYTES);
+        edge_key16_kernel<false, K16_WAVES, 0, true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     } else {
-        TD_LDS_ONCE((edge_logits16_kernel<K16_WAVES, 1>), K16_LDS_BYTES);
-        edge_logits16_kernel<K16_WAVES, 1><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+        TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 1, true>), K16_LDS_BYTES);
+        edge_key16_kernel<false, K16_WAVES, 1, true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
