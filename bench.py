@@ -345,7 +345,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    distributed = world > 1
+    # under a launcher (torchrun or the self-spawn) the process group is always set up -- also for a world of one rank, so
+    # that a single-GPU box exercises the same RCCL initialisation, barrier and reduction as the N-rank job
+    distributed = world > 1 or launch.under_launcher()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (MI355X); there is no CPU path')
     torch.cuda.set_device(local_rank)

@@ -226,3 +226,26 @@ def test_model_options_live_in_the_handle(state_dict):
     assert torch.equal(res[(1, 1)]['final_h'], res[(1, 0)]['final_h'])          # fusing the h2x halves changes no arithmetic
     with pytest.raises(RuntimeError, match='unknown option'):
         nat.set_option('no_such_switch', 1)
+
+
+@pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
+def test_forward_other_weight_scales_vs_oracle(seed, gain):
+    """Parity must not depend on the one seeded weight set the fixtures use: other seeds and weight scales (stronger /
+    weaker non-linearity, larger coordinate updates) against the oracle restatement."""
+    from oracle import restatement as R
+    from oracle import weights
+    from oracle.make_golden import small_batch
+    dev = _dev()
+    sd = weights.make_state_dict(seed, gain=gain)
+    model = _model(sd)
+    b, lpos, lv = small_batch()
+    ppos, lpos_c, _ = R.center_positions(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch)
+    want = R.model_forward(sd, None, ppos, b.protein_atom_feature.float(), b.protein_element_batch, lpos_c, lv, b.ligand_element_batch)
+    got = model(ppos.to(dev), b.protein_atom_feature.float().to(dev), b.protein_element_batch.to(dev), lpos_c.to(dev), lv.to(dev),
+                b.ligand_element_batch.to(dev))
+    scale = max(1.0, float(want['final_h'].abs().max()))
+    print(f'seed {seed} gain {gain}: |dx| {_maxdiff(got["pred_ligand_pos"], want["pred_ligand_pos"]):.2e}  '
+          f'|dh| {_maxdiff(got["final_h"], want["final_h"]):.2e} (max |h| {scale:.1f})')
+    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= TOL_X * scale
+    assert _maxdiff(got['final_h'], want['final_h']) <= TOL_H * scale
+    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= TOL_H * scale

@@ -419,3 +419,22 @@ def test_overlapped_batches_equal_sequential_batches(model):
         assert len(a_list) == len(b_list) == 22
         for a, b in zip(a_list, b_list):
             assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def test_bench_through_the_launcher_initialises_rccl(tmp_path):
+    """`bench.py` started by targetdiff_amd.launch (the way `--gpus N` starts N ranks) on this box's single GPU: a world of
+    one rank still goes through dist.init_process_group('nccl'), the barrier and the max-reduction, and prints one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from targetdiff_amd import launch
+    _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = launch.rank_env(0, 1, launch.free_port())
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-full-run', '--workload', 'c1'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 1 and d['value'] > 0 and d['unit'] == 'ligands/s' and d['roofline'] is not None
