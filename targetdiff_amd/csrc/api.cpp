@@ -156,8 +156,9 @@ inline float bf16_to_f32(uint32_t b) {
     memcpy(&x, &u, 4);
     return x;
 }
-// B operand of the split node-projection GEMM: [s 8][piece 3][lane 64][tile 4] x 8 bf16 (two per 32-bit word, slot j of lane
-// half hi = k index 16s + 8(j >> 2) + 4hi + (j & 3)); piece p of W = bf16 of the residual left by pieces 0 .. p-1 (exact)
+// B operand of the split node-projection GEMM: [s 8][piece 3][tile 4][lane 64] x 8 bf16 (two per 32-bit word, slot j of lane
+// half hi = k index 16s + 8(j >> 2) + 4hi + (j & 3)); piece p of W = bf16 of the residual left by pieces 0 .. p-1 (exact).
+// Lane-minor: a wave's 16-byte reads of one (piece, tile) fragment are consecutive in LDS (no bank conflicts).
 size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
     size_t off = pk.alloc((size_t)8 * 3 * 64 * 4 * 4);
     uint32_t *d = reinterpret_cast<uint32_t *>(pk.data.data() + off);
@@ -175,7 +176,7 @@ size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
                 }
                 for (int p = 0; p < 3; ++p)
                     for (int w = 0; w < 4; ++w)
-                        d[((((size_t)s * 3 + p) * 64 + lane) * 4 + t) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+                        d[((((size_t)s * 3 + p) * 4 + t) * 64 + lane) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
             }
     return off;
 }

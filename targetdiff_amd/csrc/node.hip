@@ -59,9 +59,9 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
 // ---- experimental: exact 3-way bf16 splitting of both GEMM operands (TD_NODE_PROJ_SPLIT=1) ------------------------------
 // An fp32 significand (24 bits) is exactly the sum of three bf16 pieces (8 bits each): x = x1 + x2 + x3.  The six largest of
 // the nine piece products (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) on v_mfma_f32_32x32x16_bf16, accumulated in fp32, reproduce
-// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time ([s 8][piece 3][lane][tile 4]
+// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time ([s 8][piece 3][tile 4][lane]
 // x 8 bf16, the 8 k-slots of lane half `hi` in k-step s being k = 16s + 8(j >> 2) + 4hi + (j & 3), i.e. exactly the two float4
-// of the fp32 A tile), A is split once per tile in registers.
+// of the fp32 A tile), A is split once per tile in registers.  B layout in LDS / memory: [s][piece][tile][lane] (lane-minor).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int NPS_CHUNK_U4 = 2 * 3 * 64 * 4;            // uint4 per staged chunk: 2 k-steps x 3 pieces x 64 lanes x 4 tiles (24 KiB)
 constexpr int NPS_CHUNKS = 4;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void gemm128_split(const uint4 (&ap)[3][8], const uin
             for (int u = 0; u < NPS_CHUNK_U4; u += nthr)
                 td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
         }
-        const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane * 4;
+        const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane;
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const int s = 2 * ch + ss;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void gemm128_split(const uint4 (&ap)[3][8], const uin
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b[p][t] = bl[(ss * 3 + p) * 256 + t];
+                for (int t = 0; t < 4; ++t) b[p][t] = bl[((ss * 3 + p) * 4 + t) * 64];      // lane-minor: conflict-free b128 reads
             // low-order products first
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[1][t], acc[t]);
