@@ -156,9 +156,10 @@ inline float bf16_to_f32(uint32_t b) {
     memcpy(&x, &u, 4);
     return x;
 }
-// B operand of the split node-projection GEMM: [s 8][piece 3][tile 4][lane 64] x 8 bf16 (two per 32-bit word, slot j of lane
-// half hi = k index 16s + 8(j >> 2) + 4hi + (j & 3)); piece p of W = bf16 of the residual left by pieces 0 .. p-1 (exact).
-// Lane-minor: a wave's 16-byte reads of one (piece, tile) fragment are consecutive in LDS (no bank conflicts).
+// B operand of the split node-projection GEMM, in the order node_proj_split_kernel streams it: 4 chunks per matrix =
+// [half 2][k-chunk 2], each [k-step 4][piece 3][tile 2][lane 64] x 8 bf16 (two per 32-bit word, slot j of lane half hi =
+// k index 16s + 8(j >> 2) + 4hi + (j & 3) with s = 4 * k-chunk + k-step; N tile = 2 * half + tile); piece p of W = bf16 of
+// the residual left by pieces 0 .. p-1 (exact).  Lane-minor: a wave's 16-byte reads of one fragment are consecutive in LDS.
 size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
     size_t off = pk.alloc((size_t)8 * 3 * 64 * 4 * 4);
     uint32_t *d = reinterpret_cast<uint32_t *>(pk.data.data() + off);
@@ -176,7 +177,10 @@ size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
                 }
                 for (int p = 0; p < 3; ++p)
                     for (int w = 0; w < 4; ++w)
-                        d[((((size_t)s * 3 + p) * 4 + t) * 64 + lane) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+                    {
+                        const size_t chunk = (size_t)(t >> 1) * 2 + (s >> 2), ss = s & 3, tt = t & 1;
+                        d[(((((chunk * 4 + ss) * 3 + p) * 2 + tt) * 64 + lane)) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+                    }
             }
     return off;
 }

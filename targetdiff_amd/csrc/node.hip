@@ -56,14 +56,14 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
     }
 }
 
-// ---- experimental: exact 3-way bf16 splitting of both GEMM operands (TD_NODE_PROJ_SPLIT=1) ------------------------------
+// ---- exact 3-way bf16 splitting of both GEMM operands (model option node_proj_split, default on) ------------------------
 // An fp32 significand (24 bits) is exactly the sum of three bf16 pieces (8 bits each): x = x1 + x2 + x3.  The six largest of
 // the nine piece products (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) on v_mfma_f32_32x32x16_bf16, accumulated in fp32, reproduce
-// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time ([s 8][piece 3][tile 4][lane]
-// x 8 bf16, the 8 k-slots of lane half `hi` in k-step s being k = 16s + 8(j >> 2) + 4hi + (j & 3), i.e. exactly the two float4
-// of the fp32 A tile), A is split once per tile in registers.  B layout in LDS / memory: [s][piece][tile][lane] (lane-minor).
+// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time (api.cpp pack_B128_split:
+// chunks of [k-step 4][piece 3][tile 2][lane 64] x 8 bf16, the 8 k-slots of lane half `hi` in k-step s being
+// k = 16s + 8(j >> 2) + 4hi + (j & 3), i.e. exactly the two float4 of the fp32 A tile), A is split once per tile in registers.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int NPS_CHUNK_U4 = 2 * 3 * 64 * 4;            // uint4 per staged chunk: 2 k-steps x 3 pieces x 64 lanes x 4 tiles (24 KiB)
+constexpr int NPS_CHUNK_U4 = 4 * 3 * 2 * 64;            // uint4 per staged chunk: 4 k-steps x 3 pieces x 2 tiles x 64 lanes (24 KiB)
 constexpr int NPS_CHUNKS = 4;
 constexpr size_t NPS_LDS_BYTES = (size_t)2 * NPS_CHUNK_U4 * 16 + (size_t)4 * 32 * NP_TSTRIDE * sizeof(float);
 
@@ -94,45 +94,6 @@ __device__ __forceinline__ void td_split_tile(const float4 (&a)[16], uint4 (&ap)
         td_split2(v.z, v.w, ap[0][s].w, ap[1][s].w, ap[2][s].w);
     }
 }
-__device__ __forceinline__ void gemm128_split(const uint4 (&ap)[3][8], const uint4 *__restrict__ B, const uint4 *__restrict__ next,
-                                              uint4 *__restrict__ bufs, int &cur, int tid, int lane, floatx16 (&acc)[4]) {
-#pragma unroll
-    for (int ch = 0; ch < NPS_CHUNKS; ++ch) {
-        const uint4 *src = ch + 1 < NPS_CHUNKS ? B + (size_t)(ch + 1) * NPS_CHUNK_U4 : next;
-        if (src) {
-            uint4 *dst = bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63);
-            const int nthr = blockDim.x;
-            for (int u = 0; u < NPS_CHUNK_U4; u += nthr)
-                td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
-        }
-        const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane;
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            const int s = 2 * ch + ss;
-            uint4 b[3][4];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b[p][t] = bl[((ss * 3 + p) * 4 + t) * 64];      // lane-minor: conflict-free b128 reads
-            // low-order products first
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[1][t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[2][s], b[0][t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[2][t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[0][t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[1][t], acc[t]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[0][t], acc[t]);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-}
-
 // One launch processes up to three row segments, each with its own stage weights, row list and outputs:
 //   mask: bit m (0..3) -> projection m of [k_i, k_j, v_i, v_j]; bit 4 -> query MLP
 //   rows != nullptr: only the listed node ids; count_ptr != nullptr: device-side list length (N is then the bound the
@@ -157,7 +118,6 @@ struct NpArgs {
     int nseg;
 };
 
-template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const float *__restrict__ h) {
     int bx = blockIdx.x, si = 0;
     while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
@@ -177,10 +137,9 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
         if ((int64_t)bx * (blockDim.x >> 1) >= N) return;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks (SPLIT: 2 x 24 KiB)
-    uint4 *bufs3 = reinterpret_cast<uint4 *>(lds);
+    float4 *bufs = reinterpret_cast<float4 *>(lds);                          // 2 x 16 KiB B chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float *tb = lds + (SPLIT ? 2 * NPS_CHUNK_U4 * 4 : 2 * NP_CHUNK_F4 * 4) + wave * 32 * NP_TSTRIDE;   // wave-private transpose tile
+    float *tb = lds + 2 * NP_CHUNK_F4 * 4 + wave * 32 * NP_TSTRIDE;   // wave-private transpose tile
     const int c = lane & 31, hi = lane >> 5;
     const int64_t row0 = ((int64_t)bx * (blockDim.x >> 6) + wave) * 32;
     const int64_t aslot = row0 + c;
@@ -211,20 +170,17 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
         mat_mask = sel;
     }
     // the matrices this launch walks through, in order: selected projections, then q.net.0, then q.net.3
-    constexpr size_t MAT_F4 = SPLIT ? (size_t)NPS_CHUNKS * NPS_CHUNK_U4 : (size_t)TD_KSTEPS * 64;     // 16-byte units per matrix
-    const float4 *Bp = reinterpret_cast<const float4 *>(SPLIT ? st.projB3 : st.projB);
+    constexpr size_t MAT_F4 = (size_t)TD_KSTEPS * 64;     // 16-byte units per matrix
+    const float4 *Bp = reinterpret_cast<const float4 *>(st.projB);
     const float4 *seq[6];
     int mats[6], nseq = 0;
     for (int mat = 0; mat < 5; ++mat)
         if ((mat_mask >> mat) & 1u) { seq[nseq] = Bp + (size_t)mat * MAT_F4; mats[nseq++] = mat; }
-    if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(SPLIT ? st.q3B3 : st.q3B); mats[nseq++] = 5; }
+    if ((mat_mask >> 4) & 1u) { seq[nseq] = reinterpret_cast<const float4 *>(st.q3B); mats[nseq++] = 5; }
     // prologue: first chunk of the first matrix
-    for (int u = tid; u < (SPLIT ? NPS_CHUNK_U4 : NP_CHUNK_F4); u += blockDim.x) bufs[u] = seq[0][u];
+    for (int u = tid; u < NP_CHUNK_F4; u += blockDim.x) bufs[u] = seq[0][u];
     __syncthreads();
     int cur = 0;
-    uint4 ap[SPLIT ? 3 : 1][8];
-    if constexpr (SPLIT) td_split_tile(a, ap);
-
     floatx16 acc[4];
     for (int si = 0; si < nseq; ++si) {
         const int mat = mats[si];
@@ -236,10 +192,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
             for (int r = 0; r < 16; ++r) acc[t][r] = bv;
         }
         const float4 *next = si + 1 < nseq ? seq[si + 1] : nullptr;
-        if constexpr (SPLIT)
-            gemm128_split(ap, reinterpret_cast<const uint4 *>(seq[si]), reinterpret_cast<const uint4 *>(next), bufs3, cur, tid, lane, acc);
-        else
-            gemm128_lds(a, seq[si], next, bufs, cur, tid, lane, acc);     // for q.net.3 `a` holds the normalised hidden tile
+        gemm128_lds(a, seq[si], next, bufs, cur, tid, lane, acc);     // for q.net.3 `a` holds the normalised hidden tile
         if (mat < 4) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -277,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
                 for (int mm = 0; mm < 4; ++mm)
                     a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);   // h tile no longer needed
             }
-            if constexpr (SPLIT) td_split_tile(a, ap);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -286,6 +238,176 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
 #pragma unroll
                     for (int t = 0; t < 4; ++t) q[(size_t)orow * TD_H + 32 * t + c] = acc[t][r];
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ split path, half-N GEMMs
+// The bf16 x 3 kernel.  Register budget is what shapes it: the A tile's piece triples take 96 VGPRs for the whole
+// workgroup lifetime, so a GEMM runs as two half-N GEMMs (2 N tiles = 32 accumulator VGPRs, 6 B fragments in flight) and
+// the wave stays under 256 VGPRs without spilling at 2 waves per SIMD.  B stream per matrix (packed by pack_B128_split):
+// 4 chunks of 24 KiB = [half 2][k-chunk 2] x [k-step 4][piece 3][tile 2][lane 64] x 16 B, consumed in that order.
+__global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, const float *__restrict__ h) {
+    int bx = blockIdx.x, si = 0;
+    while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
+    const NpSeg &sg = args.seg[si];
+    const TdNodeStage st = sg.st;
+    const int32_t *__restrict__ rows = sg.rows;
+    float *__restrict__ P = sg.P, *__restrict__ q = sg.q;
+    unsigned mat_mask = sg.mask;
+    int64_t N = sg.N;
+    int unit = gridDim.y > 1 ? (int)blockIdx.y : -1;
+    if (sg.units > 1) {
+        unit = bx % sg.units;
+        bx /= sg.units;
+    }
+    if (sg.count_ptr) {
+        N = *sg.count_ptr;
+        if ((int64_t)bx * (blockDim.x >> 1) >= N) return;
+    }
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    uint4 *bufs = reinterpret_cast<uint4 *>(lds);                                  // 2 x 24 KiB B chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *tb = lds + 2 * NPS_CHUNK_U4 * 4 + wave * 32 * NP_TSTRIDE;               // wave-private transpose tile
+    const int c = lane & 31, hi = lane >> 5;
+    const int64_t row0 = ((int64_t)bx * (blockDim.x >> 6) + wave) * 32;
+    if (unit >= 0) {          // one matrix unit per workgroup (small launches / split segments)
+        int seen = 0;
+        unsigned sel = 0;
+        for (int b = 0; b < 5; ++b)
+            if ((mat_mask >> b) & 1u) {
+                if (seen == unit) sel = 1u << b;
+                ++seen;
+            }
+        mat_mask = sel;
+    }
+    // matrices in order: selected projections (0..3), q.net.0 (4), q.net.3 (5) -- scalar bit tests, no indexed arrays
+    const unsigned seq_mask = (mat_mask & 0x1fu) | (((mat_mask >> 4) & 1u) << 5);
+    if (!seq_mask) return;
+    constexpr size_t MAT_U4 = (size_t)NPS_CHUNKS * NPS_CHUNK_U4;
+    const uint4 *Bp = reinterpret_cast<const uint4 *>(st.projB3), *Bq3 = reinterpret_cast<const uint4 *>(st.q3B3);
+    auto mat_after = [&](int m) -> int {
+        const unsigned rest = seq_mask & ~((2u << m) - 1u);
+        return rest ? __builtin_ctz(rest) : -1;
+    };
+    auto mat_ptr = [&](int m) -> const uint4 * { return m < 5 ? Bp + (size_t)m * MAT_U4 : Bq3; };
+    int mat = __builtin_ctz(seq_mask);
+    {   // prologue: first chunk of the first matrix
+        const uint4 *first = mat_ptr(mat);
+        for (int u = tid; u < NPS_CHUNK_U4; u += blockDim.x) bufs[u] = first[u];
+    }
+    uint4 ap[3][8];
+    {
+        const int64_t aslot = row0 + c;
+        const int64_t arow = aslot < N ? (rows ? (int64_t)rows[aslot] : aslot) : -1;
+        float4 a[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            a[m] = (arow >= 0) ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+        td_split_tile(a, ap);
+    }
+    __syncthreads();
+    int cur = 0;
+    floatx16 keep[2];          // q.net.0: columns 0..63 while the second half is computed (LayerNorm needs the whole row)
+    for (; mat >= 0; mat = mat_after(mat)) {
+        const float *bias = mat < 5 ? st.projBias + mat * TD_H : st.q3Bias;
+        const uint4 *B = mat_ptr(mat);
+        const int mat_next = mat_after(mat);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            floatx16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float bv = bias[64 * half + 32 * t + c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = bv;
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int chunk = 2 * half + kc;
+                const uint4 *src = chunk + 1 < NPS_CHUNKS ? B + (size_t)(chunk + 1) * NPS_CHUNK_U4
+                                                            : (mat_next >= 0 ? mat_ptr(mat_next) : nullptr);
+                if (src) {
+                    uint4 *dst = bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63);
+                    const int nthr = blockDim.x;
+                    for (int u = 0; u < NPS_CHUNK_U4; u += nthr)
+                        td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
+                }
+                const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane;
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {
+                    const int s = 4 * kc + ss;
+                    uint4 b[3][2];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) b[p][t] = bl[((ss * 3 + p) * 2 + t) * 64];
+                    // low-order products first
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[1][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[2][s], b[0][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[2][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[0][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[1][t], acc[t]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[0][t], acc[t]);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            // ---- epilogue of this half: columns 64 * half .. + 63
+            if (mat != 4) {
+                float *out = mat < 4 ? P + mat * TD_H + 64 * half + c : q + 64 * half + c;
+                const size_t ld = mat < 4 ? (size_t)(4 * TD_H) : (size_t)TD_H;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int slot = (int)row0 + td_erow(r, hi);
+                    const int orow = slot < N ? (rows ? rows[slot] : slot) : -1;
+                    if (orow >= 0) {
+                        out[(size_t)orow * ld] = acc[0][r];
+                        out[(size_t)orow * ld + 32] = acc[1][r];
+                    }
+                }
+            } else if (half == 0) {
+                keep[0] = acc[0];
+                keep[1] = acc[1];
+            } else {
+                // ---- query MLP: LayerNorm -> ReLU over the 128 columns (keep = 0..63, acc = 64..127), then C layout -> A
+                //      layout through the wave-private tile and a fresh split of the hidden tile
+                float gam[4], bet[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    gam[t] = st.qGamma[32 * t + c];
+                    bet[t] = st.qBeta[32 * t + c];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float s1 = (keep[0][r] + keep[1][r]) + (acc[0][r] + acc[1][r]);
+                    const float mean = td_sum32(s1) * (1.0f / TD_H);
+                    const float d0 = keep[0][r] - mean, d1 = keep[1][r] - mean, d2 = acc[0][r] - mean, d3 = acc[1][r] - mean;
+                    const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H);
+                    const float rstd = __frsqrt_rn(var + 1e-5f);
+                    keep[0][r] = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f);
+                    keep[1][r] = fmaxf(d1 * rstd * gam[1] + bet[1], 0.f);
+                    acc[0][r] = fmaxf(d2 * rstd * gam[2] + bet[2], 0.f);
+                    acc[1][r] = fmaxf(d3 * rstd * gam[3] + bet[3], 0.f);
+                }
+                float4 a[16];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {          // one 32-column tile at a time through the wave-private tile
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tb[td_erow(r, hi) * NP_TSTRIDE + c] = t == 0 ? keep[0][r] : t == 1 ? keep[1][r] : t == 2 ? acc[0][r] : acc[1][r];
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm)
+                        a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);
+                }
+                td_split_tile(a, ap);
             }
         }
     }
@@ -308,11 +430,11 @@ static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, uns
     bool split = true;
     for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.use_split && a.seg[i].st.projB3 != nullptr;
     if (split) {
-        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_kernel<true>), NPS_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_kernel<true><<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
+        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
     } else {
-        if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel<false>), NP_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_kernel<false><<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
+        if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_kernel<<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
     }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
