@@ -118,3 +118,42 @@ def test_mirror_loads_the_full_reference_state_dict_strict():
     assert not res.missing_keys and not res.unexpected_keys
     for k, v in mirror.state_dict().items():
         assert torch.equal(v, ref_sd[k]), k
+
+
+def test_call_signatures_are_drop_in():
+    """INTEGRATION.md route A is an import swap: every parameter of the reference's call signatures on this path exists in
+    the mirror under the same name, in the same position and with the same default (the mirror may add keyword-only
+    extras at the end)."""
+    import inspect
+    from oracle import reference_loader
+    from targetdiff_amd import models as M
+    from targetdiff_amd import sampling as S
+    ref = reference_loader.load()
+    drv = reference_loader.load_driver()
+    pairs = [(ref.ScorePosNet3D.__init__, M.ScorePosNet3D.__init__), (ref.ScorePosNet3D.forward, M.ScorePosNet3D.forward),
+             (ref.ScorePosNet3D.sample_diffusion, M.ScorePosNet3D.sample_diffusion),
+             (ref.ScorePosNet3D.fetch_embedding, M.ScorePosNet3D.fetch_embedding),
+             (ref.ScorePosNet3D.likelihood_estimation, M.ScorePosNet3D.likelihood_estimation),
+             (ref.get_refine_net, M.get_refine_net), (drv.sample_diffusion_ligand, S.sample_diffusion_ligand),
+             (drv.unbatch_v_traj, S.unbatch_v_traj)]
+    for f_ref, f_own in pairs:
+        want = list(inspect.signature(inspect.unwrap(f_ref)).parameters.values())
+        got = list(inspect.signature(inspect.unwrap(f_own)).parameters.values())
+        assert len(got) >= len(want), f_ref.__qualname__
+        for a, b in zip(want, got):
+            assert a.name == b.name and a.default == b.default, (f_ref.__qualname__, a, b)
+        for extra in got[len(want):]:
+            assert extra.default is not inspect.Parameter.empty, (f_own.__qualname__, extra)      # optional additions only
+    # the refine net seam (models/uni_transformer.py:301) and the attributes the drivers read
+    import importlib
+    ut = importlib.import_module('models.uni_transformer')
+    want = [p.name for p in inspect.signature(ut.UniTransformerO2TwoUpdateGeneral.forward).parameters.values()]
+    got = [p.name for p in inspect.signature(M.UniTransformerO2TwoUpdateGeneral.forward).parameters.values()]
+    assert got[:len(want)] == want
+    want = list(inspect.signature(ut.UniTransformerO2TwoUpdateGeneral.__init__).parameters.values())
+    got = list(inspect.signature(M.UniTransformerO2TwoUpdateGeneral.__init__).parameters.values())
+    for a, b in zip(want, got):
+        assert a.name == b.name and a.default == b.default, (a, b)
+    from oracle import weights
+    m = M.ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    assert m.num_classes == 13 and m.num_timesteps == 1000 and m.center_pos_mode == 'protein'
