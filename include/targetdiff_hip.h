@@ -39,8 +39,9 @@ typedef struct td_model td_model;
  * scripts/sample_diffusion.py:158-162).  The HIP kernels are specialised for the live architecture (hidden 128, 16 heads,
  * 20 Gaussians, 4 edge types, uni_o2, global edge gate); td_model_create returns TD_EINVAL for anything else.  The graph
  * construction of models/uni_transformer.py:276-286 is a run-time choice:
- *   TD_CUTOFF_KNN     knn_graph(x, k = knn), any 1 <= knn <= 64; knn = 32 (the live configuration) takes the fast path in
- *                     which one dst row is exactly one 32-row MFMA tile and the sampling session caches the static protein;
+ *   TD_CUTOFF_KNN     knn_graph(x, k = knn), any 1 <= knn <= 64; knn <= 32 (32 = the live configuration) takes the fast path in
+ *                     which one dst row is one 32-row MFMA tile (slots >= knn masked: the knn nearest are the first knn of
+ *                     the 32 nearest) and the sampling session caches the static protein;
  *   TD_CUTOFF_HYBRID  batch_hybrid_edge_connection(add_p_index=True) (models/common.py:165-212): a ligand atom sees every
  *                     other ligand atom of its graph and its knn nearest protein atoms, a protein atom its knn nearest nodes;
  *   TD_CUTOFF_RADIUS  radius graph with a fan-out cap: the first max_num_neighbors nodes j != i of the graph (index order)

@@ -215,7 +215,8 @@ class NativeModel:
                             cutoff_mode=CUTOFF_MODES[mode], radius=float(cfg.get('radius', 0.0)),
                             max_num_neighbors=int(cfg.get('max_num_neighbors', 32)))
         self.cutoff_mode, self.k = mode, int(cfg['knn'])
-        self.default_graph = mode == 'knn' and self.k == KNN       # the fixed-32 fast path (and the caching session)
+        self.default_graph = mode == 'knn' and self.k <= KNN       # the 32-slot fast path (and the caching session); k < 32
+                                                                   # is the 32-NN row with the slots >= k masked
         self.num_classes = int(cfg['ligand_num_classes'])
         blob = flatten_state_dict(state_dict, cfg['num_layers'])
         expect = self.lib.td_model_num_weights(ctypes.byref(self.cfg))

@@ -120,7 +120,8 @@ bool config_supported(const td_config &c) {
 }
 
 // the graph every kernel's fast path is specialised for: exactly 32 in-edges per node, one MFMA tile per dst row
-bool default_graph(const td_config &c) { return c.cutoff_mode == TD_CUTOFF_KNN && c.knn == TD_K; }
+// (a k-NN graph with k < 32 is the 32-NN graph with the slots >= k masked, so it shares that path)
+bool default_graph(const td_config &c) { return c.cutoff_mode == TD_CUTOFF_KNN && c.knn <= TD_K; }
 
 // Packed-buffer builder: collects tensors into one host vector; pointers are fixed up after the upload.
 struct Packer {
@@ -572,7 +573,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
     auto level_count = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_count + (k - 1) : nullptr; };
     if (!graph_ready) {
-        { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc; }
         { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
     }
     float4 *xc = w.x4a, *xn = w.x4b;
@@ -1350,7 +1351,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     TD_TRY_HIP(hipMemcpyAsync(w.x4b, w.x4a, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
     // protein-only graph, its gate rows, layer-0 projections / queries, layer-0 x2h output
     TD_TRY_HIP(hipMemsetAsync(S->snbr, 0xff, n * TD_K * 4, s));
-    TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s));
+    TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s, m->cfg.knn));
     TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
     const TdLayer &L0 = m->layers[0];
     TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
@@ -1414,8 +1415,8 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     {
         ProfScope ps(PC_KNN, s);
         if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
-                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s)) != TD_OK) return rc;
-        if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s)) != TD_OK) return rc;
+                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
+        if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc;
         if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
         // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
         // clears it; without the forward reach a memset does

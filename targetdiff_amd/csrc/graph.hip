@@ -123,8 +123,11 @@ constexpr int TD_COMPOSE_ATOMS = 16;
 template <int CH, bool STATIC>
 __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
                                                   const int32_t *__restrict__ gid, const int32_t *__restrict__ rows,
-                                                  int64_t N, int32_t *__restrict__ nbr,
+                                                  int64_t N, int k, int32_t *__restrict__ nbr,
                                                   unsigned long long *__restrict__ skeys) {
+    // k <= 32 neighbours per row in a 32-slot row (slots >= k: -1).  The k nearest are the first k of the 32 nearest, so
+    // every fan-in up to 32 shares the 32-slot fast path; STATIC extracts all 32 keys (the session merges into them).
+    const int rounds = STATIC ? TD_K : k;
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= N) return;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
         }
         unsigned long long carry = best;     // previous passes' winners compete again
         unsigned long long out = TD_KEY_MAX;
-        for (int r = 0; r < TD_K; ++r) {
+        for (int r = 0; r < rounds; ++r) {
             unsigned long long lmin = carry;
 #pragma unroll
             for (int u = 0; u < CH; ++u) lmin = key[u] < lmin ? key[u] : lmin;
@@ -163,43 +166,43 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
         best = out;
     }
     if (lane < TD_K) {
-        nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+        nbr[i * TD_K + lane] = (best == TD_KEY_MAX || lane >= k) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
         if (STATIC) skeys[i * TD_K + lane] = best;
     }
 }
 
 template <bool STATIC>
 static int launch_knn_t(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t N,
-                        int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s) {
+                        int max_graph_nodes, int k, int32_t *nbr, unsigned long long *skeys, hipStream_t s) {
     if (N == 0) return TD_OK;
     dim3 grid((unsigned)((N + 3) / 4)), block(256);
     if (max_graph_nodes > 0 && max_graph_nodes <= 256)
-        knn_kernel<4, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+        knn_kernel<4, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, k, nbr, skeys);
     else if (max_graph_nodes > 0 && max_graph_nodes <= 384)
-        knn_kernel<6, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+        knn_kernel<6, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, k, nbr, skeys);
     else if (max_graph_nodes <= 704)         // also the "unknown" (0) default
-        knn_kernel<11, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+        knn_kernel<11, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, k, nbr, skeys);
     else
-        knn_kernel<17, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, nbr, skeys);
+        knn_kernel<17, STATIC><<<grid, block, 0, s>>>(x4, node_ptr, gid, rows, N, k, nbr, skeys);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
 int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, int max_graph_nodes,
-                  int32_t *nbr, hipStream_t s) {
-    return launch_knn_t<false>(x4, node_ptr, gid, nullptr, N, max_graph_nodes, nbr, nullptr, s);
+                  int32_t *nbr, hipStream_t s, int k) {
+    return launch_knn_t<false>(x4, node_ptr, gid, nullptr, N, max_graph_nodes, k, nbr, nullptr, s);
 }
 
 // kNN of the listed query rows only (ligand atoms of a session step): full search over the query's graph.
 int td_launch_knn_rows(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
-                       int max_graph_nodes, int32_t *nbr, hipStream_t s) {
-    return launch_knn_t<false>(x4, node_ptr, gid, rows, count, max_graph_nodes, nbr, nullptr, s);
+                       int max_graph_nodes, int32_t *nbr, hipStream_t s, int k) {
+    return launch_knn_t<false>(x4, node_ptr, gid, rows, count, max_graph_nodes, k, nbr, nullptr, s);
 }
 
 // Protein-only neighbour lists + their sorted keys for the listed (protein) rows.
 int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
-                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s) {
-    return launch_knn_t<true>(x4, node_ptr, gid, rows, count, max_graph_nodes, nbr, skeys, s);
+                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s, int k) {
+    return launch_knn_t<true>(x4, node_ptr, gid, rows, count, max_graph_nodes, k, nbr, skeys, s);
 }
 
 // ------------------------------------------------------------------------------------------ session step: kNN merge
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
     const int32_t *__restrict__ gid, const int32_t *__restrict__ prot_rows, int64_t Np,
     const unsigned long long *__restrict__ skeys, const int32_t *__restrict__ snbr, const float *__restrict__ h0,
     const float *__restrict__ h1s, const float *__restrict__ ews, int32_t *__restrict__ nbr, float *__restrict__ h,
-    float *__restrict__ ew, uint8_t *__restrict__ clean, uint8_t *__restrict__ flags2) {
+    float *__restrict__ ew, uint8_t *__restrict__ clean, uint8_t *__restrict__ flags2, int k) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= Np) return;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
     const int lbeg = ptr[g] + (pptr[g + 1] - pptr[g]), lend = ptr[g + 1];
     const float4 xi = x4[i];
     unsigned long long ks = lane < TD_K ? skeys[i * TD_K + lane] : TD_KEY_MAX;
-    const unsigned long long thr = __shfl(ks, TD_K - 1);          // 32nd static neighbour (MAX if fewer exist)
+    const unsigned long long thr = __shfl(ks, k - 1);             // k-th static neighbour (MAX if fewer exist)
     unsigned long long kl[2] = {TD_KEY_MAX, TD_KEY_MAX};
     bool closer = false;
     bool overflow = lend - lbeg > 128;                            // > 128 ligand atoms: handled by extra passes below
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
                 }
             }
             unsigned long long carry = best, out = TD_KEY_MAX;
-            for (int r = 0; r < TD_K; ++r) {
+            for (int r = 0; r < k; ++r) {
                 unsigned long long lmin = carry;
                 lmin = kl[0] < lmin ? kl[0] : lmin;
                 lmin = kl[1] < lmin ? kl[1] : lmin;
@@ -268,9 +271,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
             }
             best = out;
         }
-        if (lane < TD_K) nbr[i * TD_K + lane] = (best == TD_KEY_MAX) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
-        // the winners are the 32 smallest of static U ligand; if none of them is a ligand atom the row is still clean
-        const bool lig_in = lane < TD_K && best != TD_KEY_MAX && (int)(unsigned)(best & 0xffffffffull) >= lbeg;
+        if (lane < TD_K) nbr[i * TD_K + lane] = (best == TD_KEY_MAX || lane >= k) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+        // the winners are the k smallest of static U ligand; if none of them is a ligand atom the row is still clean
+        const bool lig_in = lane < k && best != TD_KEY_MAX && (int)(unsigned)(best & 0xffffffffull) >= lbeg;
         is_clean = __ballot(lig_in) == 0ull;
     } else if (lane < TD_K) {
         nbr[i * TD_K + lane] = snbr[i * TD_K + lane];
@@ -288,10 +291,10 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, uint8_t *flags2, hipStream_t s) {
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k) {
     if (Np == 0) return TD_OK;
     knn_merge_kernel<<<dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, pptr, gid, prot_rows, Np, skeys,
-                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean, flags2);
+                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean, flags2, k);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -144,20 +144,21 @@ int td_launch_graph_ptr(const int64_t *batch, int64_t N, int64_t B, int32_t *ptr
 int td_launch_node_gid(const int32_t *node_ptr, int64_t N, int64_t B, int32_t *gid, hipStream_t s);
 int td_launch_pack_x(const float *x3, const uint8_t *mask, int64_t N, float4 *x4, hipStream_t s);
 int td_launch_unpack_x(const float4 *x4, int64_t N, float *x3, hipStream_t s);
+// k <= TD_K neighbours per 32-slot row (slots >= k are -1): every fan-in up to 32 runs on the 32-slot fast path
 int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, int max_graph_nodes,
-                  int32_t *nbr, hipStream_t s);
+                  int32_t *nbr, hipStream_t s, int k = TD_K);
 int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
                       const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
                       float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, int32_t *prot_node,
                       hipStream_t s);
 int td_launch_knn_rows(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
-                       int max_graph_nodes, int32_t *nbr, hipStream_t s);
+                       int max_graph_nodes, int32_t *nbr, hipStream_t s, int k = TD_K);
 int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
-                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s);
+                         int max_graph_nodes, int32_t *nbr, unsigned long long *skeys, hipStream_t s, int k = TD_K);
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, uint8_t *flags2, hipStream_t s);
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k = TD_K);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
 int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,

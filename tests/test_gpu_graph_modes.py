@@ -173,9 +173,11 @@ def test_radius_graph_and_forward_vs_oracle(state_dict, r, cap):
 
 
 # ------------------------------------------------------------------------------------------ sampling on a general graph
-@pytest.mark.parametrize('cfg', [dict(cutoff_mode='hybrid'), dict(knn=48)])
+@pytest.mark.parametrize('cfg', [dict(cutoff_mode='hybrid'), dict(knn=48), dict(knn=16), dict(knn=5)])
 def test_sampling_steps_on_general_graph_vs_oracle(state_dict, cfg):
-    """5 reverse steps with injected draws through the sampler (plain session) against the restatement's loop."""
+    """5 reverse steps with injected draws through the sampler against the restatement's loop.  hybrid / k = 48: the plain
+    session of the chunked path; k = 16 / 5: the caching session of the 32-slot path with the slots >= k masked (merged
+    k-NN lists, cached gate / layer-0 rows, receptive-field pruning), which must equal the stateless forward bit for bit."""
     from oracle import draws
     from oracle import restatement as R
     from oracle import weights
