@@ -120,8 +120,12 @@ bool config_supported(const td_config &c) {
 }
 
 // the graph every kernel's fast path is specialised for: exactly 32 in-edges per node, one MFMA tile per dst row
-// (a k-NN graph with k < 32 is the 32-NN graph with the slots >= k masked, so it shares that path)
-bool default_graph(const td_config &c) { return c.cutoff_mode == TD_CUTOFF_KNN && c.knn <= TD_K; }
+// (a k-NN graph with k < 32 is the 32-NN graph with the slots >= k masked, so it shares that path; so does a radius graph
+// whose fan-out cap is <= 32).  The caching session additionally needs the k-NN structure (sorted lists to merge into).
+bool caching_graph(const td_config &c) { return c.cutoff_mode == TD_CUTOFF_KNN && c.knn <= TD_K; }
+bool default_graph(const td_config &c) {
+    return caching_graph(c) || (c.cutoff_mode == TD_CUTOFF_RADIUS && c.max_num_neighbors <= TD_K);
+}
 
 // Packed-buffer builder: collects tensors into one host vector; pointers are fixed up after the upload.
 struct Packer {
@@ -573,7 +577,14 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
     auto level_count = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_count + (k - 1) : nullptr; };
     if (!graph_ready) {
-        { ProfScope ps(PC_KNN, s); if ((rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc; }
+        {
+            ProfScope ps(PC_KNN, s);
+            if (m->cfg.cutoff_mode == TD_CUTOFF_RADIUS)
+                rc = td_launch_radius32(w.x4a, w.node_ptr, w.gid, N, m->cfg.radius, m->cfg.max_num_neighbors, w.nbr, s);
+            else
+                rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn);
+            if (rc != TD_OK) return rc;
+        }
         { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
     }
     float4 *xc = w.x4a, *xn = w.x4b;
@@ -1251,7 +1262,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     td_session *S = new (std::nothrow) td_session();
     if (!S) { td_set_error("td_session_create: out of host memory"); return TD_ENOMEM; }
     S->m = m; S->N = N; S->Np = N_p; S->Nl = N_l; S->B = B; S->max_graph_nodes = max_graph_nodes;
-    S->general = !default_graph(m->cfg);
+    S->general = !caching_graph(m->cfg);
     if (S->general) {
         // general graphs: the session keeps the embedded protein rows and the chunk layout; every step runs every row
         const size_t ws = carve(nullptr, N, B, N_l).bytes;
@@ -1397,7 +1408,9 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
             if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
         }
         float4 *xg = nullptr;
-        if ((rc = run_backbone_general(m, S->plan, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s)) != TD_OK) return rc;
+        if (default_graph(m->cfg)) rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s);      // 32-slot rows (radius, cap <= 32)
+        else rc = run_backbone_general(m, S->plan, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s);
+        if (rc != TD_OK) return rc;
         ProfScope ps(PC_HEAD, s);
         return td_launch_head(m->head, w.h, xg, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
                               d_final_ligand_h, s);

@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void radius_kernel(const float4 *__restrict__ 
     const int g = gid[i];
     const int beg = ptr[g], end = ptr[g + 1];
     const float4 xi = x4[i];
-    int32_t *row = cnbr + (int64_t)cptr[i] * TD_K;
+    int32_t *row = cnbr + (cptr ? (int64_t)cptr[i] : i) * TD_K;       // cptr == nullptr: one 32-slot row per node (cap <= 32)
     int cnt = 0;
     for (int base = beg; base < end && cnt < cap; base += 64) {
         const int j = base + lane;
@@ -796,6 +796,16 @@ __global__ void slots_to_dense_kernel(const int32_t *__restrict__ cptr, const in
 int td_launch_slots_to_dense(const int32_t *cptr, const int32_t *cnbr, int64_t N, int width, int32_t *out, hipStream_t s) {
     if (N == 0) return TD_OK;
     slots_to_dense_kernel<<<dim3((unsigned)((N * width + 255) / 256)), dim3(256), 0, s>>>(cptr, cnbr, N, width, out);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// radius graph with a fan-out cap <= 32 straight into the 32-slot neighbour table of the fast path
+int td_launch_radius32(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, float radius, int cap,
+                       int32_t *nbr, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    TD_CHECK_HIP(hipMemsetAsync(nbr, 0xff, (size_t)N * TD_K * sizeof(int32_t), s));
+    radius_kernel<<<dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, gid, N, radius * radius, cap, nullptr, nbr);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

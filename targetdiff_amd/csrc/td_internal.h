@@ -218,6 +218,8 @@ int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t
 int td_launch_graph_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                             const int32_t *prot_node, int64_t Np, const int32_t *lig_node, int64_t Nl, int64_t N, int k,
                             float radius, int max_graph_nodes, const int32_t *cptr, int32_t *cnbr, int64_t NC, hipStream_t s);
+int td_launch_radius32(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, float radius, int cap,
+                       int32_t *nbr, hipStream_t s);
 int td_launch_slots_to_dense(const int32_t *cptr, const int32_t *cnbr, int64_t N, int width, int32_t *out, hipStream_t s);
 // misc.hip
 int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int32_t *lig_node, int64_t Nl,

@@ -173,7 +173,9 @@ def test_radius_graph_and_forward_vs_oracle(state_dict, r, cap):
 
 
 # ------------------------------------------------------------------------------------------ sampling on a general graph
-@pytest.mark.parametrize('cfg', [dict(cutoff_mode='hybrid'), dict(knn=48), dict(knn=16), dict(knn=5)])
+@pytest.mark.parametrize('cfg', [dict(cutoff_mode='hybrid'), dict(knn=48), dict(knn=16), dict(knn=5),
+                                 dict(cutoff_mode='radius', r=5.0, max_num_neighbors=24),
+                                 dict(cutoff_mode='radius', r=6.0, max_num_neighbors=40)])
 def test_sampling_steps_on_general_graph_vs_oracle(state_dict, cfg):
     """5 reverse steps with injected draws through the sampler against the restatement's loop.  hybrid / k = 48: the plain
     session of the chunked path; k = 16 / 5: the caching session of the 32-slot path with the slots >= k masked (merged
