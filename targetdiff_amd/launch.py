@@ -45,20 +45,26 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None) -> int:
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    import time
     rc = 0
-    try:
-        for p in procs:
-            code = p.wait(timeout=timeout)
+    deadline = None if timeout is None else time.monotonic() + timeout
+    live = list(procs)
+    while live:                       # poll all ranks: one that dies must not leave the others waiting in a rendezvous
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
             if code != 0 and rc == 0:
                 rc = code
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
-    except subprocess.TimeoutExpired:
-        rc = 124
-        for q in procs:
-            if q.poll() is None:
+                for q in live:
+                    q.terminate()
+        if live and deadline is not None and time.monotonic() > deadline:
+            rc = rc or 124
+            for q in live:
                 q.kill()
+        if live:
+            time.sleep(0.05)
     return rc
 
 
@@ -67,5 +73,12 @@ def self_spawn_if_needed(n_gpus: int) -> bool:
     their status.  Returns False when nothing had to be spawned (N == 1, or already inside a launched rank)."""
     if n_gpus <= 1 or under_launcher():
         return False
+    try:
+        import torch
+        visible = torch.cuda.device_count()
+    except Exception:
+        visible = None
+    if visible is not None and n_gpus > visible:
+        raise SystemExit(f'--gpus {n_gpus}: only {visible} HIP device(s) visible to this process')
     sys.stdout.flush()
     raise SystemExit(spawn_ranks([sys.executable] + sys.argv, n_gpus))

@@ -55,3 +55,25 @@ def test_rank_environment_matches_torchrun():
     assert env['RANK'] == '3' and env['LOCAL_RANK'] == '3' and env['WORLD_SIZE'] == '8'
     assert env['MASTER_ADDR'] == '127.0.0.1' and env['MASTER_PORT'] == '29511'
     assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_a_failing_rank_ends_the_job(tmp_path):
+    """One rank exits with an error while the other would wait forever: spawn_ranks must notice, stop the rest and report."""
+    import time
+    script = tmp_path / 'w.py'
+    script.write_text('import os, sys, time\n'
+                      'if os.environ["RANK"] == "1":\n    sys.exit(3)\n'
+                      'time.sleep(600)\n')
+    t0 = time.time()
+    rc = launch.spawn_ranks([sys.executable, str(script)], 2, timeout=120)
+    assert rc == 3 and time.time() - t0 < 30
+
+
+def test_self_spawn_refuses_more_ranks_than_devices(monkeypatch):
+    import pytest
+    import torch
+    monkeypatch.delenv('RANK', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    assert launch.self_spawn_if_needed(1) is False
+    with pytest.raises(SystemExit, match='visible'):
+        launch.self_spawn_if_needed(torch.cuda.device_count() + 1)
