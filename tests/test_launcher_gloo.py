@@ -76,4 +76,4 @@ def test_self_spawn_refuses_more_ranks_than_devices(monkeypatch):
     monkeypatch.delenv('WORLD_SIZE', raising=False)
     assert launch.self_spawn_if_needed(1) is False
     with pytest.raises(SystemExit, match='visible'):
-        launch.self_spawn_if_needed(torch.cuda.device_count() + 1)
+        launch.self_spawn_if_needed(torch.cuda.device_count() + 2)
