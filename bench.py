@@ -432,7 +432,9 @@ def main():
         if not p['launches']:
             return None
         ms = p['ms'] / p['launches']
-        per_row = KEY_PASS_FLOP_EXECUTED if default_graph else (flop_key if cls == 'x2h_k' else flop_val)
+        # 32-slot rows with fewer than 32 edges (k < 32, radius cap < 32): the per-edge terms count the edges that exist
+        per_row = (2 * (fan_in * 128 * 20 + 128 * 128 + fan_in * 128 * 16) if fan_in <= 32
+                   else (flop_key if cls == 'x2h_k' else flop_val))
         achieved = per_row * rows_per_launch / (ms * 1e-3) / 1e12
         # HBM traffic of the same kernel: PMC counters cannot be read in-process, so this is the figure of the COMMITTED
         # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
@@ -463,6 +465,8 @@ def main():
     f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows if default_graph else None)
     if not default_graph:       # per-chunk work scales with the chunks per row (uniform for k-NN / radius; hybrid: protein rows)
         f_exec *= cpn
+    if fan_in < 32:             # fewer edges per row: scale the per-edge share (about 80 % of a row's FLOPs) -- an estimate
+        f_exec *= 0.2 + 0.8 * fan_in / 32.0
     whole_step = {'executed_flop': f_exec, 'executed_tflops': f_exec / sec_per_step / 1e12,
                   'executed_frac_of_fp32_peak': f_exec / sec_per_step / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                   'f_alg_flop': F_ALG_PER_NODE * n_nodes, 'f_alg_tflops': F_ALG_PER_NODE * n_nodes / sec_per_step / 1e12,
