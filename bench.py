@@ -456,7 +456,7 @@ def main():
                 'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
                 'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}
 
-    vk, kk = ('edge_value16_kernel', 'edge_key16_kernel<false, 16, 0>') if default_graph else ('edge_value16_ragged_kernel', 'edge_key16_kernel<false, 16, 0, true>')
+    vk, kk = ('edge_value16_kernel', 'edge_key16_kernel<false, 16, 0, false>') if default_graph else ('edge_value16_ragged_kernel', 'edge_key16_kernel<false, 16, 0, true>')
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
