@@ -482,7 +482,9 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded random weights of the reference architecture; '
         + ('real 1h36 pocket geometry' if args.workload in ('c1', 'c2') else 'synthetic pockets')
         + '; k-NN rule (d2 association, ties -> lower index) is the project\'s: torch_cluster is not in the reference tree, '
-          'parity-unpinned upstream)',
+          'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
+        + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
+           '(fp32-equivalent: errors against the reference golden unchanged, profiles/r02c_split_error_table.txt)') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
