@@ -264,7 +264,7 @@ def test_forward_1h36_vs_reference_golden(model):
 
 
 def test_forward_deterministic_and_batch_independent(model):
-    """Size-independent properties at a larger batch: bit-identical reruns (no atomics), and every replica
+    """Size-independent properties at a larger batch: bit-identical reruns (no atomics in any arithmetic), and every replica
     of the same (pocket, ligand) graph gets bit-identical outputs wherever it sits in the ragged pack."""
     from targetdiff_amd import workloads
     dev = _dev()
