@@ -196,7 +196,7 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int alt) {
     EdgeOff o;
@@ -235,6 +235,35 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
                             else if (kk == TD_NG) v = m.w0[(size_t)n * in_dim + type];
                             d16[((((size_t)cls * 2 + sl) * 6 + st) * 64 + lane) * 8 + hb] = v;
                         }
+            }
+    }
+    // the same table as exact bf16 piece triples, A-operand order of v_mfma_f32_16x16x32_bf16 (lane = (hidden lo, k group g),
+    // slots j = 0..7 -> k = 8g + j; k < 20 Gaussians, k = 20 the edge-type column, k >= 21 zero: P_i is added separately)
+    o.R16p = 0;
+    if (out_dim == TD_H) {
+        o.R16p = pk.alloc((size_t)2 * 2 * 3 * 8 * 48 * 4);
+        uint32_t *dp = reinterpret_cast<uint32_t *>(pk.data.data() + o.R16p);
+        for (int cls = 0; cls < 2; ++cls)
+            for (int sl = 0; sl < 2; ++sl) {
+                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+                for (int hb = 0; hb < 8; ++hb)
+                    for (int l48 = 0; l48 < 48; ++l48) {
+                        const int lo = l48 & 15, g = l48 >> 4, n = 16 * hb + lo;
+                        uint32_t pieces[3][8];
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = 8 * g + j;
+                            float r = 0.f;
+                            if (kk < TD_NG) r = m.w0[(size_t)n * in_dim + 4 + TD_NG * type + kk];
+                            else if (kk == TD_NG) r = m.w0[(size_t)n * in_dim + type];
+                            for (int p = 0; p < 3; ++p) {
+                                pieces[p][j] = bf16_rne(r);
+                                r -= bf16_to_f32(pieces[p][j]);
+                            }
+                        }
+                        for (int p = 0; p < 3; ++p)
+                            for (int w = 0; w < 4; ++w)
+                                dp[(((((size_t)cls * 2 + sl) * 3 + p) * 8 + hb) * 48 + l48) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+                    }
             }
     }
     o.gamma = pack_vec(pk, m.g, TD_H);
@@ -440,7 +469,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     const float *D = m->blob;
     m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
-    auto edge = [&](const EdgeOff &o) { return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt}; };
+    auto edge = [&](const EdgeOff &o, bool split = false) {
+        return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
+                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0};
+    };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
                            m->opt.node_proj_split != 0};
@@ -448,7 +480,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
         Ly.nodeX2h = node(lo[l].nx); Ly.nodeH2x = node(lo[l].nh);
-        Ly.hk = edge(lo[l].hk); Ly.hv = edge(lo[l].hv); Ly.xk = edge(lo[l].xk); Ly.xv = edge(lo[l].xv);
+        Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true); Ly.xk = edge(lo[l].xk); Ly.xv = edge(lo[l].xv);
         Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
@@ -471,6 +503,12 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     else if (strcmp(name, "node_proj_split") == 0) {
         m->opt.node_proj_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+    } else if (strcmp(name, "edge_key_split") == 0) {
+        m->opt.edge_key_split = value != 0;
+        for (int l = 0; l < m->cfg.num_layers; ++l) {
+            m->layers[l].hk.use_split = m->layers[l].hk.R16p && value != 0;
+            m->layers[l].hv.use_split = m->layers[l].hv.R16p && value != 0;
+        }
     } else if (strcmp(name, "session_hop_levels") == 0) {
         if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }
         m->opt.session_hop_levels = value;
@@ -483,6 +521,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     if (!m || !name || !value) { td_set_error("td_model_get_option: null argument"); return TD_EINVAL; }
     if (strcmp(name, "h2x_fused") == 0) *value = m->opt.h2x_fused;
     else if (strcmp(name, "node_proj_split") == 0) *value = m->opt.node_proj_split;
+    else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
     else { td_set_error("td_model_get_option: unknown option '%s'", name); return TD_EINVAL; }
@@ -525,9 +564,11 @@ int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int
              const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
     return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s);
 }
+// lig / Nl: the ligand rows of the batch (all of them are among `rows`: every row list of a step contains the ligand atoms)
 int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
-               const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, hipStream_t s) {
-    return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, s);
+               const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig,
+               int64_t Nl, hipStream_t s) {
+    return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
@@ -608,7 +649,7 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
             }
             proj_done = false;
             { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
             if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
@@ -876,10 +917,11 @@ extern "C" int td_refine_forward(const td_model *m, const float *d_h, const floa
     TD_CHECK_HIP(hipMemcpyAsync(w.node_ptr, d_node_ptr, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if ((rc = td_launch_node_gid(w.node_ptr, N, B, w.gid, s)) != TD_OK) return rc;
     if ((rc = td_launch_pack_x(d_x, d_mask_ligand, N, w.x4a, s)) != TD_OK) return rc;
-    // ligand dst list for h2x; its length is needed for the launch shape -> one small D2H (this entry point
-    // mirrors the refine_net seam; the sampler path uses td_model_forward, which knows N_l on the host).
+    // ligand row list (h2x destinations; the x2h value pass serves the ligand rows from it); its length is needed for the
+    // launch shapes -> one small D2H (this entry point mirrors the refine_net seam; the sampler path uses td_model_forward,
+    // which knows N_l on the host).
     int32_t nl = 0;
-    if (!fix_x) {
+    {
         if ((rc = td_launch_ligand_list(d_mask_ligand, N, w.lig_node, w.lig_node + N, s)) != TD_OK) return rc;
         TD_CHECK_HIP(hipMemcpyAsync(&nl, w.lig_node + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         TD_CHECK_HIP(hipStreamSynchronize(s));
@@ -891,7 +933,6 @@ extern "C" int td_refine_forward(const td_model *m, const float *d_h, const floa
         GraphPlan p;
         int64_t nl_all = 0;
         if ((rc = plan_from_mask(m->cfg, d_mask_ligand, w.node_ptr, N, B, s, &p, &nl_all)) != TD_OK) return rc;
-        if (fix_x && nl_all > 0 && (rc = td_launch_ligand_list(d_mask_ligand, N, w.lig_node, w.lig_node + N, s)) != TD_OK) { plan_destroy(p, s); return rc; }
         rc = plan_layout(p, w.node_ptr, w.gid, s);
         if (rc == TD_OK) rc = run_backbone_general(m, p, w, d_out_h, N, nl_all, fix_x, max_graph_nodes, &xf, s);
         if (rc == TD_OK) rc = td_launch_unpack_x(xf, N, d_out_x, s);
@@ -1368,13 +1409,13 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
     TD_TRY(key_pass(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
     TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-    TD_TRY(value_pass(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, s));
+    TD_TRY(value_pass(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, nullptr, 0, s));
     if (S->use_fwd) {      // layer-1 x2h output of the protein-only graph (valid wherever the ligand is two hops away)
         const TdLayer &L1 = m->layers[1];
         TD_TRY(td_launch_node_proj(L1.nodeX2h, S->h1s, N, nullptr, 0x1f, w.P, w.q, s));
         TD_TRY(key_pass(L1.hk, L1, w.x4a, S->snbr, S->ews, w.P, w.q, S->prot_node, nullptr, N_p, w.alpha, s));
         TD_TRY_HIP(hipMemcpyAsync(S->h2s, S->h1s, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-        TD_TRY(value_pass(L1.hv, L1, w.x4a, S->snbr, w.P, S->prot_node, nullptr, N_p, S->h2s, w.alpha, s));
+        TD_TRY(value_pass(L1.hv, L1, w.x4a, S->snbr, w.P, S->prot_node, nullptr, N_p, S->h2s, w.alpha, nullptr, 0, s));
     }
 #undef TD_TRY
 #undef TD_TRY_HIP
@@ -1448,7 +1489,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     {   // layer 0, x2h: only ligand rows need new projections, only dirty rows need the attention passes
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L0.nodeX2h, w.h, Nl, w.lig_node, 0x1f, S->P0, S->q0, s)) != TD_OK) return rc; }
         { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
     if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;

@@ -43,13 +43,17 @@ struct Args16 {
     // general graphs (ragged kernels only): the in-edges of node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha
     const int32_t *chunk_node;
     const int32_t *cptr;
+    // value pass with the bf16 first layer: the ligand rows (all of them are in the row list)
+    const int32_t *lig_rows;
+    int64_t lig_count;
 };
 
-__device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end) {
+// contiguous share of `count` rows for block b of a (sub-)grid of G blocks
+__device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end, int G = gridDim.x,
+                                                int b = blockIdx.x) {
     if (count_ptr) count = *count_ptr;
-    const int G = gridDim.x;
-    int chunk = blockIdx.x;
-    if ((G & 7) == 0) chunk = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // XCD x gets the x-th eighth
+    int chunk = b;
+    if ((G & 7) == 0) chunk = (b & 7) * (G >> 3) + (b >> 3);   // XCD x gets the x-th eighth
     const int64_t per = (count + G - 1) / G;
     begin = (int64_t)chunk * per;
     end = begin + per < count ? begin + per : count;
@@ -121,6 +125,39 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
     for (int hb = 0; hb < 8; ++hb) r.pit[hb] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 16 * hb + lo];
 }
 
+// LayerNorm over the 128 hidden units of each edge + ReLU, in the transposed accumulator layout (a lane owns 32 of an edge's
+// 128 hidden units for each of its two edges; the other 96 sit in the lanes lo + 16 g')
+__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ GAM, const float *__restrict__ BET, int g,
+                                             floatx4_t (&acc)[2][8]) {
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
+        const float mean = td_sum_groups(s1) * (1.0f / TD_H);
+        float s2 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dv = acc[eb][hb][r] - mean;
+                s2 = fmaf(dv, dv, s2);
+            }
+        const float rstd = __frsqrt_rn(td_sum_groups(s2) * (1.0f / TD_H) + 1e-5f);
+        const float nms = -mean * rstd;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            const float4 gm = *reinterpret_cast<const float4 *>(GAM + 16 * hb + 4 * g);
+            const float4 bm = *reinterpret_cast<const float4 *>(BET + 16 * hb + 4 * g);
+            acc[eb][hb][0] = fmaxf(fmaf(fmaf(acc[eb][hb][0], rstd, nms), gm.x, bm.x), 0.f);
+            acc[eb][hb][1] = fmaxf(fmaf(fmaf(acc[eb][hb][1], rstd, nms), gm.y, bm.y), 0.f);
+            acc[eb][hb][2] = fmaxf(fmaf(fmaf(acc[eb][hb][2], rstd, nms), gm.z, bm.z), 0.f);
+            acc[eb][hb][3] = fmaxf(fmaf(fmaf(acc[eb][hb][3], rstd, nms), gm.w, bm.w), 0.f);
+        }
+    }
+}
+
+
 // radial / type first layer on the gathered operands + LayerNorm + ReLU: z^T in acc[eb][hb]
 template <bool LOAD_EW>
 __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const float4 *__restrict__ Rt,
@@ -178,33 +215,122 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    // ---- LayerNorm over the 128 hidden units of each edge + ReLU ---------------------------------------------------
+    td_ln_relu16(GAM, BET, g, acc);
+}
+
+// ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
+// Both operands as exact bf16 piece triples (the table pre-split at pack time, the per-edge Gaussians split in registers),
+// 6 of the 9 piece products, fp32 accumulation: fp32-equivalent (the dropped products are below 2^-24 relative).  One
+// instruction covers the whole K = 21 (20 Gaussians + the edge-type column; k = 8 g + j for lane group g, slot j) at half the
+// issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds after the products.
+typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
+constexpr int E16P_U4 = 2 * 2 * 3 * 8 * 48;                 // uint4 entries of the piece table [cls][slot][piece][hb][48] (72 KiB)
+constexpr int E16P_HALF_U4 = E16P_U4 / 2;                   // one destination class
+
+__device__ __forceinline__ floatx4_t td_mfma16b(uint4 a, uint4 b, floatx4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned td_cvt_pk_bf16_e(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// exact split of a pair of fp32 values into three packed bf16 pairs
+__device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = td_cvt_pk_bf16_e(x, y);
+    float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+    p2 = td_cvt_pk_bf16_e(rx, ry);
+    rx -= __uint_as_float(p2 << 16);
+    ry -= __uint_as_float(p2 & 0xffff0000u);
+    p3 = td_cvt_pk_bf16_e(rx, ry);
+}
+
+// Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
+// offj[j] = Gaussian centre of k = 8g + j.  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
+// PI_LATE: the P_i loads are issued first and consumed after the products (their latency hides behind the MFMAs at the
+// price of 32 registers); otherwise P_i is added up front.
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE>
+__device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
+                                                       const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                       const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
+                                                       floatx4_t (&acc)[2][8], Edge2 &ed) {
+    const int lo = lane & 15, g = lane >> 4;
+    const int l48 = (g < 3 ? g : 2) * 16 + lo;
+    const float4 xi = r.xi;
+    ed.xi = xi;
+    const int cls = xi.w > 0.5f ? 0 : 1;
+    // dst-side projection P_i in the accumulator layout (hidden 16hb + 4g + r)
+    float4 pi[8];
+    {
+        const float *pp = a.P + (size_t)i * (4 * TD_H) + a.p_off + 4 * g;
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
-        float s1 = 0.f;
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
-        const float mean = td_sum_groups(s1) * (1.0f / TD_H);
-        float s2 = 0.f;
+        for (int hb = 0; hb < 8; ++hb) pi[hb] = *reinterpret_cast<const float4 *>(pp + 16 * hb);
+    }
+    auto add_pi = [&]() {
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dv = acc[eb][hb][r] - mean;
-                s2 = fmaf(dv, dv, s2);
+            for (int eb = 0; eb < 2; ++eb) {
+                acc[eb][hb][0] += pi[hb].x; acc[eb][hb][1] += pi[hb].y; acc[eb][hb][2] += pi[hb].z; acc[eb][hb][3] += pi[hb].w;
             }
-        const float rstd = __frsqrt_rn(td_sum_groups(s2) * (1.0f / TD_H) + 1e-5f);
-        const float nms = -mean * rstd;
+    };
+    if (!PI_LATE) add_pi();
+    int slot[2];
+    bool has[2][2];
+    float gv[2][8];
 #pragma unroll
-        for (int hb = 0; hb < 8; ++hb) {
-            const float4 gm = *reinterpret_cast<const float4 *>(GAM + 16 * hb + 4 * g);
-            const float4 bm = *reinterpret_cast<const float4 *>(BET + 16 * hb + 4 * g);
-            acc[eb][hb][0] = fmaxf(fmaf(fmaf(acc[eb][hb][0], rstd, nms), gm.x, bm.x), 0.f);
-            acc[eb][hb][1] = fmaxf(fmaf(fmaf(acc[eb][hb][1], rstd, nms), gm.y, bm.y), 0.f);
-            acc[eb][hb][2] = fmaxf(fmaf(fmaf(acc[eb][hb][2], rstd, nms), gm.z, bm.z), 0.f);
-            acc[eb][hb][3] = fmaxf(fmaf(fmaf(acc[eb][hb][3], rstd, nms), gm.w, bm.w), 0.f);
+    for (int eb = 0; eb < 2; ++eb) {
+        ed.valid[eb] = r.j[eb] >= 0;
+        const float4 xj = r.xj[eb];
+        if (LOAD_EW) ed.ew[eb] = r.ew[eb];
+        const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
+        const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+        ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
+        slot[eb] = xj.w > 0.5f ? 0 : 1;
+        has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
+        has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            const float u = dist - offj[j];
+            gv[eb][j] = !ed.valid[eb] ? 0.f : (k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f));
         }
     }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        if (!(has[sl][0] || has[sl][1])) continue;
+        // B: the edge inputs of this source class in 3 pieces (edges of the other class contribute nothing)
+        uint4 bm[2][3];
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = keep ? gv[eb][j] : 0.f;
+            td_split_pair(m[0], m[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
+            td_split_pair(m[2], m[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
+            td_split_pair(m[4], m[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
+            td_split_pair(m[6], m[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
+        }
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            uint4 ar[2][3];                 // A: table pieces of hidden blocks 2hp, 2hp + 1
+            const uint4 *Rs = Rp + (size_t)(((ONE_CLASS ? 0 : cls * 2) + sl) * 3) * 8 * 48 + l48;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ar[h2][p] = Rs[(p * 8 + 2 * hp + h2) * 48];
+            // lane group 3 (k = 24 .. 31) re-reads group 2's entries: its B slots are all zero, so they contribute nothing
+            // low-order products first; two hidden blocks x two edge blocks interleave four accumulator chains
+#define TD_PROD(pa, pb)                                                                                  \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < 2; ++eb)      \
+        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][pa], bm[eb][pb], acc[eb][2 * hp + h2]);
+            TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
+#undef TD_PROD
+        }
+    }
+    if (PI_LATE) add_pi();
+    td_ln_relu16(GAM, BET, g, acc);
 }
 
 template <bool LOAD_EW>
@@ -223,6 +349,8 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, one LDS copy of the weights per CU
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
+constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
+constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -231,25 +359,31 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_
 // STAGE only tags the instantiation (0 = x2h, 1 = h2x) so that profilers report the two stages separately.
 // RAW = true (general graphs): `it` walks chunks, the dst node comes from chunk_node, and the scaled logits are stored as they
 //             are (-inf on pads): the softmax over all chunks of a node happens in the ragged value / xv kernels.
-template <bool XV, int WAVES, int STAGE, bool RAW = false>
+// SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
+template <bool XV, int WAVES, int STAGE, bool RAW = false, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
+    constexpr int RF = SPLIT ? E16P_U4 * 4 : E16_R_FLOATS;       // floats of the radial/type table
+    constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);       // [hb][r][jq][lane] x 4 j
-    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const float4 *Wq = reinterpret_cast<const float4 *>(lds + RF);       // [hb][r][jq][lane] x 4 j
+    const float *GAM = lds + RF + E16_WQ_FLOATS, *BET = GAM + TD_H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, WAVES * 64);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), nw4, tid,
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + RF), nw4, tid,
                        WAVES * 64);
-        if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
-        else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
+        if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
+        else if (tid < 2 * TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
     }
-    float offk[E16_STEPS];
+    float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
 #pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    for (int s = 0; s < NOFF; ++s) {
+        const int k = SPLIT ? 8 * g + s : 4 * s + g;
+        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+    }
     __syncthreads();
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
@@ -259,10 +393,16 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         const int64_t i = RAW ? (int64_t)a.chunk_node[c] : c;          // its dst node
         floatx4_t acc[2][8];
         Edge2 ed;
-        td_first_layer16<!XV && !RAW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+        if constexpr (SPLIT) {
+            RowIn16 rin;
+            td_row_index16(a, i, c, lane, rin);
+            td_row_gather16<!XV && !RAW>(a, i, c, lane, rin, acc);
+            td_first_layer_split16<!XV && !RAW, false, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+        } else
+            td_first_layer16<!XV && !RAW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
 
         if (XV) {
-            const float *Wx = lds + E16_R_FLOATS;                 // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
+            const float *Wx = lds + RF;                 // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
             floatx4_t xv[2];
             const float b2 = a.mlp.b2[lo];
 #pragma unroll
@@ -474,36 +614,97 @@ constexpr int V16_ZB_STRIDE = 132;
 constexpr int V16_WAVE_FLOATS = 2 * 32 * V16_TB_STRIDE;   // 1280 >= 8 * 132: two transpose tiles, later the Zbar half
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
+constexpr size_t V16S_LDS_BYTES =
+    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
 
+// SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
+// (36 KiB), so a workgroup makes two passes: the protein rows of its contiguous share of the row list with the
+// protein-destination half, then -- after re-staging the other half -- its stride of the ligand rows (a.lig_rows: every
+// ligand atom; the row lists of a sampling session always contain them all).  Ligand rows are a few per cent of a launch
+// and cost about twice a protein row, so they are dealt round-robin over all waves of the launch rather than left to the
+// workgroups whose share happens to hold them.  A wave looks at 64 candidate rows at a time (lane t reads the class of
+// candidate t) and walks the ones of the pass's class.
+template <bool SPLIT>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
+    constexpr int RF = SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS;
+    constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wv = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);          // [kq 32][n 128] x 4 k
+    const float4 *Wv = reinterpret_cast<const float4 *>(lds + RF);          // [kq 32][n 128] x 4 k
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
-    float *TB = lds + E16_R_FLOATS + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
-    float *SB = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
-    float *B2 = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
+    float *TB = lds + RF + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
+    float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
+    float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
     const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
     {
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, V16_WAVES * 64);
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), V16_W_FLOATS / 4, tid,
+        td_stage_lds16(SPLIT ? reinterpret_cast<const float4 *>(a.mlp.R16p) + E16P_HALF_U4 : reinterpret_cast<const float4 *>(a.mlp.R16),
+                       reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid,
                        V16_WAVES * 64);
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
         else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
         else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
     }
-    float offk[E16_STEPS];
+    float offk[NOFF];
 #pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    for (int s = 0; s < NOFF; ++s) {
+        const int k = SPLIT ? 8 * g + s : 4 * s + g;
+        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+    }
     __syncthreads();
-    int64_t begin, end;
-    td_node_range16(a.count, a.count_ptr, begin, end);
 
     // Software pipeline over the wave's rows: the neighbour indices of row n + 1 are fetched at the top of row n, and its
     // gathers (32 neighbour projections straight into the accumulator registers, which are free once Zbar is done) are
     // issued before row n's output GEMV, so that they land while it runs.
-    auto row_id = [&](int64_t itx) -> int64_t { return a.rows ? (int64_t)a.rows[itx] : itx; };
+#pragma unroll 1
+  for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+    // the pass's candidates: entries scan + stride t (t = 0, 1, ..) of `list` (nullptr: the identity), below `end`
+    const int pass_cls = 1 - pass;               // SPLIT: destination class served (1 = protein, 0 = ligand)
+    const int32_t *list = a.rows;
+    int64_t scan, end;
+    int stride = V16_WAVES;
+    if (pass == 0) {
+        td_node_range16(a.count, a.count_ptr, scan, end);
+        scan += wid;
+    } else {
+        if (a.lig_count == 0) break;
+        __syncthreads();                          // every wave is done with the protein half
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16p), reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
+        __syncthreads();
+        list = a.lig_rows;
+        end = a.lig_count;
+        scan = (int64_t)blockIdx.x * V16_WAVES + wid;
+        stride = gridDim.x * V16_WAVES;
+    }
+    auto row_id = [&](int64_t itx) -> int64_t { return list ? (int64_t)list[itx] : itx; };
+    int cand = 0;                      // SPLIT: lane t = row id of candidate t of the current window
+    unsigned long long todo = 0ull;    // SPLIT: candidates of the window still to do
+    auto next_row = [&]() -> int64_t {
+        if (!SPLIT) {
+            if (scan >= end) return -1;
+            const int64_t r = row_id(scan);
+            scan += V16_WAVES;
+            return r;
+        }
+        while (true) {
+            if (todo) {
+                const int t = __ffsll(todo) - 1;
+                todo &= todo - 1;
+                return (int64_t)__builtin_amdgcn_readlane(cand, t);
+            }
+            if (scan >= end) return -1;
+            const int64_t idx = scan + (int64_t)stride * lane;
+            scan += (int64_t)stride * 64;
+            bool mine = false;
+            cand = 0;
+            if (idx < end) {
+                cand = (int)row_id(idx);
+                mine = (a.x4[cand].w > 0.5f ? 0 : 1) == pass_cls;
+            }
+            todo = __ballot(mine);
+        }
+    };
     auto load_side = [&](int64_t ix, float (&alx)[8], float &h0, float &h1) {
         // A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads); residual row
         const float *ap = a.alpha + ((size_t)ix * TD_HEADS + lo) * TD_K + 8 * g;
@@ -512,27 +713,25 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         h0 = a.h[(size_t)ix * TD_H + lane];
         h1 = a.h[(size_t)ix * TD_H + 64 + lane];
     };
-    int64_t it = begin + wid;
-    int64_t i = 0;
+    int64_t i = next_row();
     RowIn16 rin;
     floatx4_t acc[2][8];
     float al[8], hres0 = 0.f, hres1 = 0.f;
-    if (it < end) {
-        i = row_id(it);
+    if (i >= 0) {
         td_row_index16(a, i, i, lane, rin);
         td_row_gather16<false>(a, i, i, lane, rin, acc);
         load_side(i, al, hres0, hres1);
     }
-    for (; it < end; it += V16_WAVES) {
-        const bool more = it + V16_WAVES < end;
-        int64_t inext = 0;
+    while (i >= 0) {
+        const int64_t inext = next_row();
+        const bool more = inext >= 0;
         RowIn16 rnext;
-        if (more) {
-            inext = row_id(it + V16_WAVES);
-            td_row_index16(a, inext, inext, lane, rnext);
-        }
+        if (more) td_row_index16(a, inext, inext, lane, rnext);
         Edge2 ed;
-        td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+        if constexpr (SPLIT)
+            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+        else
+            td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
 
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
@@ -569,8 +768,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             td_row_gather16<false>(a, inext, inext, lane, rnext, acc);
             load_side(inext, al, hres0, hres1);
             rin = rnext;
-            i = inext;
         }
+        i = inext;
 
         // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -------
         // zb[hb][r] = Zbar[head 4g + r][hidden 16hb + lo]; heads 8ph .. 8ph+7 sit in lane groups g = 2ph, 2ph + 1
@@ -595,6 +794,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
     }
+  }
 }
 
 // ================================================================================================ general graphs
@@ -812,6 +1012,8 @@ __global__ __launch_bounds__(XV16_WAVES * 64) void edge_xv16_ragged_kernel(Args1
 // Workgroups of a row-loop kernel: one per CU (256) when there is a row per wave for all of them.  With fewer rows the
 // waves of a workgroup would queue on their SIMD's shared matrix / vector pipe while other CUs idle, so small launches
 // spread over as many workgroups as there are rows (up to one per CU) and leave part of each workgroup's waves without a row.
+#define TD_LDS_ONCE(fn, bytes) do { static TdLdsOnce once; int _rc = td_set_lds(once, reinterpret_cast<const void *>(fn), bytes); if (_rc != TD_OK) return _rc; } while (0)
+
 static int grid16(int64_t count, int waves) {
     int64_t g = (count + waves - 1) / waves;
     if (g < 256) g = count < 256 ? count : 256;
@@ -831,7 +1033,15 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    if (rows && !count_ptr)      // h2x key pass (ligand row list of known length)
+    if (mlp.use_split) {         // first layer on bf16 piece triples
+        if (rows && !count_ptr) {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, false, true>), K16S_LDS_BYTES);
+            edge_key16_kernel<false, K16S_WAVES, 1, false, true><<<dim3(grid16(count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
+        } else {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, false, true>), K16S_LDS_BYTES);
+            edge_key16_kernel<false, K16S_WAVES, 0, false, true><<<dim3(grid16(count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
+        }
+    } else if (rows && !count_ptr)      // h2x key pass (ligand row list of known length)
         edge_key16_kernel<false, K16_WAVES, 1><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     else
         edge_key16_kernel<false, K16_WAVES, 0><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
@@ -856,15 +1066,20 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
-                           hipStream_t s) {
+                           const int32_t *lig_rows, int64_t lig_count, hipStream_t s) {
     if (count == 0) return TD_OK;
     int rc_lds;
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_value16_kernel), V16_LDS_BYTES)) != TD_OK) return rc_lds; }
+    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_value16_kernel<false>), V16_LDS_BYTES)) != TD_OK) return rc_lds; }
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
-    edge_value16_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    if (mlp.use_split) {
+        TD_LDS_ONCE((edge_value16_kernel<true>), V16S_LDS_BYTES);
+        a.lig_rows = lig_rows; a.lig_count = lig_count;
+        edge_value16_kernel<true><<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16S_LDS_BYTES, s>>>(a);
+    } else
+        edge_value16_kernel<false><<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -887,7 +1102,6 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
 }
 
 // ---- general graphs: chunk-indexed nbr / ew / alpha (see the ragged kernels above) --------------------------------
-#define TD_LDS_ONCE(fn, bytes) do { static TdLdsOnce once; int _rc = td_set_lds(once, reinterpret_cast<const void *>(fn), bytes); if (_rc != TD_OK) return _rc; } while (0)
 
 // stage 0: x2h keys, 1: h2x keys.  `chunks`: optional list of chunk ids (count = its length), else all NC chunks.
 int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr,

@@ -230,6 +230,19 @@ def test_model_options_live_in_the_handle(state_dict):
     assert torch.equal(res[(1, 1)]['final_h'], res[(1, 0)]['final_h'])          # fusing the h2x halves changes no arithmetic
     with pytest.raises(RuntimeError, match='unknown option'):
         nat.set_option('no_such_switch', 1)
+    # key passes with the radial/type first layer on bf16 piece triples
+    for fused in (1, 0):
+        model = _model(state_dict)
+        nat = model._native(dev)
+        nat.set_option('edge_key_split', 1)
+        nat.set_option('h2x_fused', fused)
+        assert nat.get_option('edge_key_split') == 1
+        p = model(inp['protein_pos'], inp['protein_v'], inp['batch_protein'], inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'])
+        print(f'edge_key_split fused={fused}: |dx| = {_maxdiff(p["pred_ligand_pos"], g["pred_ligand_pos"]):.2e}  '
+              f'|dh| = {_maxdiff(p["final_h"], g["final_h"]):.2e}  vs fp32 first layer '
+              f'{float((p["final_h"] - res[(1, fused)]["final_h"]).abs().max()):.2e}')
+        assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
+        assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
 
 
 @pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
