@@ -20,11 +20,14 @@ rank per GPU over RCCL) every rank samples its own pocket replica -- pockets sha
 collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = edge_value16_kernel (x2h value pass; the key pass edge_key16_kernel<false,16,0> is its
-               twin and is reported under roofline.key_pass);
+  roofline     dominant kernel = edge_value16_kernel (x2h value pass; the key pass edge_key16_kernel is its twin and is
+               reported under roofline.key_pass);
                achieved = executed algorithmic FLOPs per launch (327,680 per dst node) / mean
                launch time from HIP events recorded on the launch stream inside the timed region;
-               peak = 157.3 TFLOP/s (fp32 MFMA = fp32 vector peak, dense).
+               peak = the matrix-pipe bound of the kernel as built, in the same algorithmic FLOPs: with the radial/type
+               first layer on bf16 piece triples (default) that layer's 6 x 32-deep bf16 products are priced at the
+               2.5 PFLOP/s dense bf16 peak and everything else at the 157.3 TFLOP/s fp32 MFMA peak (= 196 TFLOP/s for a
+               32-edge row); with --option edge_key_split=0 it is the fp32 peak.  frac_of_fp32_peak is reported beside it.
   cpu_baseline the oracle restatement (torch CPU, same weights) timed on this host's cores over a bounded
                sample of the same workload (the same pocket, fewer samples, a few steps).
 """
@@ -46,6 +49,9 @@ from targetdiff_amd import capi, launch, workloads  # noqa: E402
 from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: ~2.5 PFLOP/s dense bf16 (2495 measured)
+# first layer of an attention pass on bf16 piece triples: 6 piece products, K padded 21 -> 32, all 32 slots of the row
+FIRST_LAYER_FLOP_BF16_EXECUTED = 6 * 2 * 32 * 128 * 32
 PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E ~ 8 TB/s
 # Dominant kernels: edge_value16_kernel (x2h value pass) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
 # identical for the two passes:
@@ -426,6 +432,7 @@ def main():
     cpn = (fan_in + 31) // 32
     flop_key = cpn * KEY_PASS_FLOP_EXECUTED
     flop_val = cpn * (KEY_PASS_FLOP_EXECUTED - 2 * 128 * 128) + 2 * 128 * 128
+    split = bool(model._native(dev).get_option('edge_key_split'))
 
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]
@@ -436,6 +443,15 @@ def main():
         per_row = (2 * (fan_in * 128 * 20 + 128 * 128 + fan_in * 128 * 16) if fan_in <= 32
                    else (flop_key if cls == 'x2h_k' else flop_val))
         achieved = per_row * rows_per_launch / (ms * 1e-3) / 1e12
+        # matrix-pipe bound of the kernel as built (algorithmic TFLOP/s): the first layer's share at the bf16 peak when it runs
+        # on piece triples (32-slot rows only; the chunked value pass keeps fp32), the rest at the fp32 peak
+        first_alg = 2 * min(fan_in, 32) * 128 * 20 * (cpn if fan_in > 32 else 1)
+        split_here = split and (default_graph or cls == 'x2h_k')
+        if split_here:
+            t_min = cpn * FIRST_LAYER_FLOP_BF16_EXECUTED / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
+            peak = per_row / t_min
+        else:
+            peak = PEAK_FP32_MFMA_TFLOPS
         # HBM traffic of the same kernel: PMC counters cannot be read in-process, so this is the figure of the COMMITTED
         # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- static, see traffic_source
@@ -447,7 +463,9 @@ def main():
             traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
             source = f'profiles/{traffic_file} (static: PMC pass of an earlier run of this command, not measured in this run)'
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
-                'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS, 'frac_of_fp32_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'first_layer': 'bf16 x 3 piece triples (v_mfma_f32_16x16x32_bf16)' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
                 'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
@@ -456,7 +474,12 @@ def main():
                 'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
                 'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}
 
-    vk, kk = ('edge_value16_kernel', 'edge_key16_kernel<false, 16, 0, false>') if default_graph else ('edge_value16_ragged_kernel', 'edge_key16_kernel<false, 16, 0, true>')
+    if default_graph:
+        vk, kk = (('edge_value16_kernel<true>', 'edge_key16_kernel<false, 12, 0, false, true>') if split
+                  else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, false, false>'))
+    else:
+        vk = 'edge_value16_ragged_kernel'
+        kk = 'edge_key16_kernel<false, 12, 0, true, true>' if split else 'edge_key16_kernel<false, 16, 0, true, false>'
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
@@ -484,10 +507,12 @@ def main():
         + '; k-NN rule (d2 association, ties -> lower index) is the project\'s: torch_cluster is not in the reference tree, '
           'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
         + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
-           '(fp32-equivalent: errors against the reference golden unchanged, profiles/r02c_split_error_table.txt)') + ')',
+           '(fp32-equivalent: errors against the reference golden unchanged, profiles/r02d_split_error_table.txt)')
+        + ('; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split' if split else '') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
+                   'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
     }

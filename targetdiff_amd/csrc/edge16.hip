@@ -1111,7 +1111,16 @@ int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, c
     Args16 a = {};
     a.x4 = x4; a.nbr = cnbr; a.P = P; a.q = q; a.rows = chunks; a.alpha = alpha; a.count = count; a.mlp = mlp;
     a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0; a.chunk_node = chunk_node;
-    if (stage == 0) {
+    if (mlp.use_split) {
+        const dim3 grid(grid16(count, K16S_WAVES)), block(K16S_WAVES * 64);
+        if (stage == 0) {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, true, true>), K16S_LDS_BYTES);
+            edge_key16_kernel<false, K16S_WAVES, 0, true, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
+        } else {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, true, true>), K16S_LDS_BYTES);
+            edge_key16_kernel<false, K16S_WAVES, 1, true, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
+        }
+    } else if (stage == 0) {
         TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 0, true>), K16_LDS_BYTES);
         edge_key16_kernel<false, K16_WAVES, 0, true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     } else {

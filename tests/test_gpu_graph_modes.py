@@ -245,6 +245,29 @@ def test_model_options_live_in_the_handle(state_dict):
         assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
 
 
+def test_sampling_with_fp32_edge_first_layer(state_dict):
+    """edge_key_split = 0 (radial/type first layer on fp32 MFMA) stays a tested path: 5 reverse steps through the session and
+    the stateless forward against the default (bf16 piece triples): same types, positions within the sampling tolerance, and
+    session == stateless bit for bit under either setting."""
+    from oracle import draws
+    from oracle.make_golden_r2 import hybrid_small_batch
+    dev = _dev()
+    b, lpos, lv = hybrid_small_batch()
+    bd = b.to(dev)
+    res = {}
+    for split in (1, 0):
+        for use_session in (True, False):
+            model = _model(state_dict)
+            model._native(dev).set_option('edge_key_split', split)
+            res[(split, use_session)] = model.sample_diffusion(
+                bd.protein_pos, bd.protein_atom_feature.float(), bd.protein_element_batch, lpos.to(dev), lv.to(dev),
+                bd.ligand_element_batch, num_steps=5, center_pos_mode='protein', noise_source=draws.Source(77, dev),
+                use_session=use_session)
+        assert torch.equal(res[(split, True)]['pos'], res[(split, False)]['pos'])
+    assert torch.equal(torch.stack(res[(1, True)]['v_traj']), torch.stack(res[(0, True)]['v_traj']))
+    assert _maxdiff(torch.stack(res[(1, True)]['pos_traj']), torch.stack(res[(0, True)]['pos_traj'])) <= 5e-5
+
+
 @pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
 def test_forward_other_weight_scales_vs_oracle(seed, gain):
     """Parity must not depend on the one seeded weight set the fixtures use: other seeds and weight scales (stronger /
