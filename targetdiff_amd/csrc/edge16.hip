@@ -52,8 +52,9 @@ struct Args16 {
 __device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end, int G = gridDim.x,
                                                 int b = blockIdx.x) {
     if (count_ptr) count = *count_ptr;
-    int chunk = b;
-    if ((G & 7) == 0) chunk = (b & 7) * (G >> 3) + (b >> 3);   // XCD x gets the x-th eighth
+    // XCD x (blocks b = x mod 8) gets a contiguous run of chunks: G / 8 of them, one more for the first G mod 8 XCDs
+    const int x = b & 7, r = G & 7;
+    const int chunk = x * (G >> 3) + (x < r ? x : r) + (b >> 3);
     const int64_t per = (count + G - 1) / G;
     begin = (int64_t)chunk * per;
     end = begin + per < count ? begin + per : count;
@@ -618,12 +619,14 @@ constexpr size_t V16S_LDS_BYTES =
     (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
-// (36 KiB), so a workgroup makes two passes: the protein rows of its contiguous share of the row list with the
-// protein-destination half, then -- after re-staging the other half -- its stride of the ligand rows (a.lig_rows: every
-// ligand atom; the row lists of a sampling session always contain them all).  Ligand rows are a few per cent of a launch
-// and cost about twice a protein row, so they are dealt round-robin over all waves of the launch rather than left to the
-// workgroups whose share happens to hold them.  A wave looks at 64 candidate rows at a time (lane t reads the class of
-// candidate t) and walks the ones of the pass's class.
+// (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
+// rows (a.lig_rows: every ligand atom; the row lists of a forward pass / sampling step always contain them all), 8
+// neighbouring ligand rows at a time per workgroup; the others stage the protein half and walk the protein rows of their
+// contiguous share of the row list.  GL is chosen inside the kernel from the list's length (device-side in a session) and
+// the ligand count so that both kinds finish together: a ligand row costs about 1.25 protein rows (both source classes in
+// its first layer).
+// A wave looks at 64 candidate rows at a time (lane t reads the class of candidate t) and walks the ones of its class.
+constexpr int TD_LIG_ROW_COST_X4 = 5;      // 1.25, in quarters (measured: 8.7 us against 7.0 us per row and wave at C2)
 template <bool SPLIT>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS;
@@ -637,8 +640,23 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
     float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
     const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
+    // SPLIT: workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0)
+    int my_cls = 1, GL = 0;
+    int64_t n_rows = 0;
+    if (SPLIT) {
+        n_rows = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
+        const int64_t G = gridDim.x, nl = a.lig_count, np = n_rows > nl ? n_rows - nl : 0;
+        if (nl > 0) {
+            const int64_t wl = TD_LIG_ROW_COST_X4 * nl, wp = 4 * np;
+            GL = (int)((wl * G + (wl + wp) / 2) / (wl + wp));
+            const int cap = (int)G - (np > 0 ? 1 : 0);
+            GL = GL < 1 ? 1 : (GL > cap ? cap : GL);
+        }
+        my_cls = (int)blockIdx.x >= (int)G - GL ? 0 : 1;
+    }
+    const int GP = gridDim.x - GL;
     {
-        td_stage_lds16(SPLIT ? reinterpret_cast<const float4 *>(a.mlp.R16p) + E16P_HALF_U4 : reinterpret_cast<const float4 *>(a.mlp.R16),
+        td_stage_lds16(SPLIT ? reinterpret_cast<const float4 *>(a.mlp.R16p) + my_cls * E16P_HALF_U4 : reinterpret_cast<const float4 *>(a.mlp.R16),
                        reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid,
                        V16_WAVES * 64);
@@ -657,26 +675,18 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     // Software pipeline over the wave's rows: the neighbour indices of row n + 1 are fetched at the top of row n, and its
     // gathers (32 neighbour projections straight into the accumulator registers, which are free once Zbar is done) are
     // issued before row n's output GEMV, so that they land while it runs.
-#pragma unroll 1
-  for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
-    // the pass's candidates: entries scan + stride t (t = 0, 1, ..) of `list` (nullptr: the identity), below `end`
-    const int pass_cls = 1 - pass;               // SPLIT: destination class served (1 = protein, 0 = ligand)
+    // The wave's candidates: entries scan + 8 t (t = 0, 1, ..) of `list` (nullptr: the identity), below `end`.
     const int32_t *list = a.rows;
     int64_t scan, end;
-    int stride = V16_WAVES;
-    if (pass == 0) {
-        td_node_range16(a.count, a.count_ptr, scan, end);
-        scan += wid;
-    } else {
-        if (a.lig_count == 0) break;
-        __syncthreads();                          // every wave is done with the protein half
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16p), reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
-        __syncthreads();
+    if (!SPLIT) td_node_range16(a.count, a.count_ptr, scan, end);
+    else if (my_cls) td_node_range16(n_rows, nullptr, scan, end, GP, (int)blockIdx.x);
+    else {
         list = a.lig_rows;
-        end = a.lig_count;
-        scan = (int64_t)blockIdx.x * V16_WAVES + wid;
-        stride = gridDim.x * V16_WAVES;
+        const int64_t per = (a.lig_count + GL - 1) / GL;
+        scan = ((int)blockIdx.x - GP) * per;
+        end = scan + per < a.lig_count ? scan + per : a.lig_count;
     }
+    scan += wid;
     auto row_id = [&](int64_t itx) -> int64_t { return list ? (int64_t)list[itx] : itx; };
     int cand = 0;                      // SPLIT: lane t = row id of candidate t of the current window
     unsigned long long todo = 0ull;    // SPLIT: candidates of the window still to do
@@ -694,13 +704,13 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 return (int64_t)__builtin_amdgcn_readlane(cand, t);
             }
             if (scan >= end) return -1;
-            const int64_t idx = scan + (int64_t)stride * lane;
-            scan += (int64_t)stride * 64;
+            const int64_t idx = scan + (int64_t)V16_WAVES * lane;
+            scan += V16_WAVES * 64;
             bool mine = false;
             cand = 0;
             if (idx < end) {
                 cand = (int)row_id(idx);
-                mine = (a.x4[cand].w > 0.5f ? 0 : 1) == pass_cls;
+                mine = (a.x4[cand].w > 0.5f ? 0 : 1) == my_cls;
             }
             todo = __ballot(mine);
         }
@@ -794,7 +804,6 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
     }
-  }
 }
 
 // ================================================================================================ general graphs
@@ -1077,7 +1086,9 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     if (mlp.use_split) {
         TD_LDS_ONCE((edge_value16_kernel<true>), V16S_LDS_BYTES);
         a.lig_rows = lig_rows; a.lig_count = lig_count;
-        edge_value16_kernel<true><<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16S_LDS_BYTES, s>>>(a);
+        int G = grid16(count, V16_WAVES);
+        if (G < 2 && lig_count > 0) G = 2;         // a workgroup for each destination class
+        edge_value16_kernel<true><<<dim3(G), dim3(V16_WAVES * 64), V16S_LDS_BYTES, s>>>(a);
     } else
         edge_value16_kernel<false><<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());

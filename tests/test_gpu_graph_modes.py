@@ -207,8 +207,8 @@ def test_sampling_steps_on_general_graph_vs_oracle(state_dict, cfg):
 
 
 def test_model_options_live_in_the_handle(state_dict):
-    """node_proj_split / h2x_fused are per-model switches (no environment variables): both settings of each reproduce the
-    reference golden, fp32 MFMA and exact bf16 x 3 splitting to the same tolerance."""
+    """node_proj_split / h2x_fused / edge_key_split are per-model switches (no environment variables): both settings of each
+    reproduce the reference golden, fp32 MFMA and exact bf16 x 3 splitting to the same tolerance."""
     from conftest import small_inputs
     dev = _dev()
     g = load_golden('forward_small.npz')
@@ -230,16 +230,17 @@ def test_model_options_live_in_the_handle(state_dict):
     assert torch.equal(res[(1, 1)]['final_h'], res[(1, 0)]['final_h'])          # fusing the h2x halves changes no arithmetic
     with pytest.raises(RuntimeError, match='unknown option'):
         nat.set_option('no_such_switch', 1)
-    # key passes with the radial/type first layer on bf16 piece triples
+    # the runs above had the x2h passes' radial/type first layer on bf16 piece triples (edge_key_split, default 1): fp32 MFMA
     for fused in (1, 0):
         model = _model(state_dict)
         nat = model._native(dev)
-        nat.set_option('edge_key_split', 1)
-        nat.set_option('h2x_fused', fused)
         assert nat.get_option('edge_key_split') == 1
+        nat.set_option('edge_key_split', 0)
+        nat.set_option('h2x_fused', fused)
+        assert nat.get_option('edge_key_split') == 0
         p = model(inp['protein_pos'], inp['protein_v'], inp['batch_protein'], inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'])
-        print(f'edge_key_split fused={fused}: |dx| = {_maxdiff(p["pred_ligand_pos"], g["pred_ligand_pos"]):.2e}  '
-              f'|dh| = {_maxdiff(p["final_h"], g["final_h"]):.2e}  vs fp32 first layer '
+        print(f'edge_key_split=0 fused={fused}: |dx| = {_maxdiff(p["pred_ligand_pos"], g["pred_ligand_pos"]):.2e}  '
+              f'|dh| = {_maxdiff(p["final_h"], g["final_h"]):.2e}  vs bf16 x 3 first layer '
               f'{float((p["final_h"] - res[(1, fused)]["final_h"]).abs().max()):.2e}')
         assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
         assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
