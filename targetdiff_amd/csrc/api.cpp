@@ -240,7 +240,7 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
     // the same table as exact bf16 piece triples, A-operand order of v_mfma_f32_16x16x32_bf16 (lane = (hidden lo, k group g),
     // slots j = 0..7 -> k = 8g + j; k < 20 Gaussians, k = 20 the edge-type column, k >= 21 zero: P_i is added separately)
     o.R16p = 0;
-    if (out_dim == TD_H) {
+    {
         o.R16p = pk.alloc((size_t)2 * 2 * 3 * 8 * 48 * 4);
         uint32_t *dp = reinterpret_cast<uint32_t *>(pk.data.data() + o.R16p);
         for (int cls = 0; cls < 2; ++cls)
@@ -480,7 +480,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
         Ly.nodeX2h = node(lo[l].nx); Ly.nodeH2x = node(lo[l].nh);
-        Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true); Ly.xk = edge(lo[l].xk); Ly.xv = edge(lo[l].xv);
+        Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true); Ly.xk = edge(lo[l].xk, true); Ly.xv = edge(lo[l].xv, true);
         Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
@@ -508,6 +508,8 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         for (int l = 0; l < m->cfg.num_layers; ++l) {
             m->layers[l].hk.use_split = m->layers[l].hk.R16p && value != 0;
             m->layers[l].hv.use_split = m->layers[l].hv.R16p && value != 0;
+            m->layers[l].xk.use_split = m->layers[l].xk.R16p && value != 0;
+            m->layers[l].xv.use_split = m->layers[l].xv.R16p && value != 0;
         }
     } else if (strcmp(name, "session_hop_levels") == 0) {
         if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }

@@ -482,17 +482,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 
 // ================================================================================================ fused h2x stage
 // Key pass + value pass of the h2x stage for the listed ligand rows in one launch: the attention weights never leave
-// registers (alpha[eb][r] and xv[eb][r] share the (edge 16eb + lo, head 4g + r) layout).  The two edge MLPs' tables do
-// not fit in LDS together, so a workgroup alternates: xk tables -> logits / softmax for one row per wave -> barrier ->
-// xv tables -> coordinate update, with up to two rows per wave per table residency (one round per workgroup for the
-// ligand rows of a sampling batch).  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
+// registers (alpha[eb][r] and xv[eb][r] share the (edge 16eb + lo, head 4g + r) layout).  Every destination is a ligand
+// atom, so only the ligand-destination half of each MLP's radial/type table is needed and both MLPs' tables are resident
+// together (SPLIT: 36 + 64 + 36 + 8 KiB of bf16 piece tables, W2k copy, xv weights; fp32: 24 + 64 + 24 + 8): one staging
+// per workgroup, no barrier in the row loop, and the value half's neighbour projections are gathered while the key half's
+// logits and softmax run.  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
 constexpr int H2X16_WAVES = 8;
+constexpr int H2X16_WX_FLOATS = 8 * 4 * 64;                                  // W2xv16[hb][r][lane]
+template <bool SPLIT> constexpr int h2x16_table_floats() { return SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS / 2; }
+template <bool SPLIT> constexpr size_t h2x16_lds_bytes() {
+    return (size_t)(2 * h2x16_table_floats<SPLIT>() + E16_WQ_FLOATS + H2X16_WX_FLOATS + 4 * TD_H) * sizeof(float);
+}
 
 struct ArgsH2x {
     Args16 a;              // a.mlp = xk MLP (keys), a.p_off = 0
     TdEdgeMlp mlp_v;       // xv MLP
 };
 
+// the fp32 tables of one edge MLP in the layout of edge_key16_kernel: radial/type table, second-layer weights, LayerNorm affine
 template <int WAVES>
 __device__ __forceinline__ void td_stage_tables16(float *lds, const TdEdgeMlp &mlp, int nw4, int tid) {
     td_stage_lds16(reinterpret_cast<const float4 *>(mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, WAVES * 64);
@@ -501,109 +508,119 @@ __device__ __forceinline__ void td_stage_tables16(float *lds, const TdEdgeMlp &m
     else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.beta[tid - TD_H];
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar) {
     constexpr int WAVES = H2X16_WAVES;
+    constexpr int RH = h2x16_table_floats<SPLIT>();
+    constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Args16 &a = ar.a;
-    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wq = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
-    const float *Wx = lds + E16_R_FLOATS;
-    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    float *Rk = lds, *WqF = Rk + RH, *Rv = WqF + E16_WQ_FLOATS, *WxF = Rv + RH, *GB = WxF + H2X16_WX_FLOATS;
+    const float4 *Wq = reinterpret_cast<const float4 *>(WqF);
+    const float *Wx = WxF;
+    const float *GAMk = GB, *BETk = GB + TD_H, *GAMv = GB + 2 * TD_H, *BETv = GB + 3 * TD_H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
-    float offk[E16_STEPS];
+    {
+        // destination class 0 (ligand) is the first half of either table
+        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? ar.mlp_v.R16p : ar.mlp_v.R16), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
+        if (tid < TD_H) GB[tid] = a.mlp.gamma[tid];
+        else if (tid < 2 * TD_H) GB[tid] = a.mlp.beta[tid - TD_H];
+        else if (tid < 3 * TD_H) GB[tid] = ar.mlp_v.gamma[tid - 2 * TD_H];
+        else if (tid < 4 * TD_H) GB[tid] = ar.mlp_v.beta[tid - 3 * TD_H];
+    }
+    float offk[NOFF];
 #pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
+    for (int s = 0; s < NOFF; ++s) {
+        const int k = SPLIT ? 8 * g + s : 4 * s + g;
+        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+    }
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
     Args16 av = a;
     av.p_off = 2 * TD_H;
     const float b2 = ar.mlp_v.b2[lo];
+    __syncthreads();
 
-    constexpr int RPW = 2;      // rows per wave and table residency: the ligand rows of a batch are ~1.1x the resident waves
-    for (int64_t base = begin; base < end; base += WAVES * RPW) {      // uniform trip count: every wave reaches the barriers
-        if (base != begin) __syncthreads();
-        td_stage_tables16<WAVES>(lds, a.mlp, E16_WQ_FLOATS / 4, tid);
-        __syncthreads();
-        floatx4_t al[RPW][2];
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        // ---- key half: first layer -> z, logits = z . U_i, softmax x gate -> al ---------------------------------------
+        RowIn16 rin;
+        floatx4_t acc[2][8];
+        Edge2 ed;
+        td_row_index16(a, i, i, lane, rin);
+        td_row_gather16<true>(a, i, i, lane, rin, acc);
+        if constexpr (SPLIT) td_first_layer_split16<true, true, false>(a, reinterpret_cast<const uint4 *>(Rk), GAMk, BETk, offk, rin, i, lane, acc, ed);
+        else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), GAMk, BETk, offk, rin, lane, acc, ed);
+        // the value half's gathers (its own accumulators) fly while the logits and the softmax run
+        RowIn16 rv = rin;
+        floatx4_t accv[2][8];
+        td_row_gather16<false>(av, i, i, lane, rv, accv);
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+        floatx4_t lg[2];
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int64_t it = base + rr * WAVES + wid;
-            if (it >= end) continue;
-            const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-            floatx4_t acc[2][8];
-            Edge2 ed;
-            td_first_layer16<true>(a, Rt, GAM, BET, offk, i, lane, acc, ed);
-            const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
-            const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
-            floatx4_t lg[2];
+        for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
-                    const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
-                    float u = w0.x * q0.x;
-                    u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
-                    u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
-                    lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                    lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
-                }
+        for (int hb = 0; hb < 8; ++hb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
-                float mx = td_max16(fmaxf(x0, x1));
-                if (mx == -INFINITY) mx = 0.f;
-                const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
-                const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
-                const float sm = td_sum16(p0 + p1);
-                const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
-                al[rr][0][r] = p0 * inv * ed.ew[0];
-                al[rr][1][r] = p1 * inv * ed.ew[1];
+                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
+                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
+                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
             }
+        floatx4_t al[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+            const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+            float mx = td_max16(fmaxf(x0, x1));
+            if (mx == -INFINITY) mx = 0.f;
+            const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
+            const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
+            const float sm = td_sum16(p0 + p1);
+            const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
+            al[0][r] = p0 * inv * ed.ew[0];
+            al[1][r] = p1 * inv * ed.ew[1];
         }
-        __syncthreads();
-        td_stage_tables16<WAVES>(lds, ar.mlp_v, 8 * 4 * 64 / 4, tid);
-        __syncthreads();
+        // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
+        Edge2 ev;
+        if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), GAMv, BETv, offk, rv, i, lane, accv, ev);
+        else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), GAMv, BETv, offk, rv, lane, accv, ev);
+        floatx4_t xv[2];
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int64_t it = base + rr * WAVES + wid;
-            if (it >= end) continue;
-            const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
-            floatx4_t acc[2][8];
-            Edge2 ev;
-            td_first_layer16<false>(av, Rt, GAM, BET, offk, i, lane, acc, ev);
-            floatx4_t xv[2];
+        for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = Wx[(hb * 4 + r) * 64 + lane];
-                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
-                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
-                }
-            float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int hb = 0; hb < 8; ++hb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float bias = __shfl(b2, 4 * g + r);
-#pragma unroll
-                for (int eb = 0; eb < 2; ++eb) {
-                    const float wgt = ev.valid[eb] ? al[rr][eb][r] * (xv[eb][r] + bias) : 0.f;
-                    sx = fmaf(wgt, ev.rel[eb][0], sx);
-                    sy = fmaf(wgt, ev.rel[eb][1], sy);
-                    sz = fmaf(wgt, ev.rel[eb][2], sz);
-                }
+                const float u = Wx[(hb * 4 + r) * 64 + lane];
+                xv[0] = td_mfma16(u, accv[0][hb][r], xv[0]);
+                xv[1] = td_mfma16(u, accv[1][hb][r], xv[1]);
             }
-            sx = td_sum64(sx) * (1.0f / TD_HEADS);
-            sy = td_sum64(sy) * (1.0f / TD_HEADS);
-            sz = td_sum64(sz) * (1.0f / TD_HEADS);
-            if (lane == 0) a.x4_out[i] = make_float4(ev.xi.x + sx, ev.xi.y + sy, ev.xi.z + sz, ev.xi.w);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bias = __shfl(b2, 4 * g + r);
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                const float wgt = ev.valid[eb] ? al[eb][r] * (xv[eb][r] + bias) : 0.f;
+                sx = fmaf(wgt, ev.rel[eb][0], sx);
+                sy = fmaf(wgt, ev.rel[eb][1], sy);
+                sz = fmaf(wgt, ev.rel[eb][2], sz);
+            }
         }
+        sx = td_sum64(sx) * (1.0f / TD_HEADS);
+        sy = td_sum64(sy) * (1.0f / TD_HEADS);
+        sz = td_sum64(sz) * (1.0f / TD_HEADS);
+        if (lane == 0) a.x4_out[i] = make_float4(ev.xi.x + sx, ev.xi.y + sy, ev.xi.z + sz, ev.xi.w);
     }
 }
 
@@ -1062,13 +1079,18 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
                         const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s) {
     if (count == 0) return TD_OK;
-    int rc_lds;
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
     Args16 a = {};
     a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
-    edge_key16_kernel<true, XV16_WAVES, 1><<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    const dim3 grid(grid16(count, XV16_WAVES)), block(XV16_WAVES * 64);
+    if (mlp.use_split) {
+        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, false, true>), K16S_LDS_BYTES);
+        edge_key16_kernel<true, XV16_WAVES, 1, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
+    } else {
+        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES);
+        edge_key16_kernel<true, XV16_WAVES, 1><<<grid, block, K16_LDS_BYTES, s>>>(a);
+    }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -1100,14 +1122,19 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
                          int64_t count, hipStream_t s) {
     if (count == 0) return TD_OK;
-    int rc_lds;
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_h2x16_kernel), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
     ArgsH2x ar = {};
     Args16 &a = ar.a;
     a.x4 = x4_in; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = nullptr; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     ar.mlp_v = mlp_v;
-    edge_h2x16_kernel<<<dim3(grid16(count, H2X16_WAVES)), dim3(H2X16_WAVES * 64), K16_LDS_BYTES, s>>>(ar);
+    const dim3 grid(grid16(count, H2X16_WAVES)), block(H2X16_WAVES * 64);
+    if (mlp_k.use_split && mlp_v.use_split) {
+        TD_LDS_ONCE((edge_h2x16_kernel<true>), h2x16_lds_bytes<true>());
+        edge_h2x16_kernel<true><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
+    } else {
+        TD_LDS_ONCE((edge_h2x16_kernel<false>), h2x16_lds_bytes<false>());
+        edge_h2x16_kernel<false><<<grid, block, h2x16_lds_bytes<false>(), s>>>(ar);
+    }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
