@@ -59,9 +59,9 @@ struct TdEdgeMlp {
     const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
     const float *Walt16;   // key MLPs: Wq16[hb][r][jq][lane][4] = W2[8 lo + 4jq + jj][16hb + 4g + r]
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
-    const float *R16p;     // key MLPs: the radial/type table as bf16 piece triples for v_mfma_f32_16x16x32_bf16:
+    const float *R16p;     // the radial/type table as bf16 piece triples for v_mfma_f32_16x16x32_bf16:
                            // [2 dst class][2 slot][3 piece][8 hidden block][48 lanes (k group g < 3)] x 8 bf16 (k = 8g + j)
-    bool use_split;        // key pass: first layer on the piece triples (model option "edge_key_split")
+    bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
 };
 
 // Node-side weights of one stage (x2h or h2x): 4 projections (k_i,k_j,v_i,v_j) + the query MLP.
@@ -125,7 +125,7 @@ struct TdSchedules {       // [T] each
 struct TdOptions {
     int h2x_fused = 1;             // one launch for the h2x stage's key + value halves (0: two launches, alpha through memory)
     int node_proj_split = 1;       // node-side GEMMs on exact bf16 x 3 operand pieces with fp32 accumulation (0: fp32 MFMA)
-    int edge_key_split = 1;        // key passes (32-slot tables): radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
+    int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
 };
