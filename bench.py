@@ -24,10 +24,10 @@ Extra objects on the JSON line:
                reported under roofline.key_pass);
                achieved = executed algorithmic FLOPs per launch (327,680 per dst node) / mean
                launch time from HIP events recorded on the launch stream inside the timed region;
-               peak = the matrix-pipe bound of the kernel as built, in the same algorithmic FLOPs: with the radial/type
-               first layer on bf16 piece triples (default) that layer's 6 x 32-deep bf16 products are priced at the
-               2.5 PFLOP/s dense bf16 peak and everything else at the 157.3 TFLOP/s fp32 MFMA peak (= 196 TFLOP/s for a
-               32-edge row); with --option edge_key_split=0 it is the fp32 peak.  frac_of_fp32_peak is reported beside it.
+               peak = 157.3 TFLOP/s, the dense fp32 MFMA peak (= fp32 vector peak) -- the dtype the path computes in.
+               matrix_bound_as_built is reported beside it: with the radial/type first layer on bf16 piece triples
+               (default) that layer's 6 x 32-deep bf16 products are priced at the 2.5 PFLOP/s dense bf16 peak and
+               everything else at the fp32 peak (= 196 TFLOP/s of the same algorithmic FLOPs for a 32-edge row).
   cpu_baseline the oracle restatement (torch CPU, same weights) timed on this host's cores over a bounded
                sample of the same workload (the same pocket, fewer samples, a few steps).
 """
@@ -449,9 +449,9 @@ def main():
         split_here = split and (default_graph or cls == 'x2h_k')
         if split_here:
             t_min = cpn * FIRST_LAYER_FLOP_BF16_EXECUTED / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
-            peak = per_row / t_min
+            bound = per_row / t_min
         else:
-            peak = PEAK_FP32_MFMA_TFLOPS
+            bound = PEAK_FP32_MFMA_TFLOPS
         # HBM traffic of the same kernel: PMC counters cannot be read in-process, so this is the figure of the COMMITTED
         # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- static, see traffic_source
@@ -463,8 +463,8 @@ def main():
             traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
             source = f'profiles/{traffic_file} (static: PMC pass of an earlier run of this command, not measured in this run)'
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
-                'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS, 'frac_of_fp32_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
                 'first_layer': 'bf16 x 3 piece triples (v_mfma_f32_16x16x32_bf16)' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline

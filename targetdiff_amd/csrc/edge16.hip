@@ -1,6 +1,8 @@
-// Key / value passes on v_mfma_f32_16x16x4_f32 tiles (gfx950).  Same re-associated arithmetic as edge_fast.hip
-// (logits = z . U_i, out = W2v . (alpha^T z)); the 16-row tile matches the 16 attention heads exactly, so the two
-// head-shaped products cost 64 x 32 cycles instead of 64 x 64 and the U_i build uses all 64 lanes.
+// Attention passes (x2h key / value, h2x) on 16 x 16 MFMA tiles (gfx950), re-associated arithmetic: logits = z . U_i,
+// out = W2v . (alpha^T z).  The 16-row tile matches the 16 attention heads exactly, so the two head-shaped products cost
+// 64 x 32 cycles and the U_i build uses all 64 lanes.  The per-edge 128-deep products run on v_mfma_f32_16x16x4_f32; the
+// 21-wide radial/type first layer runs on v_mfma_f32_16x16x32_bf16 with both operands as exact bf16 piece triples
+// (td_first_layer_split16; model option edge_key_split, default) or on the fp32 instruction (td_first_layer_compute16).
 //
 // Lane coordinates: lo = lane & 15, g = lane >> 4.   16x16x4 fragment maps (cdna_hip_programming.md section 3):
 //   A: lane holds A[row = lo][k = g]      B: lane holds B[k = g][col = lo]      C/D: reg r holds D[row = 4g + r][col = lo]
@@ -1052,25 +1054,29 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
                          float *alpha, hipStream_t s) {
     if (count == 0) return TD_OK;
-    int rc_lds;
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 0>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<false, K16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES)) != TD_OK) return rc_lds; }
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
-    if (mlp.use_split) {         // first layer on bf16 piece triples
-        if (rows && !count_ptr) {
+    const bool h2x = rows && !count_ptr;      // h2x key pass (ligand row list of known length): STAGE tag 1
+    if (mlp.use_split) {                      // first layer on bf16 piece triples
+        const dim3 grid(grid16(count, K16S_WAVES)), block(K16S_WAVES * 64);
+        if (h2x) {
             TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, false, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 1, false, true><<<dim3(grid16(count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
+            edge_key16_kernel<false, K16S_WAVES, 1, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
         } else {
             TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, false, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 0, false, true><<<dim3(grid16(count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
+            edge_key16_kernel<false, K16S_WAVES, 0, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
         }
-    } else if (rows && !count_ptr)      // h2x key pass (ligand row list of known length)
-        edge_key16_kernel<false, K16_WAVES, 1><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
-    else
-        edge_key16_kernel<false, K16_WAVES, 0><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
+    } else {
+        const dim3 grid(grid16(count, K16_WAVES)), block(K16_WAVES * 64);
+        if (h2x) {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 1>), K16_LDS_BYTES);
+            edge_key16_kernel<false, K16_WAVES, 1><<<grid, block, K16_LDS_BYTES, s>>>(a);
+        } else {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 0>), K16_LDS_BYTES);
+            edge_key16_kernel<false, K16_WAVES, 0><<<grid, block, K16_LDS_BYTES, s>>>(a);
+        }
+    }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -1095,24 +1101,26 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
     return TD_OK;
 }
 
+// lig_rows / lig_count: the ligand rows among `rows` (all of them: every row list of a forward pass or sampling step holds
+// the ligand atoms); nullptr / 0 for a list without ligand rows.
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            const int32_t *lig_rows, int64_t lig_count, hipStream_t s) {
     if (count == 0) return TD_OK;
-    int rc_lds;
-    { static TdLdsOnce once; if ((rc_lds = td_set_lds(once, reinterpret_cast<const void *>(edge_value16_kernel<false>), V16_LDS_BYTES)) != TD_OK) return rc_lds; }
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H;
+    int G = grid16(count, V16_WAVES);
     if (mlp.use_split) {
         TD_LDS_ONCE((edge_value16_kernel<true>), V16S_LDS_BYTES);
-        a.lig_rows = lig_rows; a.lig_count = lig_count;
-        int G = grid16(count, V16_WAVES);
-        if (G < 2 && lig_count > 0) G = 2;         // a workgroup for each destination class
+        a.lig_rows = lig_rows; a.lig_count = lig_rows ? lig_count : 0;
+        if (G < 2 && a.lig_count > 0) G = 2;       // a workgroup for each destination class
         edge_value16_kernel<true><<<dim3(G), dim3(V16_WAVES * 64), V16S_LDS_BYTES, s>>>(a);
-    } else
-        edge_value16_kernel<false><<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    } else {
+        TD_LDS_ONCE((edge_value16_kernel<false>), V16_LDS_BYTES);
+        edge_value16_kernel<false><<<dim3(G), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+    }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
