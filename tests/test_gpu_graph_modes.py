@@ -290,3 +290,39 @@ def test_forward_other_weight_scales_vs_oracle(seed, gain):
     assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= TOL_X * scale
     assert _maxdiff(got['final_h'], want['final_h']) <= TOL_H * scale
     assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= TOL_H * scale
+
+
+@pytest.mark.parametrize('sizes', [[(1, 1)], [(3, 2)], [(1, 1), (40, 1), (2, 9)], [(33, 1), (1, 30)], [(200, 24)] * 3])
+def test_forward_and_sampling_on_tiny_and_lopsided_batches(state_dict, sizes):
+    """Launch shapes at the small end: graphs of one protein and one ligand atom, rows with a single in-edge, batches where the
+    ligand rows outnumber the protein rows, a handful of rows per launch (fewer rows than waves; the value pass must still
+    give each destination class a workgroup).  Forward against the oracle; 3 sampling steps session == stateless bit for bit."""
+    from oracle import draws
+    from oracle import restatement as R
+    dev = _dev()
+    gen = torch.Generator().manual_seed(1234 + len(sizes) * 17 + sizes[0][0])
+    ppos, lpos, pb, lb = [], [], [], []
+    for gi, (n_p, n_l) in enumerate(sizes):
+        ppos.append(torch.randn(n_p, 3, generator=gen) * 4.0)
+        lpos.append(torch.randn(n_l, 3, generator=gen) * 1.5)
+        pb += [gi] * n_p
+        lb += [gi] * n_l
+    ppos, lpos = torch.cat(ppos), torch.cat(lpos)
+    pb, lb = torch.tensor(pb), torch.tensor(lb)
+    pv = torch.zeros(len(pb), 27)
+    pv[torch.arange(len(pb)), torch.randint(0, 6, (len(pb),), generator=gen)] = 1.0
+    pv[torch.arange(len(pb)), 6 + torch.randint(0, 20, (len(pb),), generator=gen)] = 1.0
+    lv = torch.randint(0, 13, (len(lb),), generator=gen)
+    model = _model(state_dict)
+    ppos_c, lpos_c, _ = R.center_positions(ppos, lpos, pb, lb)
+    want = R.model_forward(state_dict, None, ppos_c, pv, pb, lpos_c, lv, lb)
+    got = model(ppos_c.to(dev), pv.to(dev), pb.to(dev), lpos_c.to(dev), lv.to(dev), lb.to(dev))
+    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= TOL_X
+    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= TOL_H
+    assert _maxdiff(got['final_h'], want['final_h']) <= TOL_H
+    outs = []
+    for use_session in (True, False):
+        outs.append(model.sample_diffusion(ppos.to(dev), pv.to(dev), pb.to(dev), lpos.to(dev), lv.to(dev), lb.to(dev), num_steps=3,
+                                           center_pos_mode='protein', noise_source=draws.Source(31, dev), use_session=use_session))
+    assert torch.equal(outs[0]['pos'], outs[1]['pos']) and torch.equal(outs[0]['v'], outs[1]['v'])
+    assert bool(torch.isfinite(outs[0]['pos']).all())
