@@ -225,7 +225,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
 // Both operands as exact bf16 piece triples (the table pre-split at pack time, the per-edge Gaussians split in registers),
 // 6 of the 9 piece products, fp32 accumulation: fp32-equivalent (the dropped products are below 2^-24 relative).  One
 // instruction covers the whole K = 21 (20 Gaussians + the edge-type column; k = 8 g + j for lane group g, slot j) at half the
-// issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds after the products.
+// issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds (before or after the products).
 typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
 constexpr int E16P_U4 = 2 * 2 * 3 * 8 * 48;                 // uint4 entries of the piece table [cls][slot][piece][hb][48] (72 KiB)
 constexpr int E16P_HALF_U4 = E16P_U4 / 2;                   // one destination class
