@@ -95,7 +95,9 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *                            with the same exact three-piece split of both operands; 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
  *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
  *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with
- *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only */
+ *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only
+ *   "session_step_lists"     1 (default): the row lists of a session step come from one launch (a workgroup per graph);
+ *                            0 = the separate list kernels (also used when a graph exceeds 12288 nodes) */
 int td_model_set_option(td_model *m, const char *name, int32_t value);
 int td_model_get_option(const td_model *m, const char *name, int32_t *value);
 

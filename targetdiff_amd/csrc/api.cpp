@@ -515,6 +515,7 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }
         m->opt.session_hop_levels = value;
     } else if (strcmp(name, "session_forward_reach") == 0) m->opt.session_forward_reach = value != 0;
+    else if (strcmp(name, "session_step_lists") == 0) m->opt.session_step_lists = value != 0;
     else { td_set_error("td_model_set_option: unknown option '%s'", name); return TD_EINVAL; }
     return TD_OK;
 }
@@ -526,6 +527,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
+    else if (strcmp(name, "session_step_lists") == 0) *value = m->opt.session_step_lists;
     else { td_set_error("td_model_get_option: unknown option '%s'", name); return TD_EINVAL; }
     return TD_OK;
 }
@@ -1289,6 +1291,7 @@ struct td_session {
     int32_t *fwd_rows, *fwd_rest, *fwd_counts;
     bool use_fwd;
     uint8_t *clean;
+    int graph_nodes_max;         // exact size of the largest graph (0: unknown) -- sizes the LDS flags of td_launch_step_lists
     bool general;                // non-default graph (k != 32, hybrid, radius): no static-protein caching, only the layout is kept
     GraphPlan plan;
 };
@@ -1397,6 +1400,13 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
 #define TD_TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { td_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return fail(TD_EHIP); } } while (0)
     TD_TRY_HIP(hipMemcpyAsync(S->pptr, d_protein_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
     TD_TRY_HIP(hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
+    {   // exact size of the largest graph (max_graph_nodes is only a hint): one small D2H at session creation
+        std::vector<int32_t> hp, hl;
+        TD_TRY(fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s));
+        int gmax = 0;
+        for (int64_t g = 0; g < B; ++g) gmax = std::max(gmax, (hp[g + 1] - hp[g]) + (hl[g + 1] - hl[g]));
+        S->graph_nodes_max = gmax;
+    }
     TD_TRY_HIP(hipMemsetAsync(tmp_lpos, 0, (size_t)N_l * 12, s));
     TD_TRY_HIP(hipMemsetAsync(tmp_lv, 0, (size_t)N_l * 8, s));
     // embeddings + packed order (ligand rows are placeholders until the first step), protein row list
@@ -1468,19 +1478,30 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         rs.flags2 = S->use_fwd ? S->flags2 : nullptr;
         if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, &rs)) != TD_OK) return rc;
     }
+    bool lists_done = false;
     {
         ProfScope ps(PC_KNN, s);
         if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
                                       S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
         if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc;
-        if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
-        // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
-        // clears it; without the forward reach a memset does
-        if (S->use_fwd) {
-            if ((rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest, S->fwd_counts,
-                                              S->clean, s)) != TD_OK) return rc;
-        } else {
-            TD_CHECK_HIP(hipMemsetAsync(S->clean, 0, (size_t)N, s));
+        // every row list of the step (dirty rows, forward reach, receptive-field levels) in one launch, one workgroup per graph;
+        // graphs too large for its LDS flags take the separate kernels
+        const TdStepLists lists{S->dirty_rows, S->dirty_count, S->use_fwd ? S->fwd_rows : nullptr, S->fwd_rest, S->fwd_counts,
+                                S->hop_rows, S->hop_count, S->hop_levels};
+        rc = (m->opt.session_step_lists && S->graph_nodes_max > 0) ? td_launch_step_lists(S->clean, w.x4a, w.nbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s)
+                                    : TD_EINVAL;
+        lists_done = rc == TD_OK;
+        if (rc != TD_OK && rc != TD_EINVAL) return rc;
+        if (!lists_done) {
+            if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
+            // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
+            // clears it; without the forward reach a memset does
+            if (S->use_fwd) {
+                if ((rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest, S->fwd_counts,
+                                                  S->clean, s)) != TD_OK) return rc;
+            } else {
+                TD_CHECK_HIP(hipMemsetAsync(S->clean, 0, (size_t)N, s));
+            }
         }
     }
     {
@@ -1494,7 +1515,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
-    if ((rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;
+    if (!lists_done && (rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;
     float4 *xf = nullptr;
     const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s};
     if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels,

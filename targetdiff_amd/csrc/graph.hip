@@ -481,6 +481,137 @@ int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr
     return TD_OK;
 }
 
+// ---- every row list of a sampling step in one launch ---------------------------------------------------------------------
+// dirty rows (compact_dirty_kernel), the ligand's one-hop forward reach and its complement (forward_reach_kernel +
+// compact_split_kernel), the receptive-field levels (expand_hop / expand_level / compact_levels): all of them follow from the
+// step's neighbour table and the clean flags, and edges never leave a graph -- so one workgroup per graph keeps the three
+// per-node flag bytes in LDS, walks its rows level by level with __syncthreads() in between (16 waves, four neighbour loads in
+// flight per thread), and hands out list slots with one atomicAdd per 1024-node tile and list.  Same sets as the separate kernels (the order inside a list is irrelevant: rows
+// are independent); 8 launches of a step become one, which is what small batches feel.
+constexpr int TD_STEP_LISTS = 3 + TD_HOP_LEVELS;        // dirty, reach, rest, levels 1 .. 4
+
+template <int L, int WAVES>
+__device__ __forceinline__ void td_block_slots_each(const bool (&flag)[L], int32_t *const (&counter)[L], int (&slot)[L]) {
+    __shared__ int s_cnt[L][WAVES];
+    __shared__ int s_base[L];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long m[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        m[l] = __ballot(flag[l]);
+        if (lane == 0) s_cnt[l][wave] = __popcll(m[l]);
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        const int l = threadIdx.x;
+        int total = 0;
+        for (int w = 0; w < WAVES; ++w) total += s_cnt[l][w];
+        int32_t *c = counter[0];
+#pragma unroll
+        for (int q = 1; q < L; ++q) c = l == q ? counter[q] : c;
+        s_base[l] = (total && c) ? atomicAdd(c, total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_cnt[l][w];
+        slot[l] = s_base[l] + before + __popcll(m[l] & below);
+    }
+    __syncthreads();          // s_cnt / s_base are reused by the next tile
+}
+
+constexpr int TD_LISTS_THREADS = 1024;
+
+__global__ __launch_bounds__(TD_LISTS_THREADS) void step_lists_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4,
+                                                                      const int32_t *__restrict__ nbr, const int32_t *__restrict__ node_ptr,
+                                                                      int64_t N, int cap, TdStepLists out) {
+    constexpr int T = TD_LISTS_THREADS, RPT = T / TD_K;      // rows per trip: thread = (row a0 + tid / 32, slot tid % 32)
+    extern __shared__ uint8_t s_flags[];
+    uint8_t *dirty = s_flags, *reach = s_flags + cap, *level = s_flags + 2 * cap, *lig = s_flags + 3 * cap;
+    const int n0 = node_ptr[blockIdx.x], n = node_ptr[blockIdx.x + 1] - n0;
+    const int tid = threadIdx.x, e = tid & 31, r0 = tid >> 5;
+    for (int a = tid; a < n; a += T) {
+        const bool l = x4[n0 + a].w > 0.5f;
+        const bool d = l || !clean[n0 + a];
+        dirty[a] = d;
+        reach[a] = d;
+        lig[a] = l;
+        level[a] = l ? 1 : 0;                           // level 1 starts from the ligand atoms
+    }
+    __syncthreads();
+    const int32_t *row0 = nbr + (int64_t)n0 * TD_K + e;
+    // forward reach = rows with a dirty in-neighbour; level 1 = the ligand rows' in-neighbours
+    for (int a0 = r0; a0 < n; a0 += 4 * RPT) {
+        int j[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + u * RPT;
+            j[u] = a < n ? row0[(int64_t)a * TD_K] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + u * RPT;
+            if (j[u] < 0) continue;
+            if (dirty[j[u] - n0]) reach[a] = 1;                               // racing writers store the same value
+            if (lig[a] && level[j[u] - n0] == 0) level[j[u] - n0] = 1;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= out.levels; ++k) {
+        // rows reached at level k - 1 mark their still unreached in-neighbours with k (earlier levels did so in earlier passes)
+        for (int a0 = r0; a0 < n; a0 += 4 * RPT) {
+            int j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + u * RPT;
+                j[u] = (a < n && level[a] == k - 1) ? row0[(int64_t)a * TD_K] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j[u] >= 0 && level[j[u] - n0] == 0) level[j[u] - n0] = (uint8_t)k;
+        }
+        __syncthreads();
+    }
+    int32_t *const counters[TD_STEP_LISTS] = {out.dirty_count,
+                                              out.reach_rows ? out.reach_counts : nullptr, out.reach_rows ? out.reach_counts + 1 : nullptr,
+                                              out.level_counts, out.level_counts + 1, out.level_counts + 2, out.level_counts + 3};
+    for (int base = 0; base < n; base += T) {         // uniform trip count: every thread reaches the barriers inside
+        const int a = base + tid;
+        const bool in = a < n;
+        const int lv = in ? level[a] : 0;
+        bool flag[TD_STEP_LISTS];
+        flag[0] = in && dirty[a];
+        flag[1] = in && out.reach_rows && reach[a];
+        flag[2] = in && out.reach_rows && !reach[a];
+#pragma unroll
+        for (int k = 0; k < TD_HOP_LEVELS; ++k) flag[3 + k] = k < out.levels && lv != 0 && lv <= k + 1;
+        int slot[TD_STEP_LISTS];
+        td_block_slots_each<TD_STEP_LISTS, T / 64>(flag, counters, slot);
+        const int32_t i = n0 + a;
+        if (flag[0]) out.dirty_rows[slot[0]] = i;
+        if (flag[1]) out.reach_rows[slot[1]] = i;
+        if (flag[2]) out.rest_rows[slot[2]] = i;
+#pragma unroll
+        for (int k = 0; k < TD_HOP_LEVELS; ++k)
+            if (flag[3 + k]) out.level_rows[(size_t)k * N + slot[3 + k]] = i;
+    }
+}
+
+// `max_nodes`: an upper bound on the nodes of one graph (exact, not a hint: it sizes the LDS flag arrays).  Counters are zeroed
+// by the step's first kernel.  Returns TD_EINVAL when a graph is too large for LDS (the caller then uses the separate kernels).
+int td_launch_step_lists(const uint8_t *clean, const float4 *x4, const int32_t *nbr, const int32_t *node_ptr, int64_t N,
+                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s) {
+    if (N == 0 || B == 0) return TD_OK;
+    const int cap = (max_nodes + 15) & ~15;
+    const size_t bytes = (size_t)4 * cap;
+    if (bytes > 48 * 1024 || out.levels > TD_HOP_LEVELS) return TD_EINVAL;
+    step_lists_kernel<<<dim3((unsigned)B), dim3(TD_LISTS_THREADS), bytes, s>>>(clean, x4, nbr, node_ptr, N, cap, out);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 // per-step refresh of the ligand rows: x4 = (pos, 1), h = Linear(one_hot(v)) ; 1
 // First kernel of a session step, so it also resets the step's bookkeeping (instead of a handful of memset launches): the
 // device-side counters of the row lists and the forward-reach flags of the ligand rows (knn_merge_kernel clears the

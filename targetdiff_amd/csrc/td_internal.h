@@ -128,6 +128,8 @@ struct TdOptions {
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
+    int session_step_lists = 1;    // a step's row lists from one launch (a workgroup per graph; 0: the separate kernels, which
+                                   // graphs too large for its LDS flags use anyway)
 };
 
 struct td_model {
@@ -172,6 +174,15 @@ int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_
 constexpr int TD_HOP_LEVELS = 4;
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
                          int32_t *rows, int32_t *counts, int levels, hipStream_t s, bool zeroed = false);
+// all row lists of a sampling step in one launch (graph.hip); TD_EINVAL when a graph does not fit the LDS flag arrays
+struct TdStepLists {
+    int32_t *dirty_rows, *dirty_count;
+    int32_t *reach_rows, *rest_rows, *reach_counts;
+    int32_t *level_rows, *level_counts;
+    int levels;
+};
+int td_launch_step_lists(const uint8_t *clean, const float4 *x4, const int32_t *nbr, const int32_t *node_ptr, int64_t N,
+                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s);
 // bookkeeping a session step resets in its first kernel: up to three counter arrays and the ligand rows' forward-reach flags
 struct TdStepReset {
     int32_t *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;

@@ -354,6 +354,18 @@ def test_session_forward_equals_stateless_forward(model, case):
             assert torch.equal(got[k], want[k]), (case, step, k, _maxdiff(got[k], want[k]))
         n_all, dirty, levels = sess.row_counts()
         assert n_all == N and lpos.shape[0] <= dirty <= N
+        # the step's row lists come from one launch (a workgroup per graph) or, for graphs too large for that kernel's LDS flags,
+        # from the separate list kernels: same sets, same outputs
+        nat.set_option('session_step_lists', 0)
+        again = sess.forward(lpos, lv)
+        assert sess.row_counts() == (n_all, dirty, levels) and sess.forward_reach_rows() is not None
+        n_fwd0 = sess.forward_reach_rows()
+        nat.set_option('session_step_lists', 1)
+        for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+            assert torch.equal(again[k], want[k]), (case, step, k, 'separate list kernels')
+        once_more = sess.forward(lpos, lv)
+        assert sess.forward_reach_rows() == n_fwd0 and sess.row_counts() == (n_all, dirty, levels)
+        assert torch.equal(once_more['pred_ligand_pos'], want['pred_ligand_pos'])
         # receptive-field levels of the ligand outputs: nested, each at least the ligand atoms, at most every node
         assert len(levels) >= 1 and all(lpos.shape[0] <= a <= b <= N for a, b in zip(levels, levels[1:] + [N]))
         if case == '1h36':
