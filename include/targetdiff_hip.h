@@ -91,7 +91,7 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *                            split exactly into three bf16 pieces (an fp32 significand = 3 x 8 bits; 6 of the 9 piece products,
  *                            fp32 accumulation): fp32-equivalent results, 0 = plain fp32 MFMA
  *   "edge_key_split"         1 (default): the 21-wide radial / edge-type first layer of the attention passes on 32-slot rows
- *                            (x2h key and value passes, the h2x stage) and of the chunked key pass on v_mfma_f32_16x16x32_bf16
+ *                            (x2h key and value passes, the h2x stage), of the chunked key pass and of the edge gate on v_mfma_f32_16x16x32_bf16
  *                            with the same exact three-piece split of both operands; 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
  *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
  *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with

@@ -421,6 +421,27 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     size_t oGb0 = pack_vec(pk, gate.b0, H), oGg = pack_vec(pk, gate.g, H), oGb = pack_vec(pk, gate.b, H),
            oGw3 = pack_vec(pk, gate.w3, H), oGoff = pack_vec(pk, goff, TD_NG);
     const float gate_b3 = gate.b3[0], gate_coeff = gaussian_coeff(goff);
+    // the same first layer as bf16 piece triples in the A-operand order of v_mfma_f32_16x16x32_bf16 (see pack_edge_mlp)
+    const size_t oGRp = pk.alloc((size_t)3 * 8 * 48 * 4);
+    {
+        uint32_t *dp = reinterpret_cast<uint32_t *>(pk.data.data() + oGRp);
+        for (int hb = 0; hb < 8; ++hb)
+            for (int l48 = 0; l48 < 48; ++l48) {
+                const int lo = l48 & 15, g = l48 >> 4, n = 16 * hb + lo;
+                uint32_t pieces[3][8];
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = 8 * g + j;
+                    float r = kk < TD_NG ? gate.w0[(size_t)n * TD_NG + kk] : 0.f;
+                    for (int p = 0; p < 3; ++p) {
+                        pieces[p][j] = bf16_rne(r);
+                        r -= bf16_to_f32(pieces[p][j]);
+                    }
+                }
+                for (int p = 0; p < 3; ++p)
+                    for (int w = 0; w < 4; ++w)
+                        dp[(((size_t)p * 8 + hb) * 48 + l48) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
+            }
+    }
     // ---- layers
     struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; };
     std::vector<LayerOff> lo(L);
@@ -468,7 +489,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     const float *D = m->blob;
     m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
-    m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff};
+    m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
                          o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0};
@@ -505,6 +526,7 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
     } else if (strcmp(name, "edge_key_split") == 0) {
         m->opt.edge_key_split = value != 0;
+        m->gate.use_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) {
             m->layers[l].hk.use_split = m->layers[l].hk.R16p && value != 0;
             m->layers[l].hv.use_split = m->layers[l].hv.R16p && value != 0;

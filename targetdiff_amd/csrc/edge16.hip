@@ -825,6 +825,102 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     }
 }
 
+// ================================================================================================ edge gate
+// e_w = sigmoid(MLP(20 -> 128 -> 1)(GaussianSmearing(dist)))  (models/uni_transformer.py:312-316): the attention passes' tile
+// layout with a bias instead of the node projections and a 128-wide dot product instead of the second product.  One wave per
+// 32-slot row (a dst node, or a chunk of a node's in-edges on general graphs), first layer on bf16 piece triples (the 18 KiB
+// piece table, bias, LayerNorm affine and output weights in LDS), LayerNorm + ReLU in the transposed layout, then each lane
+// dots its 32 hidden units of an edge with w3 and the four lane groups add up.
+constexpr int G16_WAVES = 4;        // 162 VGPRs: three 4-wave workgroups per CU
+constexpr int G16P_U4 = 3 * 8 * 48;                                     // uint4 entries of the gate's piece table
+constexpr size_t G16_LDS_BYTES = (size_t)G16P_U4 * 16 + (size_t)4 * TD_H * sizeof(float);
+
+__global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, const float4 *__restrict__ x4,
+                                                                     const int32_t *__restrict__ nbr, int64_t N,
+                                                                     const int32_t *__restrict__ rows,
+                                                                     const int32_t *__restrict__ count_ptr,
+                                                                     const int32_t *__restrict__ chunk_node, float *__restrict__ ew) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint4 *Rp = reinterpret_cast<const uint4 *>(lds);              // [piece][hb][48]
+    float *B0 = lds + G16P_U4 * 4, *GAM = B0 + TD_H, *BET = GAM + TD_H, *W3 = BET + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    {
+        td_stage_lds16(reinterpret_cast<const float4 *>(gt.R16p), reinterpret_cast<float4 *>(lds), G16P_U4, tid, G16_WAVES * 64);
+        for (int t = tid; t < 4 * TD_H; t += G16_WAVES * 64) {
+            const int n = t & (TD_H - 1);
+            B0[t] = t < TD_H ? gt.b0[n] : (t < 2 * TD_H ? gt.gamma[n] : (t < 3 * TD_H ? gt.beta[n] : gt.w3[n]));
+        }
+    }
+    float offj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) offj[j] = (8 * g + j) < TD_NG ? gt.offsets[8 * g + j] : 0.f;
+    __syncthreads();
+    int64_t begin, end;
+    td_node_range16(N, count_ptr, begin, end);
+    const int l48 = (g < 3 ? g : 2) * 16 + lo;
+
+    for (int64_t it = begin + wid; it < end; it += G16_WAVES) {
+        const int64_t row = rows ? (int64_t)rows[it] : it;                       // row of nbr / ew
+        const int64_t i = chunk_node ? (int64_t)chunk_node[row] : row;          // its dst node
+        const float4 xi = x4[i];
+        int jn[2];
+        jn[0] = nbr[row * TD_K + lo];
+        jn[1] = nbr[row * TD_K + 16 + lo];
+        floatx4_t acc[2][8];
+        uint4 bm[2][3];
+        bool valid[2];
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            valid[eb] = jn[eb] >= 0;
+            const float4 xj = x4[valid[eb] ? jn[eb] : (int)i];
+            const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
+            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            float gv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = dist - offj[j];
+                gv[j] = (8 * g + j) < TD_NG ? expf(gt.coeff * u * u) : 0.f;
+            }
+            td_split_pair(gv[0], gv[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
+            td_split_pair(gv[2], gv[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
+            td_split_pair(gv[4], gv[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
+            td_split_pair(gv[6], gv[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                const float4 b = *reinterpret_cast<const float4 *>(B0 + 16 * hb + 4 * g);
+                acc[eb][hb][0] = b.x; acc[eb][hb][1] = b.y; acc[eb][hb][2] = b.z; acc[eb][hb][3] = b.w;
+            }
+        }
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            uint4 ar[2][3];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ar[h2][p] = Rp[(p * 8 + 2 * hp + h2) * 48 + l48];
+#define TD_PROD(pa, pb)                                                                                  \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < 2; ++eb)      \
+        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][pa], bm[eb][pb], acc[eb][2 * hp + h2]);
+            TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
+#undef TD_PROD
+        }
+        td_ln_relu16(GAM, BET, g, acc);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            float part = 0.f;
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                const float4 w = *reinterpret_cast<const float4 *>(W3 + 16 * hb + 4 * g);
+                part = fmaf(acc[eb][hb][0], w.x, part); part = fmaf(acc[eb][hb][1], w.y, part);
+                part = fmaf(acc[eb][hb][2], w.z, part); part = fmaf(acc[eb][hb][3], w.w, part);
+            }
+            const float logit = td_sum_groups(part) + gt.b3;
+            if (g == 0) ew[row * TD_K + 16 * eb + lo] = valid[eb] ? 1.0f / (1.0f + expf(-logit)) : 0.f;
+        }
+    }
+}
+
 // ================================================================================================ general graphs
 // Rows that are not exactly 32 wide (k-NN with k != 32, `hybrid`, radius with a fan-out cap): the in-edges of node i are
 // the chunks cptr[i] .. cptr[i+1]-1 of 32 slots (-1 padded; graph.hip).  The per-chunk arithmetic is the one above; what
@@ -1202,3 +1298,16 @@ int td_launch_edge_xv16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const flo
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
+
+// ---- edge gate ------------------------------------------------------------------------------------------------------
+int td_launch_gate16(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
+                     const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node) {
+    if (N == 0) return TD_OK;
+    TD_LDS_ONCE((edge_gate16_kernel), G16_LDS_BYTES);
+    int64_t G = (N + G16_WAVES - 1) / G16_WAVES;
+    if (G > 768) G = 768;              // three workgroups per CU
+    edge_gate16_kernel<<<dim3((unsigned)G), dim3(G16_WAVES * 64), G16_LDS_BYTES, s>>>(g, x4, nbr, N, rows, count_ptr, chunk_node, ew);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+

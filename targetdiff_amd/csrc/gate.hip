@@ -3,6 +3,7 @@
 //   models/common.py:24-26 (Gaussians), :60-80 (Linear -> LayerNorm -> ReLU -> Linear).
 // One wave per 32-slot row of the neighbour table (a dst node on the default k = 32 graph, a chunk of a dst node's
 // in-edges on general graphs: chunk_node != nullptr), all 128 hidden units as 4 N tiles.  Pure register kernel.
+// This is the fp32 variant (model option edge_key_split = 0); the default is edge_gate16_kernel in edge16.hip.
 #include "td_device.h"
 #include "td_internal.h"
 
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node) {
     if (N == 0) return TD_OK;
+    if (g.use_split) return td_launch_gate16(g, x4, nbr, N, rows, count_ptr, ew, s, chunk_node);
     int64_t blocks = (N + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     edge_gate_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(g, x4, nbr, N, rows, count_ptr, chunk_node, ew);

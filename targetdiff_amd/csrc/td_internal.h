@@ -89,6 +89,8 @@ struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_tr
     float b3;
     const float *offsets;  // [20]
     float coeff;
+    const float *R16p;     // the 20 x 128 first layer as bf16 piece triples [3 piece][8 hidden block][48 lanes] x 8 bf16 (k = 8g + j)
+    bool use_split;        // model option "edge_key_split"
 };
 
 struct TdEmbed {
@@ -174,6 +176,9 @@ int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_
 constexpr int TD_HOP_LEVELS = 4;
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
                          int32_t *rows, int32_t *counts, int levels, hipStream_t s, bool zeroed = false);
+// edge gate on 16 x 16 tiles with the bf16 first layer (edge16.hip); td_launch_gate (gate.hip) dispatches to it
+int td_launch_gate16(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
+                     const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node);
 // all row lists of a sampling step in one launch (graph.hip); TD_EINVAL when a graph does not fit the LDS flag arrays
 struct TdStepLists {
     int32_t *dirty_rows, *dirty_count;
