@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
     float *__restrict__ P = sg.P, *__restrict__ q = sg.q;
     unsigned mat_mask = sg.mask;
     int64_t N = sg.N;
-    int unit = gridDim.y > 1 ? (int)blockIdx.y : -1;
+    int unit = -1;
     if (sg.units > 1) {
         unit = bx % sg.units;
         bx /= sg.units;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
         return slot < N ? (rows ? rows[slot] : slot) : -1;
     };
 
-    // Small launches (ligand rows only) are split over blockIdx.y: one independent unit (a projection, or the
-    // two-GEMM query MLP) per y, so that a 3 k-row launch fills the chip instead of 28 CUs.
+    // Small launches are split by matrix unit (sg.units > 1): one independent unit (a projection, or the two-GEMM query
+    // MLP) per workgroup, so that a 3 k-row launch fills the chip instead of 28 CUs.
     if (unit >= 0) {
         int seen = 0;
         unsigned sel = 0;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
     float *__restrict__ P = sg.P, *__restrict__ q = sg.q;
     unsigned mat_mask = sg.mask;
     int64_t N = sg.N;
-    int unit = gridDim.y > 1 ? (int)blockIdx.y : -1;
+    int unit = -1;
     if (sg.units > 1) {
         unit = bx % sg.units;
         bx /= sg.units;
@@ -423,7 +423,7 @@ static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const i
 
 static TdLdsOnce g_np_lds, g_nps_lds, g_egnn_node_lds;
 
-static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, unsigned y, unsigned threads, hipStream_t s) {
+static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, hipStream_t s) {
     int rc;
     // bf16 x 3 operand split (exact: an fp32 significand is three 8-bit pieces; fp32 accumulation) when every stage of the
     // launch carries the pre-split weights and the model option asks for it
@@ -431,10 +431,10 @@ static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, uns
     for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.use_split && a.seg[i].st.projB3 != nullptr;
     if (split) {
         if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel), NPS_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_split_kernel<<<dim3(total_blocks, y), dim3(threads), NPS_LDS_BYTES, s>>>(a, h);
+        node_proj_split_kernel<<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
     } else {
         if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_kernel<<<dim3(total_blocks, y), dim3(threads), NP_LDS_BYTES, s>>>(a, h);
+        node_proj_kernel<<<dim3(total_blocks), dim3(256), NP_LDS_BYTES, s>>>(a, h);
     }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
@@ -445,22 +445,14 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
                         unsigned mask2) {
     if (N == 0 || mat_mask == 0) return TD_OK;
     if (!rows2 || N2 == 0 || (mask2 & 0x1fu) == 0) { rows2 = nullptr; N2 = 0; mask2 = 0; }
-    // few rows (ligand atoms only): one wave per workgroup and one independent unit per blockIdx.y, so that the launch
-    // spreads over the whole chip; many rows: 4 waves share each staged B chunk and keep the A tile for all matrices
-    const bool small = N <= TD_SMALL_BATCH_ROWS && !rows2 && !count_ptr;
     NpArgs a;
     a.nseg = 0;
     unsigned total = 0;
-    if (small) {
-        const unsigned units = (unsigned)__builtin_popcount(mat_mask & 0x1fu);
-        total += np_fill(a.seg[a.nseg++], st, rows, nullptr, N, mat_mask, P, q, false, 32);
-        return np_launch(a, h, total, units, 64u, s);
-    }
     if (rows2) total += np_fill(a.seg[a.nseg++], st, rows2, nullptr, N2, mask2, P, q, true, 128);
     // a small batch (N bounds the device-side count) cannot fill the chip with one workgroup per 128 rows walking through
     // all six GEMMs: one workgroup per (128 rows, matrix unit) instead -- 5x the parallelism, same arithmetic
     total += np_fill(a.seg[a.nseg++], st, rows, count_ptr, N, mat_mask, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
-    return np_launch(a, h, total, 1u, 256u, s);
+    return np_launch(a, h, total, s);
 }
 
 // The h2x-stage projections of layer l (stage `hx`: src-side units on `hop_rows`, dst-side units + queries on the ligand
@@ -477,7 +469,7 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
     if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
     total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, N <= TD_SMALL_BATCH_ROWS, 128);
     total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
-    return np_launch(a, h, total, 1u, 256u, s);
+    return np_launch(a, h, total, s);
 }
 
 // ------------------------------------------------------------------------------------------ EGNN node update
