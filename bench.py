@@ -221,6 +221,29 @@ def build_model(dev, args=None):
     return model
 
 
+def split_error_table():
+    """The committed error table of the bf16 x 3 switches (the newest profiles/*_split_error_table.txt)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_split_error_table.txt')))
+    return os.path.relpath(files[-1], ROOT) if files else 'tests/test_gpu_graph_modes.py::test_model_options_live_in_the_handle'
+
+
+def stateless_floor(model, batch, lpos, lv, max_nodes, steps=10, warmup=3):
+    """The geometry-independent floor: the same batch through the stateless td_model_forward at every step (no sampling
+    session: no static-protein caching, no row pruning -- every layer on every row)."""
+    s0 = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch, lpos, lv,
+                              batch.ligand_element_batch, num_steps=steps + warmup, center_pos_mode='protein',
+                              max_graph_nodes=max_nodes, use_session=False)
+    for _ in range(warmup):
+        s0.step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        s0.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / steps * 1e3
+
+
 def graph_desc(args):
     if args.cutoff_mode == 'radius':
         return f'radius {args.radius} A, fan-out cap {args.cap}'
@@ -338,6 +361,7 @@ def main():
     ap.add_argument('--initial-state', action='store_true',
                     help='after the timed region, also time 10 steps from the sampler\'s initial state N(0, I)')
     ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
+    ap.add_argument('--no-stateless', action='store_true', help='skip the 10 stateless steps reported as stateless_ms_per_step')
     ap.add_argument('--knn', type=int, default=32, help='fan-in of the k-NN / hybrid graph (C5 sweep: 16, 32, 48, 64)')
     ap.add_argument('--cutoff-mode', default='knn', choices=['knn', 'hybrid', 'radius'])
     ap.add_argument('--radius', type=float, default=6.0, help='cut-off (A) of --cutoff-mode radius')
@@ -387,23 +411,31 @@ def main():
     n_nodes = int(batch.protein_pos.shape[0] + lpos.shape[0])
     n_lig = int(lpos.shape[0])
     max_nodes = max(p.num_atoms for p in pockets) + max(sizes)
-    total = args.warmup + args.steps
+    args.prof_steps = max(1, min(args.steps, 10))
+    total = args.warmup + args.steps + args.prof_steps
     if total > 1000:
-        raise SystemExit('warmup + steps must be <= 1000 (one sampling run)')
+        raise SystemExit('warmup + steps + the profiled steps must be <= 1000 (one sampling run)')
     sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
                                    lpos, lv, batch.ligand_element_batch, num_steps=total, center_pos_mode='protein',
                                    max_graph_nodes=max_nodes, use_session=not args.no_session)
     for _ in range(args.warmup):
         sampler.step()
 
-    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k', 'x2h_v')
+    # the timed region: K steps, nothing else on the stream (no per-class timers)
     fence()
-    capi.profile_begin(classes)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sampler.step()
     fence()
     elapsed = time.perf_counter() - t0
+    # roofline leg: the next steps of the same run with HIP events around the x2h key / value launches, recorded on the
+    # launch stream (td_profile_begin / td_profile_end); their launch times feed `roofline`, not `value`
+    classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k', 'x2h_v')
+    prof_steps = args.prof_steps
+    capi.profile_begin(classes)
+    for _ in range(prof_steps):
+        sampler.step()
+    torch.cuda.synchronize()
     prof = capi.profile_end()
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -456,8 +488,10 @@ def main():
         # profile of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_collect.sh;
         # FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM) -- static, see traffic_source
         traffic, source = None, None
+        if args.workload != 'c2':
+            traffic_file = traffic_file.replace('.json', f'_{args.workload}.json')
         tpath = os.path.join(ROOT, 'profiles', traffic_file)
-        if os.path.exists(tpath) and args.workload == 'c2' and sampler.session is not None and default_graph:
+        if os.path.exists(tpath) and sampler.session is not None and default_graph:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
@@ -472,7 +506,7 @@ def main():
                 'hbm_frac': (traffic / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
                 'achieved_canonical_formulation': KEY_PASS_FLOP_CANONICAL * rows_per_launch / (ms * 1e-3) / 1e12,
                 'flop_per_node_executed': KEY_PASS_FLOP_EXECUTED, 'flop_per_node_canonical': KEY_PASS_FLOP_CANONICAL,
-                'share_of_step': (p['ms'] / args.steps) / (sec_per_step * 1e3)}
+                'share_of_step': (p['ms'] / prof_steps) / (sec_per_step * 1e3), 'profiled_steps': prof_steps}
 
     if default_graph:
         vk, kk = (('edge_value16_kernel<true>', 'edge_key16_kernel<false, 12, 0, false, true>') if split
@@ -507,7 +541,7 @@ def main():
         + '; k-NN rule (d2 association, ties -> lower index) is the project\'s: torch_cluster is not in the reference tree, '
           'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
         + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
-           '(fp32-equivalent: errors against the reference golden unchanged, profiles/r02d_split_error_table.txt)')
+           f'(fp32-equivalent: errors against the reference golden unchanged, {split_error_table()})')
         + ('; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split' if split else '') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
@@ -534,12 +568,18 @@ def main():
         n0, d0, lv0c = s0.session.row_counts()
         out['initial_state'] = {'ligand_spread': 1.0, 'ms_per_step': ms0, 'value': world * graphs / ms0, 'steps': 10,
                                 'session_rows': {'nodes': n0, 'layer0_rows': d0, 'receptive_field_levels': lv0c}}
+    if world == 1 and sampler.session is not None and not args.no_stateless:
+        ms_floor = stateless_floor(model, batch, lpos, lv, max_nodes)
+        out['stateless_ms_per_step'] = ms_floor
+        out['stateless_value'] = graphs / ms_floor
+        out['stateless_note'] = ('10 steps of the same batch without the sampling session (td_model_forward per step: every layer '
+                                 'on every row, no caching) -- the geometry-independent floor of `value`')
     del sampler
     if rank == 0:
         if args.profile_all:
             for k, v in prof.items():
                 if v['launches']:
-                    print(f'  {k:10s} {v["ms"] / args.steps:9.3f} ms/step  ({v["launches"] // args.steps} launches/step)',
+                    print(f'  {k:10s} {v["ms"] / prof_steps:9.3f} ms/step  ({v["launches"] // prof_steps} launches/step)',
                           file=sys.stderr)
         # a complete run the driver's own clock can witness: outside the timed region, the 20-step line above is unchanged
         if world == 1 and args.workload == 'c2' and not args.no_full_run and not args.no_session and default_graph:

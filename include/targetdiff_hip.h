@@ -25,6 +25,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the entry points declared below are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define TD_OK 0
 #define TD_EINVAL (-1)      /* bad argument / unsupported configuration */
@@ -248,6 +252,9 @@ int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const f
  *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */
 int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,8 @@ LIB = os.path.join(LIBDIR, 'libtargetdiff_hip.so')
 SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'gate.hip', 'edge16.hip', 'misc.hip', 'likelihood.hip', 'egnn.hip']
 ARCH = 'gfx950'
 # NB: the kNN distance uses __fmul_rn/__fadd_rn explicitly (td_dist2), so the default fp contraction is safe.
-FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function']
+# -fvisibility=hidden: only the extern "C" entry points of include/targetdiff_hip.h (visibility push(default)) are exported
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function']
 
 
 def hipcc() -> str:
@@ -62,8 +63,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print(out, file=sys.stderr)
     if failed:
         raise RuntimeError('hipcc compilation failed')
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+    if force or procs or _stale(LIB, objs + [os.path.join(CSRC, 'exports.map')]):
+        cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', f'-Wl,--version-script,{os.path.join(CSRC, "exports.map")}',
+               '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

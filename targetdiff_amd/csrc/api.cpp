@@ -496,7 +496,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
-                           m->opt.node_proj_split != 0};
+                           m->opt.node_proj_split != 0, m->opt.node_proj_async != 0};
     };
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
@@ -524,6 +524,9 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     else if (strcmp(name, "node_proj_split") == 0) {
         m->opt.node_proj_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+    } else if (strcmp(name, "node_proj_async") == 0) {
+        m->opt.node_proj_async = value != 0;
+        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.async_copy = m->layers[l].nodeH2x.async_copy = value != 0;
     } else if (strcmp(name, "edge_key_split") == 0) {
         m->opt.edge_key_split = value != 0;
         m->gate.use_split = value != 0;
@@ -546,6 +549,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     if (!m || !name || !value) { td_set_error("td_model_get_option: null argument"); return TD_EINVAL; }
     if (strcmp(name, "h2x_fused") == 0) *value = m->opt.h2x_fused;
     else if (strcmp(name, "node_proj_split") == 0) *value = m->opt.node_proj_split;
+    else if (strcmp(name, "node_proj_async") == 0) *value = m->opt.node_proj_async;
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
@@ -752,9 +756,14 @@ int plan_create(const td_config &c, const int32_t *host_pptr, const int32_t *hos
     p.prot_node = reinterpret_cast<int32_t *>(b + o_pn); p.pptr = reinterpret_cast<int32_t *>(b + o_pp);
     p.meta = reinterpret_cast<int32_t *>(b + o_meta);
     // the small per-graph tables: synchronous copies (the source vectors die with this frame)
-    TD_CHECK_HIP(hipMemcpyAsync(b + o_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s));
-    TD_CHECK_HIP(hipMemcpyAsync(p.pptr, host_pptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
-    TD_CHECK_HIP(hipStreamSynchronize(s));
+    e = hipMemcpyAsync(b + o_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(p.pptr, host_pptr, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        td_set_error("graph plan: copying the per-graph tables failed: %s", hipGetErrorString(e));
+        plan_destroy(p, s);
+        return TD_EHIP;
+    }
     *out = p;
     return TD_OK;
 }
@@ -824,8 +833,13 @@ int plan_from_mask(const td_config &c, const uint8_t *d_mask, const int32_t *d_n
     int rc = plan_create(c, hp.data(), hl.data(), B, s, out);
     if (rc != TD_OK) return rc;
     if (!prot.empty()) {
-        TD_CHECK_HIP(hipMemcpyAsync(out->prot_node, prot.data(), prot.size() * 4, hipMemcpyHostToDevice, s));
-        TD_CHECK_HIP(hipStreamSynchronize(s));
+        hipError_t e = hipMemcpyAsync(out->prot_node, prot.data(), prot.size() * 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            td_set_error("graph plan: copying the protein row list failed: %s", hipGetErrorString(e));
+            plan_destroy(*out, s);
+            return TD_EHIP;
+        }
     }
     *nl_out = hl[B];
     return TD_OK;
@@ -1139,7 +1153,7 @@ extern "C" int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t ed
     for (int l = 0; l < num_layers; ++l) {
         const Off &o = off[(size_t)l];
         TdEgnnLayer &L = m->layers[l];
-        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, false};
         L.W2f = D + o.W2f; L.Wxf = D + o.Wxf; L.vec = D + o.vec; L.nodeB = D + o.nodeB; L.nb1 = D + o.nb1; L.nb2 = D + o.nb2;
     }
     *out = m;

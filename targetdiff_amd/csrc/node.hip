@@ -65,7 +65,9 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int NPS_CHUNK_U4 = 4 * 3 * 2 * 64;            // uint4 per staged chunk: 4 k-steps x 3 pieces x 2 tiles x 64 lanes (24 KiB)
 constexpr int NPS_CHUNKS = 4;
-constexpr size_t NPS_LDS_BYTES = (size_t)2 * NPS_CHUNK_U4 * 16 + (size_t)4 * 32 * NP_TSTRIDE * sizeof(float);
+constexpr int NPS_BIAS_FLOATS = 6 * TD_H;               // the stage's six bias vectors (read from LDS: a global load in the round
+                                                        // loop would make the compiler wait on vmcnt, i.e. on the async B copy)
+constexpr size_t NPS_LDS_BYTES = (size_t)2 * NPS_CHUNK_U4 * 16 + (size_t)(4 * 32 * NP_TSTRIDE + NPS_BIAS_FLOATS) * sizeof(float);
 
 __device__ __forceinline__ floatx16 td_mfma_bf16(uint4 a, uint4 b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -248,6 +250,16 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
 // workgroup lifetime, so a GEMM runs as two half-N GEMMs (2 N tiles = 32 accumulator VGPRs, 6 B fragments in flight) and
 // the wave stays under 256 VGPRs without spilling at 2 waves per SIMD.  B stream per matrix (packed by pack_B128_split):
 // 4 chunks of 24 KiB = [half 2][k-chunk 2] x [k-step 4][piece 3][tile 2][lane 64] x 16 B, consumed in that order.
+// ASYNC (default): the next B chunk is copied global -> LDS by global_load_lds issued from inline assembly, and the round
+// ends with an explicit s_waitcnt vmcnt(0) in front of its barrier, so the copy flies behind the round's 48 MFMAs.  Issued
+// through the builtin (ASYNC = false, model option node_proj_async = 0) the compiler cannot tell the copy's LDS
+// destination from the buffer being read and puts s_waitcnt vmcnt(0) in front of the round's first ds_read: every one of the
+// 24 rounds then starts by waiting out a full L2 round trip (98 us per full-size launch against 33 us of MFMA time, round 2).
+// (Staging through registers instead costs 24 VGPRs the kernel does not have: the chunk lands in scratch.)
+__device__ __forceinline__ void td_glds16_asm(const uint4 *gsrc_lane, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory", "m0");
+}
+template <bool ASYNC>
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, const float *__restrict__ h) {
     int bx = blockIdx.x, si = 0;
     while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
@@ -293,9 +305,11 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
     };
     auto mat_ptr = [&](int m) -> const uint4 * { return m < 5 ? Bp + (size_t)m * MAT_U4 : Bq3; };
     int mat = __builtin_ctz(seq_mask);
-    {   // prologue: first chunk of the first matrix
+    float *sbias = lds + 2 * NPS_CHUNK_U4 * 4 + 4 * 32 * NP_TSTRIDE;
+    {   // prologue: first chunk of the first matrix, the bias vectors
         const uint4 *first = mat_ptr(mat);
         for (int u = tid; u < NPS_CHUNK_U4; u += blockDim.x) bufs[u] = first[u];
+        for (int u = tid; u < NPS_BIAS_FLOATS; u += blockDim.x) sbias[u] = u < 5 * TD_H ? st.projBias[u] : st.q3Bias[u - 5 * TD_H];
     }
     uint4 ap[3][8];
     {
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
     int cur = 0;
     floatx16 keep[2];          // q.net.0: columns 0..63 while the second half is computed (LayerNorm needs the whole row)
     for (; mat >= 0; mat = mat_after(mat)) {
-        const float *bias = mat < 5 ? st.projBias + mat * TD_H : st.q3Bias;
+        const float *bias = sbias + mat * TD_H;
         const uint4 *B = mat_ptr(mat);
         const int mat_next = mat_after(mat);
 #pragma unroll
@@ -328,10 +342,16 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
                 const int chunk = 2 * half + kc;
                 const uint4 *src = chunk + 1 < NPS_CHUNKS ? B + (size_t)(chunk + 1) * NPS_CHUNK_U4
                                                             : (mat_next >= 0 ? mat_ptr(mat_next) : nullptr);
-                if (src) {
+                if constexpr (ASYNC) {
+                    if (src) {
+                        const uint32_t lbase = __builtin_amdgcn_readfirstlane(
+                            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63)));
+#pragma unroll
+                        for (int u = 0; u < NPS_CHUNK_U4 / 256; ++u) td_glds16_asm(src + u * 256 + tid, lbase + u * 256 * 16);
+                    }
+                } else if (src) {
                     uint4 *dst = bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63);
-                    const int nthr = blockDim.x;
-                    for (int u = 0; u < NPS_CHUNK_U4; u += nthr)
+                    for (int u = 0; u < NPS_CHUNK_U4; u += 256)
                         td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
                 }
                 const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane;
@@ -357,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[0][t], acc[t]);
                 }
+                if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // the copy the compiler does not know about
                 __syncthreads();
                 cur ^= 1;
             }
@@ -421,7 +442,7 @@ static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const i
     return g.blocks;
 }
 
-static TdLdsOnce g_np_lds, g_nps_lds, g_egnn_node_lds;
+static TdLdsOnce g_np_lds, g_nps_lds, g_npsa_lds, g_egnn_node_lds;
 
 static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, hipStream_t s) {
     int rc;
@@ -429,9 +450,12 @@ static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, hip
     // launch carries the pre-split weights and the model option asks for it
     bool split = true;
     for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.use_split && a.seg[i].st.projB3 != nullptr;
-    if (split) {
-        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel), NPS_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_split_kernel<<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
+    if (split && a.seg[0].st.async_copy) {
+        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel<true>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<true><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
+    } else if (split) {
+        if ((rc = td_set_lds(g_npsa_lds, reinterpret_cast<const void *>(node_proj_split_kernel<false>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<false><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
     } else {
         if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
         node_proj_kernel<<<dim3(total_blocks), dim3(256), NP_LDS_BYTES, s>>>(a, h);

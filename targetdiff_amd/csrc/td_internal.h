@@ -74,6 +74,7 @@ struct TdNodeStage {
     const float *projB3;   // optional: the same 5 matrices as bf16 piece triples [mat][8 kstep][3 piece][64 lane][4 ntile] x 8 bf16
     const float *q3B3;     // optional: q.net.3 likewise (nullptr: the fp32 path is the only one)
     bool use_split;        // run the GEMMs on the exact 3-way bf16 operand split (model option "node_proj_split")
+    bool async_copy;         // split kernel: B chunks by inline-asm global_load_lds + explicit wait (model option "node_proj_async", default)
 };
 
 struct TdLayer {
@@ -130,6 +131,7 @@ struct TdOptions {
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
+    int node_proj_async = 1;    // split node GEMMs: B chunks by inline-asm global_load_lds + an explicit wait per round (0: the builtin, which the compiler serialises)
     int session_step_lists = 1;    // a step's row lists from one launch (a workgroup per graph; 0: the separate kernels, which
                                    // graphs too large for its LDS flags use anyway)
 };

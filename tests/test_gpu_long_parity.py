@@ -41,6 +41,14 @@ def model(state_dict):
     return m.to(dev).eval()
 
 
+def _golden_or_skip(name):
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, name)):
+        pytest.skip(f'{name} not generated yet (oracle/make_golden_r3.py)')
+    return load_golden(name)
+
+
 def _maxdiff(a, b):
     a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
     b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
@@ -170,6 +178,42 @@ def test_late_steps_teacher_forced_vs_reference(model):
         if s in kept:
             assert _maxdiff(log_v0, g['v0_traj'][kept[s]]) <= TOL_LOGP
     print(f'late steps teacher-forced: max |dx| = {worst:.3e}')
+    assert worst <= TOL_STEP
+
+
+# ------------------------------------------------------------------------------------------ 1000 steps on the real pocket
+def test_real_pocket_1000_steps_vs_reference(model):
+    """The REAL reference's complete 1000-step run on 1h36 x 2 (prior sizes) with the counter draws: late-t geometry on a real
+    pocket meets the session caching (oracle/make_golden_r3.py).  Free-running through the session and the stateless forward."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    g = _golden_or_skip('sample_1h36x2_1000.npz')
+    pocket, _ = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 2, g['sizes'])
+    init = torch.from_numpy(g['init_ligand_pos']), torch.from_numpy(g['init_ligand_v'].astype(np.int64))
+    r = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev)
+    _check_trajectory(r, g, 1000, '1h36 x 2, 1000 steps (session)')
+    r2 = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev, use_session=False)
+    assert torch.equal(torch.stack(r['pos_traj']), torch.stack(r2['pos_traj']))
+    assert torch.equal(torch.stack(r['v_traj']), torch.stack(r2['v_traj']))
+
+
+def test_real_pocket_teacher_forced_steps_vs_reference(model):
+    """Every 50th step and the last 12 (t = 11 .. 0) of that run, each started from the reference's own recorded state."""
+    from targetdiff_amd import workloads
+    dev = _dev()
+    g = _golden_or_skip('sample_1h36x2_1000.npz')
+    pocket, _ = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 2, g['sizes'])
+    worst = 0.0
+    for j, s in enumerate(int(s) for s in g['kept_steps']):
+        pos, v, log_v0, log_post = _one_step(model, batch, torch.from_numpy(g['pos_traj'][s - 1]),
+                                             torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s,
+                                             int(g['draws_base']), dev)
+        assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s} (t = {999 - s})'
+        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
+        assert _maxdiff(log_v0, g['v0_traj'][j]) <= TOL_LOGP
+    print(f'1h36 x 2 teacher-forced ({len(g["kept_steps"])} steps): max |dx| = {worst:.3e}')
     assert worst <= TOL_STEP
 
 

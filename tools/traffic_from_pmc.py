@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/traffic_x2h_{value,key}.json from a PMC summary (tools/pmc_summary.py output):
-    python tools/traffic_from_pmc.py profiles/r02d_pmc_c2.txt
+    python tools/traffic_from_pmc.py profiles/r03_pmc_c2.txt [c2|c3|c5]      (c3 / c5: traffic_x2h_*_c3.json ...)
 FETCH_SIZE / WRITE_SIZE are in KiB per launch (mean over the launches of the profiled run); bench.py applies the gfx950
 correction (FETCH_SIZE doubled) when it reads these files."""
 import json
@@ -25,17 +25,19 @@ def parse(path):
 
 def main():
     src = sys.argv[1]
+    workload = sys.argv[2] if len(sys.argv) > 2 else 'c2'
+    suffix = '' if workload == 'c2' else '_' + workload
     kernels = parse(src)
     # x2h stage instantiations: value pass; key pass tagged STAGE = 0, not RAW
-    picks = {'traffic_x2h_value.json': [k for k in kernels if k.startswith('edge_value16_kernel')],
-             'traffic_x2h_key.json': [k for k in kernels if re.match(r'edge_key16_kernel<false, \d+, 0, false', k)]}
+    picks = {f'traffic_x2h_value{suffix}.json': [k for k in kernels if k.startswith('edge_value16_kernel')],
+             f'traffic_x2h_key{suffix}.json': [k for k in kernels if re.match(r'edge_key16_kernel<false, \d+, 0', k)]}
     for fname, names in picks.items():
         if not names:
             print(f'{fname}: no matching kernel in {src}', file=sys.stderr)
             continue
         name = max(names, key=lambda k: kernels[k].get('FETCH_SIZE', (0, 0))[1])
         c = kernels[name]
-        out = {'kernel': name, 'workload': 'c2 (default bench state: ligand cloud std 2.0 A)',
+        out = {'kernel': name, 'workload': f'{workload} (default bench state: ligand cloud std 2.0 A)',
                'source': f'{os.path.relpath(src, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
                          f'tools/pmc_collect.sh; mean over the {c["FETCH_SIZE"][1]} launches of the profiled run)',
                'fetch_kb': c['FETCH_SIZE'][0], 'write_kb': c['WRITE_SIZE'][0],
