@@ -496,7 +496,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
-                           m->opt.node_proj_split != 0, m->opt.node_proj_async != 0};
+                           m->opt.node_proj_split != 0, m->opt.node_proj_bpipe != 0, m->opt.node_proj_async != 0};
     };
     for (int l = 0; l < L; ++l) {
         TdLayer &Ly = m->layers[l];
@@ -524,6 +524,9 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     else if (strcmp(name, "node_proj_split") == 0) {
         m->opt.node_proj_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+    } else if (strcmp(name, "node_proj_bpipe") == 0) {
+        m->opt.node_proj_bpipe = value != 0;
+        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.bpipe = m->layers[l].nodeH2x.bpipe = value != 0;
     } else if (strcmp(name, "node_proj_async") == 0) {
         m->opt.node_proj_async = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.async_copy = m->layers[l].nodeH2x.async_copy = value != 0;
@@ -550,6 +553,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     if (strcmp(name, "h2x_fused") == 0) *value = m->opt.h2x_fused;
     else if (strcmp(name, "node_proj_split") == 0) *value = m->opt.node_proj_split;
     else if (strcmp(name, "node_proj_async") == 0) *value = m->opt.node_proj_async;
+    else if (strcmp(name, "node_proj_bpipe") == 0) *value = m->opt.node_proj_bpipe;
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
@@ -590,15 +594,27 @@ Workspace carve(char *base, int64_t N, int64_t B, int64_t Nl) {
     return w;
 }
 
-int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew, const float *P,
-             const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
-    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s);
+// Neighbour table and per-slot buffers of one batch.  Default graph: cptr == nullptr, one 32-slot row per node (the
+// workspace's nbr / ew / alpha).  General graphs: chunk-indexed buffers of a GraphPlan, cptr[i] .. cptr[i+1]-1 = chunks of node i.
+struct GraphTab {
+    const int32_t *cptr;
+    int32_t *nbr;
+    float *ew, *alpha;
+    int cpn_p;               // chunks per protein row
+    int64_t NCl;             // chunks of all ligand rows together
+};
+GraphTab default_tab(Workspace &w) { return GraphTab{nullptr, w.nbr, w.ew, w.alpha, 1, 0}; }
+
+int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const float *ew, const int32_t *nbr,
+             const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
+    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s, gt.cptr);
 }
 // lig / Nl: the ligand rows of the batch (all of them are among `rows`: every row list of a step contains the ligand atoms)
-int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
+int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const int32_t *nbr, const float *P,
                const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig,
                int64_t Nl, hipStream_t s) {
-    return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s);
+    return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s, gt.cptr, gt.cpn_p,
+                                  lig ? gt.NCl : 0);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
@@ -611,26 +627,27 @@ int h2x_project(const TdLayer &L, Workspace &w, float *h, int64_t N, int64_t Nl,
     return td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, P, q, s, nullptr, w.lig_node, Nl, 0x15);
 }
 
-// attention over the ligand atoms' edges and the coordinate update xc -> xn
-int h2x_attend(const td_model *m, const TdLayer &L, Workspace &w, int64_t Nl, float4 *xc, float4 *xn, float *P, float *q,
-               float *alpha, hipStream_t s) {
+// attention over the ligand atoms' edges and the coordinate update xc -> xn.  Rows of several chunks (general graphs) take the
+// two-launch form (keys + softmax over all chunks of a row -> alpha in memory -> xv); one 32-slot row per node: fused.
+int h2x_attend(const td_model *m, const TdLayer &L, Workspace &w, const GraphTab &gt, int64_t Nl, float4 *xc, float4 *xn, float *P,
+               float *q, hipStream_t s) {
     int rc;
-    if (m->opt.h2x_fused) {
+    if (m->opt.h2x_fused && !gt.cptr) {
         ProfScope ps(PC_H2X_K, s);
-        return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, w.nbr, w.ew, P, q, w.lig_node, Nl, s);
+        return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, gt.nbr, gt.ew, P, q, w.lig_node, Nl, s);
     }
     {
         ProfScope ps(PC_H2X_K, s);
-        if ((rc = key_pass(L.xk, L, xc, w.nbr, w.ew, P, q, w.lig_node, nullptr, Nl, alpha, s)) != TD_OK) return rc;
+        if ((rc = key_pass(L.xk, L, xc, gt, gt.ew, gt.nbr, P, q, w.lig_node, nullptr, Nl, gt.alpha, s)) != TD_OK) return rc;
     }
     ProfScope ps(PC_H2X_V, s);
-    return td_launch_edge_xv16(L.xv, L, xc, xn, w.nbr, P, w.lig_node, Nl, alpha, s);
+    return td_launch_edge_xv16(L.xv, L, xc, xn, gt.nbr, P, w.lig_node, Nl, gt.alpha, s, gt.cptr);
 }
 
-// kNN + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch.  h is updated in place; returns
-// the buffer holding the final coordinates through *x_final.  hop_rows (optional, sampling session): the ligand atoms
-// and their neighbours -- the only rows whose h2x-stage projections and last-layer features are ever read when just the
-// ligand outputs are consumed.
+// L x (node_proj, x2h, node_proj, h2x) on a composed batch whose graph (gt.nbr) and edge gate (gt.ew) are in place.  h is
+// updated in place; returns the buffer holding the final coordinates through *x_final.  init_xn: x4b is not yet a copy of x4a.
+// hop_rows (optional, sampling session): the ligand atoms and their neighbours -- the only rows whose h2x-stage projections and
+// last-layer features are ever read when just the ligand outputs are consumed.
 // Sampling session, layer 1: rows outside the ligand's one-hop forward reach keep the protein-only graph's layer-1
 // output (`hs`), so the attention passes run on `rows` only and `rest` is restored from the cache afterwards.
 struct FwdReach {
@@ -638,8 +655,8 @@ struct FwdReach {
     const float *hs;
 };
 
-int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x, int max_graph_nodes,
-                 float4 **x_final, hipStream_t s, bool graph_ready = false, bool layer0_x2h_done = false,
+int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, int64_t N, int64_t Nl, int fix_x,
+                 float4 **x_final, hipStream_t s, bool init_xn, bool layer0_x2h_done = false,
                  const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr, int hop_levels = 0,
                  const FwdReach *fwd = nullptr) {
     int rc;
@@ -647,20 +664,9 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
     // row list of receptive-field level k (1-based); nullptr = every row
     auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
     auto level_count = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_count + (k - 1) : nullptr; };
-    if (!graph_ready) {
-        {
-            ProfScope ps(PC_KNN, s);
-            if (m->cfg.cutoff_mode == TD_CUTOFF_RADIUS)
-                rc = td_launch_radius32(w.x4a, w.node_ptr, w.gid, N, m->cfg.radius, m->cfg.max_num_neighbors, w.nbr, s);
-            else
-                rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn);
-            if (rc != TD_OK) return rc;
-        }
-        { ProfScope ps(PC_GATE, s); if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s)) != TD_OK) return rc; }
-    }
     float4 *xc = w.x4a, *xn = w.x4b;
     const bool do_h2x = !fix_x && Nl > 0;
-    if (do_h2x && !graph_ready) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    if (do_h2x && init_xn) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
     // Sampling session: only ligand outputs are consumed, so the layer e from the end updates receptive-field level e + 1
     // only, and its projections are needed on level e + 2 (those rows and their neighbours).
     auto proj_rows = [&](int l) -> const int32_t * { return l > 0 ? level_rows(Lc - 1 - l + 2) : nullptr; };
@@ -678,8 +684,8 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
             proj_done = false;
-            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, w.nbr, w.ew, w.P, w.q, rws, cnt, N, w.alpha, s)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, w.nbr, w.P, rws, cnt, N, h, w.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, gt, gt.ew, gt.nbr, w.P, w.q, rws, cnt, N, gt.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, gt, gt.nbr, w.P, rws, cnt, N, h, gt.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
             if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
@@ -693,11 +699,26 @@ int run_backbone(const td_model *m, Workspace &w, float *h, int64_t N, int64_t N
         } else {
             if ((rc = h2x_project(L, w, h, N, Nl, w.Px, w.qx, level_rows(1), level_count(1), s)) != TD_OK) return rc;
         }
-        if ((rc = h2x_attend(m, L, w, Nl, xc, xn, w.Px, w.qx, w.alpha, s)) != TD_OK) return rc;
+        if ((rc = h2x_attend(m, L, w, gt, Nl, xc, xn, w.Px, w.qx, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
     }
     *x_final = xc;
     return TD_OK;
+}
+
+// graph + edge gate of a composed batch on the default graph (32-slot rows: k-NN with k <= 32, radius with cap <= 32)
+int build_default_graph(const td_model *m, Workspace &w, int64_t N, int max_graph_nodes, hipStream_t s) {
+    int rc;
+    {
+        ProfScope ps(PC_KNN, s);
+        if (m->cfg.cutoff_mode == TD_CUTOFF_RADIUS)
+            rc = td_launch_radius32(w.x4a, w.node_ptr, w.gid, N, m->cfg.radius, m->cfg.max_num_neighbors, w.nbr, s);
+        else
+            rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn);
+        if (rc != TD_OK) return rc;
+    }
+    ProfScope ps(PC_GATE, s);
+    return td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s);
 }
 
 // ------------------------------------------------------------------------------------------ general graphs
@@ -775,36 +796,18 @@ int plan_layout(GraphPlan &p, const int32_t *node_ptr, const int32_t *gid, hipSt
                             p.chunk_node, p.lig_chunks, (int32_t)p.NC, s);
 }
 
-// graph + gate + L x (node_proj, x2h, node_proj, h2x) on a composed batch with a general graph: every layer on every row
-// (the row-list pruning of the sampling session is specific to the default graph).
-int run_backbone_general(const td_model *m, GraphPlan &p, Workspace &w, float *h, int64_t N, int64_t Nl, int fix_x,
-                         int max_graph_nodes, float4 **x_final, hipStream_t s) {
+GraphTab plan_tab(const GraphPlan &p) { return GraphTab{p.cptr, p.cnbr, p.ew, p.alpha, p.cpn_p, p.NCl}; }
+
+// graph + edge gate of a composed batch on a general graph (chunked table of the plan)
+int build_general_graph(const td_model *m, GraphPlan &p, Workspace &w, int64_t N, int64_t Nl, int max_graph_nodes, hipStream_t s) {
     int rc;
     {
         ProfScope ps(PC_KNN, s);
         if ((rc = td_launch_graph_general(p.mode, w.x4a, w.node_ptr, p.pptr, w.gid, p.prot_node, p.Np, w.lig_node, Nl, N, p.k,
                                           p.radius, max_graph_nodes, p.cptr, p.cnbr, p.NC, s)) != TD_OK) return rc;
     }
-    {
-        ProfScope ps(PC_GATE, s);
-        if ((rc = td_launch_gate(m->gate, w.x4a, p.cnbr, p.NC, nullptr, nullptr, p.ew, s, p.chunk_node)) != TD_OK) return rc;
-    }
-    float4 *xc = w.x4a, *xn = w.x4b;
-    const bool do_h2x = !fix_x && Nl > 0;
-    if (do_h2x) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    for (int l = 0; l < m->cfg.num_layers; ++l) {
-        const TdLayer &L = m->layers[l];
-        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_K, s); if ((rc = td_launch_edge_logits16(0, L.hk, L, xc, p.cnbr, w.P, w.q, p.chunk_node, nullptr, p.NC, p.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_V, s); if ((rc = td_launch_edge_value16_ragged(L.hv, L, xc, p.cnbr, p.ew, w.P, p.cptr, nullptr, N, h, p.alpha, s)) != TD_OK) return rc; }
-        if (!do_h2x) continue;
-        { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeH2x, h, N, nullptr, 0x0a, w.Px, w.qx, s, nullptr, w.lig_node, Nl, 0x15)) != TD_OK) return rc; }
-        { ProfScope ps(PC_H2X_K, s); if ((rc = td_launch_edge_logits16(1, L.xk, L, xc, p.cnbr, w.Px, w.qx, p.chunk_node, p.lig_chunks, p.NCl, p.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_H2X_V, s); if ((rc = td_launch_edge_xv16_ragged(L.xv, L, xc, xn, p.cnbr, p.ew, w.Px, p.cptr, w.lig_node, Nl, p.alpha, s)) != TD_OK) return rc; }
-        float4 *t = xc; xc = xn; xn = t;
-    }
-    *x_final = xc;
-    return TD_OK;
+    ProfScope ps(PC_GATE, s);
+    return td_launch_gate(m->gate, w.x4a, p.cnbr, p.NC, nullptr, nullptr, p.ew, s, p.chunk_node);
 }
 
 // Plan of a composed batch given as (mask_ligand, node_ptr) -- the refine_net seam: per-graph protein / ligand counts and
@@ -974,12 +977,14 @@ extern "C" int td_refine_forward(const td_model *m, const float *d_h, const floa
         int64_t nl_all = 0;
         if ((rc = plan_from_mask(m->cfg, d_mask_ligand, w.node_ptr, N, B, s, &p, &nl_all)) != TD_OK) return rc;
         rc = plan_layout(p, w.node_ptr, w.gid, s);
-        if (rc == TD_OK) rc = run_backbone_general(m, p, w, d_out_h, N, nl_all, fix_x, max_graph_nodes, &xf, s);
+        if (rc == TD_OK) rc = build_general_graph(m, p, w, N, nl_all, max_graph_nodes, s);
+        if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), d_out_h, N, nl_all, fix_x, &xf, s, true);
         if (rc == TD_OK) rc = td_launch_unpack_x(xf, N, d_out_x, s);
         plan_destroy(p, s);
         return rc;
     }
-    if ((rc = run_backbone(m, w, d_out_h, N, nl, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
+    if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
+    if ((rc = run_backbone(m, w, default_tab(w), d_out_h, N, nl, fix_x, &xf, s, true)) != TD_OK) return rc;
     if ((rc = td_launch_unpack_x(xf, N, d_out_x, s)) != TD_OK) return rc;
     if (d_out_nbr) TD_CHECK_HIP(hipMemcpyAsync(d_out_nbr, w.nbr, (size_t)N * TD_K * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if (d_out_ew) TD_CHECK_HIP(hipMemcpyAsync(d_out_ew, w.ew, (size_t)N * TD_K * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1020,7 +1025,8 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
                                    h, w.x4a, w.node_ptr, w.gid, w.lig_node, p.prot_node, s);
         }
         if (rc == TD_OK) rc = plan_layout(p, w.node_ptr, w.gid, s);
-        if (rc == TD_OK) rc = run_backbone_general(m, p, w, h, N, N_l, fix_x, max_graph_nodes, &xg, s);
+        if (rc == TD_OK) rc = build_general_graph(m, p, w, N, N_l, max_graph_nodes, s);
+        if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), h, N, N_l, fix_x, &xg, s, true);
         if (rc == TD_OK) {
             ProfScope ps(PC_HEAD, s);
             rc = td_launch_head(m->head, h, xg, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
@@ -1036,7 +1042,8 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
             return rc;
     }
     float4 *xf = nullptr;
-    if ((rc = run_backbone(m, w, h, N, N_l, fix_x, max_graph_nodes, &xf, s)) != TD_OK) return rc;
+    if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
+    if ((rc = run_backbone(m, w, default_tab(w), h, N, N_l, fix_x, &xf, s, true)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, h, xf, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
@@ -1153,7 +1160,7 @@ extern "C" int td_egnn_create(int32_t num_layers, int32_t hidden_dim, int32_t ed
     for (int l = 0; l < num_layers; ++l) {
         const Off &o = off[(size_t)l];
         TdEgnnLayer &L = m->layers[l];
-        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, false};
+        L.proj = TdNodeStage{D + o.projB, D + o.projBias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, false, false};
         L.W2f = D + o.W2f; L.Wxf = D + o.Wxf; L.vec = D + o.vec; L.nodeB = D + o.nodeB; L.nb1 = D + o.nb1; L.nb2 = D + o.nb2;
     }
     *out = m;
@@ -1312,14 +1319,22 @@ extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *
 // only on the protein is loop-invariant there (protein_pos, protein_v, batch_protein are passed unchanged to every
 // forward, :652-661; protein coordinates are never updated, models/uni_transformer.py:206) and is computed once:
 // embeddings, protein-only sorted neighbour lists, and -- for protein atoms that no ligand atom displaces from
-// their 32-NN row ("clean" rows, 80-90 % of them) -- the edge gate row and the layer-0 x2h output.
+// their k-NN row ("clean" rows, 80-90 % of them) -- the edge gate row and the layer-0 x2h output.
+// Three kinds:
+//   CACHING, default graph    k-NN with k <= 32: one 32-slot row per node (the workspace's nbr / ew / alpha)
+//   CACHING, general graph    k-NN with 32 < k <= 64 and `hybrid` (protein rows are plain k-NN rows there too): the same
+//                             machinery on the chunked table of a GraphPlan -- 64 static keys per protein row, cached gate
+//                             chunks, chunk-aware row lists, the chunk-loop edge kernels
+//   PLAIN                     radius graphs (rows in index order: no sorted lists to merge into) and graphs too large for
+//                             the row-list kernel's LDS flags: every step is a stateless forward on the session's layout
 struct td_session {
     const td_model *m;
     int64_t N, Np, Nl, B;
     int max_graph_nodes;
     char *block;
+    hipStream_t last_stream;     // stream of the latest call: the block is freed in its order
     Workspace w;                 // per-step buffers (x4a/x4b, gid, nbr, lig_node, node_ptr, ew, P, q, h, alpha)
-    int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count, *hop_rows, *hop_count;
+    int32_t *prot_node, *pptr, *lptr, *snbr, *dirty_rows, *dirty_count, *hop_rows, *hop_count, *dirty_chunks;
     int hop_levels;
     unsigned long long *skeys;
     float *ews, *h0, *h1s, *h2s, *P0, *q0;
@@ -1327,10 +1342,24 @@ struct td_session {
     int32_t *fwd_rows, *fwd_rest, *fwd_counts;
     bool use_fwd;
     uint8_t *clean;
-    int graph_nodes_max;         // exact size of the largest graph (0: unknown) -- sizes the LDS flags of td_launch_step_lists
-    bool general;                // non-default graph (k != 32, hybrid, radius): no static-protein caching, only the layout is kept
+    int graph_nodes_max;         // exact size of the largest graph -- sizes the LDS flags of td_launch_step_lists
+    bool caching;                // static-protein caching + receptive-field pruning (false: PLAIN)
+    bool chunked;                // general graph: the neighbour table lives in `plan`
     GraphPlan plan;
 };
+
+namespace {
+constexpr int TD_STEP_LISTS_MAX_NODES = 12288;       // LDS flags of step_lists_kernel: 4 bytes per node of a graph, 48 KiB
+
+GraphTab session_tab(td_session *S) { return S->chunked ? plan_tab(S->plan) : default_tab(S->w); }
+
+void session_free(td_session *S, hipStream_t s) {
+    if (!S) return;
+    if (S->chunked) plan_destroy(S->plan, s);
+    if (S->block) (void)hipFreeAsync(S->block, s);
+    delete S;
+}
+}  // namespace
 
 extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
                                  const int32_t *d_protein_ptr, int64_t N_p, const int32_t *d_ligand_ptr, int64_t N_l,
@@ -1343,57 +1372,40 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     const int64_t N = N_p + N_l;
     td_session *S = new (std::nothrow) td_session();
     if (!S) { td_set_error("td_session_create: out of host memory"); return TD_ENOMEM; }
-    S->m = m; S->N = N; S->Np = N_p; S->Nl = N_l; S->B = B; S->max_graph_nodes = max_graph_nodes;
-    S->general = !caching_graph(m->cfg);
-    if (S->general) {
-        // general graphs: the session keeps the embedded protein rows and the chunk layout; every step runs every row
-        const size_t ws = carve(nullptr, N, B, N_l).bytes;
-        size_t total = ws;
-        const size_t o_h0 = total; total += align_up((size_t)N * TD_H * 4);
-        const size_t o_pp = total; total += align_up((size_t)(B + 1) * 4);
-        const size_t o_lp = total; total += align_up((size_t)(B + 1) * 4);
-        const size_t o_tl = total; total += align_up((size_t)N_l * 12);
-        const size_t o_tv = total; total += align_up((size_t)N_l * 8);
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), total);
-        if (e != hipSuccess) { td_set_error("td_session_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); delete S; return TD_ENOMEM; }
-        char *b = S->block;
-        S->w = carve(b, N, B, N_l);
-        S->h0 = reinterpret_cast<float *>(b + o_h0);
-        S->pptr = reinterpret_cast<int32_t *>(b + o_pp);
-        S->lptr = reinterpret_cast<int32_t *>(b + o_lp);
-        auto failg = [&](int rc) { plan_destroy(S->plan, s); (void)hipFree(S->block); delete S; return rc; };
-        int rc;
-        std::vector<int32_t> hp, hl;
-        if ((rc = fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s)) != TD_OK) return failg(rc);
-        if ((rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) return failg(rc);
-        hipError_t e2 = hipMemcpyAsync(S->pptr, d_protein_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s);
-        if (e2 == hipSuccess) e2 = hipMemsetAsync(b + o_tl, 0, (size_t)N_l * 12, s);
-        if (e2 == hipSuccess) e2 = hipMemsetAsync(b + o_tv, 0, (size_t)N_l * 8, s);
-        if (e2 != hipSuccess) { td_set_error("td_session_create: %s", hipGetErrorString(e2)); return failg(TD_EHIP); }
-        if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, reinterpret_cast<float *>(b + o_tl),
-                                    reinterpret_cast<int64_t *>(b + o_tv), S->lptr, N_l, B, S->h0, S->w.x4a, S->w.node_ptr, S->w.gid,
-                                    S->w.lig_node, S->plan.prot_node, s)) != TD_OK) return failg(rc);
-        if ((rc = plan_layout(S->plan, S->w.node_ptr, S->w.gid, s)) != TD_OK) return failg(rc);
-        *out = S;
-        return TD_OK;
-    }
+    S->m = m; S->N = N; S->Np = N_p; S->Nl = N_l; S->B = B; S->max_graph_nodes = max_graph_nodes; S->last_stream = s;
+    S->chunked = !default_graph(m->cfg);
+    int rc;
+    // per-graph atom counts: the exact size of the largest graph, and the chunk layout of a general graph
+    std::vector<int32_t> hp, hl;
+    if ((rc = fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s)) != TD_OK) { delete S; return rc; }
+    int gmax = 0;
+    for (int64_t g = 0; g < B; ++g) gmax = std::max(gmax, (hp[g + 1] - hp[g]) + (hl[g + 1] - hl[g]));
+    S->graph_nodes_max = gmax;
+    const bool knn_like = m->cfg.cutoff_mode == TD_CUTOFF_KNN || m->cfg.cutoff_mode == TD_CUTOFF_HYBRID;
+    S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES);
+    if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
+    const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table
+    const int KS = S->chunked ? 64 : TD_K;                   // static keys kept per protein row
+
     // ---- one device block: [workspace | session-static buffers]
     const size_t ws_bytes = carve(nullptr, N, B, N_l).bytes;
     size_t off = ws_bytes;
-    auto reserve = [&](size_t n) { size_t o = off; off += align_up(n); return o; };
-    const size_t n = (size_t)N;
+    auto reserve = [&](size_t n) { size_t o = off; off += align_up(n ? n : 4); return o; };
+    const size_t n = (size_t)N, nc = (size_t)NC;
+    const bool C = S->caching;
     const size_t o_prot = reserve((size_t)N_p * 4), o_pptr = reserve((size_t)(B + 1) * 4), o_lptr = reserve((size_t)(B + 1) * 4),
-                 o_snbr = reserve(n * TD_K * 4), o_skeys = reserve(n * TD_K * 8), o_ews = reserve(n * TD_K * 4),
-                 o_h0 = reserve(n * TD_H * 4), o_h1s = reserve(n * TD_H * 4), o_h2s = reserve(n * TD_H * 4), o_f2 = reserve(n),
-                 o_frows = reserve(n * 4), o_frest = reserve(n * 4), o_fcnt = reserve(256), o_P0 = reserve(n * 4 * TD_H * 4),
-                 o_q0 = reserve(n * TD_H * 4), o_clean = reserve(n), o_dirty = reserve(n * 4), o_dcnt = reserve(256),
-                 o_hop = reserve(n * 4 * TD_HOP_LEVELS), o_hcnt = reserve(256),
-                 o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&S->block), off);
+                 o_h0 = reserve(n * TD_H * 4), o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8),
+                 o_snbr = reserve(C ? nc * TD_K * 4 : 0), o_skeys = reserve(C ? n * KS * 8 : 0), o_ews = reserve(C ? nc * TD_K * 4 : 0),
+                 o_h1s = reserve(C ? n * TD_H * 4 : 0), o_h2s = reserve(C ? n * TD_H * 4 : 0), o_f2 = reserve(C ? n : 0),
+                 o_frows = reserve(C ? n * 4 : 0), o_frest = reserve(C ? n * 4 : 0), o_fcnt = reserve(256),
+                 o_P0 = reserve(C ? n * 4 * TD_H * 4 : 0), o_q0 = reserve(C ? n * TD_H * 4 : 0), o_clean = reserve(C ? n : 0),
+                 o_dirty = reserve(C ? n * 4 : 0), o_dcnt = reserve(256), o_hop = reserve(C ? n * 4 * TD_HOP_LEVELS : 0),
+                 o_hcnt = reserve(256), o_dchunks = reserve(C && S->chunked ? nc * 4 : 0);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&S->block), off, s);
     if (e != hipSuccess) {
-        td_set_error("td_session_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
-        delete S;
+        td_set_error("td_session_create: hipMallocAsync(%zu) failed: %s", off, hipGetErrorString(e));
+        S->block = nullptr;
+        session_free(S, s);
         return TD_ENOMEM;
     }
     char *b = S->block;
@@ -1411,14 +1423,15 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->fwd_rows = reinterpret_cast<int32_t *>(b + o_frows);
     S->fwd_rest = reinterpret_cast<int32_t *>(b + o_frest);
     S->fwd_counts = reinterpret_cast<int32_t *>(b + o_fcnt);
-    S->use_fwd = m->opt.session_forward_reach && m->cfg.num_layers >= 2;
+    S->use_fwd = C && m->opt.session_forward_reach && m->cfg.num_layers >= 2;
     S->P0 = reinterpret_cast<float *>(b + o_P0);
     S->q0 = reinterpret_cast<float *>(b + o_q0);
     S->clean = reinterpret_cast<uint8_t *>(b + o_clean);
     S->dirty_rows = reinterpret_cast<int32_t *>(b + o_dirty);
-    S->dirty_count = reinterpret_cast<int32_t *>(b + o_dcnt);
+    S->dirty_count = reinterpret_cast<int32_t *>(b + o_dcnt);       // [0] rows, [1] chunks (general graphs)
     S->hop_rows = reinterpret_cast<int32_t *>(b + o_hop);
     S->hop_count = reinterpret_cast<int32_t *>(b + o_hcnt);
+    S->dirty_chunks = reinterpret_cast<int32_t *>(b + o_dchunks);
     {
         // receptive-field levels tracked per step (each prunes one more layer from the end)
         int lv = m->opt.session_hop_levels;
@@ -1430,40 +1443,55 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     float *tmp_lpos = reinterpret_cast<float *>(b + o_tmp_lpos);
     int64_t *tmp_lv = reinterpret_cast<int64_t *>(b + o_tmp_lv);
     Workspace &w = S->w;
-    auto fail = [&](int rc) { (void)hipFree(S->block); delete S; return rc; };
-    int rc;
+    auto fail = [&](int r) { session_free(S, s); return r; };
 #define TD_TRY(expr) do { if ((rc = (expr)) != TD_OK) return fail(rc); } while (0)
 #define TD_TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { td_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return fail(TD_EHIP); } } while (0)
     TD_TRY_HIP(hipMemcpyAsync(S->pptr, d_protein_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
     TD_TRY_HIP(hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
-    {   // exact size of the largest graph (max_graph_nodes is only a hint): one small D2H at session creation
-        std::vector<int32_t> hp, hl;
-        TD_TRY(fetch_ptrs(d_protein_ptr, d_ligand_ptr, B, hp, hl, s));
-        int gmax = 0;
-        for (int64_t g = 0; g < B; ++g) gmax = std::max(gmax, (hp[g + 1] - hp[g]) + (hl[g + 1] - hl[g]));
-        S->graph_nodes_max = gmax;
-    }
     TD_TRY_HIP(hipMemsetAsync(tmp_lpos, 0, (size_t)N_l * 12, s));
     TD_TRY_HIP(hipMemsetAsync(tmp_lv, 0, (size_t)N_l * 8, s));
     // embeddings + packed order (ligand rows are placeholders until the first step), protein row list
+    int32_t *prot_out = S->chunked ? S->plan.prot_node : S->prot_node;
     TD_TRY(td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, tmp_lpos, tmp_lv, S->lptr, N_l, B, S->h0, w.x4a,
-                             w.node_ptr, w.gid, w.lig_node, S->prot_node, s));
+                             w.node_ptr, w.gid, w.lig_node, prot_out, s));
+    if (S->chunked) {
+        S->prot_node = S->plan.prot_node;
+        TD_TRY(plan_layout(S->plan, w.node_ptr, w.gid, s));
+    }
     TD_TRY_HIP(hipMemcpyAsync(w.x4b, w.x4a, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
-    // protein-only graph, its gate rows, layer-0 projections / queries, layer-0 x2h output
-    TD_TRY_HIP(hipMemsetAsync(S->snbr, 0xff, n * TD_K * 4, s));
-    TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s, m->cfg.knn));
-    TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
+    if (!S->caching) {
+        *out = S;
+        return TD_OK;
+    }
+    // ---- protein-only graph, its gate rows, layer-0 projections / queries, layer-0 x2h output
+    GraphTab gt = session_tab(S);                  // the step's table (alpha is scratch here)
+    GraphTab st = gt;                              // the static table
+    st.nbr = S->snbr; st.ew = S->ews;
+    TD_TRY_HIP(hipMemsetAsync(S->snbr, 0xff, nc * TD_K * 4, s));
+    if (S->chunked) {
+        TD_TRY(td_launch_knn_general_static(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, N_p, m->cfg.knn, gmax, S->plan.cptr,
+                                            S->snbr, S->skeys, s));
+        TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, NC, nullptr, nullptr, S->ews, s, S->plan.chunk_node));
+        // the step's table: ligand rows start as all pads; hybrid: their ligand half never changes
+        TD_TRY_HIP(hipMemsetAsync(S->plan.cnbr, 0xff, nc * TD_K * 4, s));
+        TD_TRY_HIP(hipMemsetAsync(S->plan.ew, 0, nc * TD_K * 4, s));
+        if (m->cfg.cutoff_mode == TD_CUTOFF_HYBRID)
+            TD_TRY(td_launch_hybrid_ligand_half(w.node_ptr, S->pptr, w.gid, w.lig_node, N_l, S->plan.cptr, S->plan.cnbr, s));
+    } else {
+        TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s, m->cfg.knn));
+        TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
+    }
     const TdLayer &L0 = m->layers[0];
     TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
-    TD_TRY(key_pass(L0.hk, L0, w.x4a, S->snbr, S->ews, S->P0, S->q0, S->prot_node, nullptr, N_p, w.alpha, s));
+    TD_TRY(key_pass(L0.hk, L0, w.x4a, st, st.ew, st.nbr, S->P0, S->q0, S->prot_node, nullptr, N_p, gt.alpha, s));
     TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-    TD_TRY(value_pass(L0.hv, L0, w.x4a, S->snbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, w.alpha, nullptr, 0, s));
+    TD_TRY(value_pass(L0.hv, L0, w.x4a, st, st.nbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, gt.alpha, nullptr, 0, s));
     if (S->use_fwd) {      // layer-1 x2h output of the protein-only graph (valid wherever the ligand is two hops away)
         const TdLayer &L1 = m->layers[1];
         TD_TRY(td_launch_node_proj(L1.nodeX2h, S->h1s, N, nullptr, 0x1f, w.P, w.q, s));
-        TD_TRY(key_pass(L1.hk, L1, w.x4a, S->snbr, S->ews, w.P, w.q, S->prot_node, nullptr, N_p, w.alpha, s));
+        TD_TRY(key_pass(L1.hk, L1, w.x4a, st, st.ew, st.nbr, w.P, w.q, S->prot_node, nullptr, N_p, gt.alpha, s));
         TD_TRY_HIP(hipMemcpyAsync(S->h2s, S->h1s, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-        TD_TRY(value_pass(L1.hv, L1, w.x4a, S->snbr, w.P, S->prot_node, nullptr, N_p, S->h2s, w.alpha, nullptr, 0, s));
+        TD_TRY(value_pass(L1.hv, L1, w.x4a, st, st.nbr, w.P, S->prot_node, nullptr, N_p, S->h2s, gt.alpha, nullptr, 0, s));
     }
 #undef TD_TRY
 #undef TD_TRY_HIP
@@ -1473,9 +1501,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
 
 extern "C" void td_session_destroy(td_session *S) {
     if (!S) return;
-    if (S->general) plan_destroy(S->plan, nullptr);
-    if (S->block) (void)hipFree(S->block);
-    delete S;
+    session_free(S, S->last_stream);
 }
 
 extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, const int64_t *d_ligand_v,
@@ -1486,19 +1512,22 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         return TD_EINVAL;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    S->last_stream = s;
     const td_model *m = S->m;
     Workspace &w = S->w;
     const int64_t N = S->N, Nl = S->Nl, Np = S->Np;
+    const GraphTab gt = session_tab(S);
     int rc;
-    if (S->general) {
+    if (!S->caching) {
         {
             ProfScope ps(PC_COMPOSE, s);
             TD_CHECK_HIP(hipMemcpyAsync(w.h, S->h0, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
         }
         float4 *xg = nullptr;
-        if (default_graph(m->cfg)) rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s);      // 32-slot rows (radius, cap <= 32)
-        else rc = run_backbone_general(m, S->plan, w, w.h, N, Nl, 0, S->max_graph_nodes, &xg, s);
+        if (S->chunked) rc = build_general_graph(m, S->plan, w, N, Nl, S->max_graph_nodes, s);
+        else rc = build_default_graph(m, w, N, S->max_graph_nodes, s);          // 32-slot rows (radius, cap <= 32)
+        if (rc == TD_OK) rc = run_backbone(m, w, gt, w.h, N, Nl, 0, &xg, s, true);
         if (rc != TD_OK) return rc;
         ProfScope ps(PC_HEAD, s);
         return td_launch_head(m->head, w.h, xg, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
@@ -1508,7 +1537,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         // first kernel of the step: also zeroes the row-list counters and the ligand rows' forward-reach flags
         ProfScope ps(PC_COMPOSE, s);
         TdStepReset rs;
-        rs.c0 = S->dirty_count; rs.n0 = 1;
+        rs.c0 = S->dirty_count; rs.n0 = 2;
         rs.c1 = S->fwd_counts; rs.n1 = 2;
         rs.c2 = S->hop_count; rs.n2 = TD_HOP_LEVELS;
         rs.flags2 = S->use_fwd ? S->flags2 : nullptr;
@@ -1517,44 +1546,65 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     bool lists_done = false;
     {
         ProfScope ps(PC_KNN, s);
-        if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
-                                      S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
-        if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc;
-        // every row list of the step (dirty rows, forward reach, receptive-field levels) in one launch, one workgroup per graph;
-        // graphs too large for its LDS flags take the separate kernels
         const TdStepLists lists{S->dirty_rows, S->dirty_count, S->use_fwd ? S->fwd_rows : nullptr, S->fwd_rest, S->fwd_counts,
-                                S->hop_rows, S->hop_count, S->hop_levels};
-        rc = (m->opt.session_step_lists && S->graph_nodes_max > 0) ? td_launch_step_lists(S->clean, w.x4a, w.nbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s)
-                                    : TD_EINVAL;
-        lists_done = rc == TD_OK;
-        if (rc != TD_OK && rc != TD_EINVAL) return rc;
-        if (!lists_done) {
-            if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
-            // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
-            // clears it; without the forward reach a memset does
-            if (S->use_fwd) {
-                if ((rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest, S->fwd_counts,
-                                                  S->clean, s)) != TD_OK) return rc;
-            } else {
-                TD_CHECK_HIP(hipMemsetAsync(S->clean, 0, (size_t)N, s));
+                                S->hop_rows, S->hop_count, S->hop_levels, S->chunked ? S->dirty_chunks : nullptr,
+                                S->chunked ? S->dirty_count + 1 : nullptr};
+        if (S->chunked) {
+            const GraphPlan &p = S->plan;
+            if ((rc = td_launch_knn_merge_general(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
+                                                  S->h1s, S->ews, p.cptr, p.cpn_p, p.cnbr, w.h, p.ew, S->clean,
+                                                  S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
+            if ((rc = td_launch_ligand_rows_general(p.mode, w.x4a, w.node_ptr, S->pptr, w.gid, w.lig_node, Nl, p.k, S->graph_nodes_max,
+                                                    p.cptr, p.cnbr, s)) != TD_OK) return rc;
+            // every row list of the step in one launch (the session is CACHING only when every graph fits its LDS flags)
+            if ((rc = td_launch_step_lists(S->clean, w.x4a, p.cnbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s, p.cptr,
+                                           p.chunk_node)) != TD_OK) {
+                if (rc == TD_EINVAL) td_set_error("td_session_forward: a graph of %d nodes does not fit the row-list kernel", S->graph_nodes_max);
+                return rc;
+            }
+            lists_done = true;
+        } else {
+            if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
+                                          S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
+            if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc;
+            // every row list of the step (dirty rows, forward reach, receptive-field levels) in one launch, one workgroup per graph;
+            // graphs too large for its LDS flags take the separate kernels
+            rc = (m->opt.session_step_lists && S->graph_nodes_max > 0) ? td_launch_step_lists(S->clean, w.x4a, w.nbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s)
+                                        : TD_EINVAL;
+            lists_done = rc == TD_OK;
+            if (rc != TD_OK && rc != TD_EINVAL) return rc;
+            if (!lists_done) {
+                if ((rc = td_launch_compact_dirty(S->clean, w.x4a, N, S->dirty_rows, S->dirty_count, s)) != TD_OK) return rc;
+                // S->clean gets its second life as the receptive-field flags below: the forward-reach compaction (its last reader)
+                // clears it; without the forward reach a memset does
+                if (S->use_fwd) {
+                    if ((rc = td_launch_forward_reach(S->clean, w.x4a, w.nbr, N, S->flags2, S->fwd_rows, S->fwd_rest, S->fwd_counts,
+                                                      S->clean, s)) != TD_OK) return rc;
+                } else {
+                    TD_CHECK_HIP(hipMemsetAsync(S->clean, 0, (size_t)N, s));
+                }
             }
         }
     }
     {
         ProfScope ps(PC_GATE, s);
-        if ((rc = td_launch_gate(m->gate, w.x4a, w.nbr, N, S->dirty_rows, S->dirty_count, w.ew, s)) != TD_OK) return rc;
+        if (S->chunked)
+            rc = td_launch_gate(m->gate, w.x4a, gt.nbr, S->plan.NC, S->dirty_chunks, S->dirty_count + 1, gt.ew, s, S->plan.chunk_node);
+        else
+            rc = td_launch_gate(m->gate, w.x4a, gt.nbr, N, S->dirty_rows, S->dirty_count, gt.ew, s);
+        if (rc != TD_OK) return rc;
     }
     const TdLayer &L0 = m->layers[0];
     {   // layer 0, x2h: only ligand rows need new projections, only dirty rows need the attention passes
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L0.nodeX2h, w.h, Nl, w.lig_node, 0x1f, S->P0, S->q0, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, w.nbr, w.ew, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, w.alpha, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, w.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, w.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, gt, gt.ew, gt.nbr, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, gt.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, gt, gt.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, gt.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
     if (!lists_done && (rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;
     float4 *xf = nullptr;
     const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s};
-    if ((rc = run_backbone(m, w, w.h, N, Nl, 0, S->max_graph_nodes, &xf, s, true, true, S->hop_rows, S->hop_count, S->hop_levels,
+    if ((rc = run_backbone(m, w, gt, w.h, N, Nl, 0, &xf, s, false, true, S->hop_rows, S->hop_count, S->hop_levels,
                            S->use_fwd ? &fwd : nullptr)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
@@ -1565,7 +1615,7 @@ extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_
     if (!S || !host_counts || n_counts < 2) { td_set_error("td_session_row_counts: bad argument"); return TD_EINVAL; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     host_counts[0] = (int32_t)S->N;
-    if (S->general) {            // every layer runs on every row
+    if (!S->caching) {            // every layer runs on every row
         host_counts[1] = (int32_t)S->N;
         for (int k = 2; k < n_counts; ++k) host_counts[k] = -1;
         return TD_OK;

@@ -42,12 +42,16 @@ struct Args16 {
     const float *offsets;
     float coeff;
     int p_off;
-    // general graphs (ragged kernels only): the in-edges of node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha
+    // general graphs: the in-edges of node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha (nullptr: chunk == node)
     const int32_t *chunk_node;
     const int32_t *cptr;
     // value pass with the bf16 first layer: the ligand rows (all of them are in the row list)
     const int32_t *lig_rows;
     int64_t lig_count;
+    // general graphs, value pass: chunks per protein row and the chunks of all ligand rows together (the class split is sized
+    // from the chunk counts: a hybrid ligand row has several times the chunks of a protein row)
+    int cpn_p;
+    int64_t lig_chunks;
 };
 
 // contiguous share of `count` rows for block b of a (sub-)grid of G blocks
@@ -360,10 +364,14 @@ constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_
 //             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
 //             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
 // STAGE only tags the instantiation (0 = x2h, 1 = h2x) so that profilers report the two stages separately.
-// RAW = true (general graphs): `it` walks chunks, the dst node comes from chunk_node, and the scaled logits are stored as they
-//             are (-inf on pads): the softmax over all chunks of a node happens in the ragged value / xv kernels.
+// CHUNKED = true (general graphs): the in-edges of dst node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha (32
+//             slots each, -1 padded).  One wave still owns one dst node and walks its chunks.  Key pass: the softmax runs
+//             over ALL slots of the node (scatter_softmax over an arbitrary segment, models/uni_transformer.py:73,135) --
+//             one chunk: in registers as on the default graph; several: the scaled logits go to alpha[c] with a running
+//             (max, sum) per head, then every lane re-reads its own entries and writes exp(x - max) / sum * gate.
+//             XV: delta_x accumulates over the chunks (scatter_sum, :139).
 // SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
-template <bool XV, int WAVES, int STAGE, bool RAW = false, bool SPLIT = false>
+template <bool XV, int WAVES, int STAGE, bool CHUNKED = false, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? E16P_U4 * 4 : E16_R_FLOATS;       // floats of the radial/type table
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
@@ -391,93 +399,153 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
 
-    for (int64_t it = begin + wid; it < end; it += WAVES) {
-        const int64_t c = a.rows ? (int64_t)a.rows[it] : it;          // row of nbr / ew / alpha: a node, or (RAW) a chunk
-        const int64_t i = RAW ? (int64_t)a.chunk_node[c] : c;          // its dst node
-        floatx4_t acc[2][8];
-        Edge2 ed;
+    // first layer of chunk c of dst node i: z^T in acc
+    auto first_layer = [&](int64_t i, int64_t c, floatx4_t (&acc)[2][8], Edge2 &ed) {
+        constexpr bool EW = !XV && !CHUNKED;       // the chunked key pass fetches the gate in its second sweep
         if constexpr (SPLIT) {
             RowIn16 rin;
             td_row_index16(a, i, c, lane, rin);
-            td_row_gather16<!XV && !RAW>(a, i, c, lane, rin, acc);
-            td_first_layer_split16<!XV && !RAW, false, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+            td_row_gather16<EW>(a, i, c, lane, rin, acc);
+            td_first_layer_split16<EW, false, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
         } else
-            td_first_layer16<!XV && !RAW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+            td_first_layer16<EW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+    };
+
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;           // dst node
+        int64_t c0 = i;
+        int nch = 1;
+        if (CHUNKED) {
+            c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]);
+            nch = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]) - (int)c0;
+        }
 
         if (XV) {
             const float *Wx = lds + RF;                 // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
-            floatx4_t xv[2];
             const float b2 = a.mlp.b2[lo];
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            float4 xi_keep = a.x4[i];
+            for (int64_t c = c0; c < c0 + nch; ++c) {
+                floatx4_t acc[2][8];
+                Edge2 ed;
+                first_layer(i, c, acc, ed);
+                floatx4_t xv[2];
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+                for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int hb = 0; hb < 8; ++hb)
+                for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float u = Wx[(hb * 4 + r) * 64 + lane];
+                        xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
+                        xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                    }
+                // xv[eb][r] = xv of edge 16eb + lo, head 4g + r (bias: b2 of that head, fetched through the head's lane)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float u = Wx[(hb * 4 + r) * 64 + lane];
-                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
-                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
-                }
-            // xv[eb][r] = xv of edge 16eb + lo, head 4g + r (bias: b2 of that head, fetched through the head's lane)
-            float sx = 0.f, sy = 0.f, sz = 0.f;
+                    const float bias = __shfl(b2, 4 * g + r);
+                    const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float bias = __shfl(b2, 4 * g + r);
-                const float *ap = a.alpha + ((size_t)i * TD_HEADS + 4 * g + r) * TD_K + lo;
-#pragma unroll
-                for (int eb = 0; eb < 2; ++eb) {
-                    const float wgt = ed.valid[eb] ? ap[16 * eb] * (xv[eb][r] + bias) : 0.f;
-                    sx = fmaf(wgt, ed.rel[eb][0], sx);
-                    sy = fmaf(wgt, ed.rel[eb][1], sy);
-                    sz = fmaf(wgt, ed.rel[eb][2], sz);
+                    for (int eb = 0; eb < 2; ++eb) {
+                        const float wgt = ed.valid[eb] ? ap[16 * eb] * (xv[eb][r] + bias) : 0.f;
+                        sx = fmaf(wgt, ed.rel[eb][0], sx);
+                        sy = fmaf(wgt, ed.rel[eb][1], sy);
+                        sz = fmaf(wgt, ed.rel[eb][2], sz);
+                    }
                 }
             }
             sx = td_sum64(sx) * (1.0f / TD_HEADS);
             sy = td_sum64(sy) * (1.0f / TD_HEADS);
             sz = td_sum64(sz) * (1.0f / TD_HEADS);
-            if (lane == 0) a.x4_out[i] = make_float4(ed.xi.x + sx, ed.xi.y + sy, ed.xi.z + sz, ed.xi.w);
+            if (lane == 0) a.x4_out[i] = make_float4(xi_keep.x + sx, xi_keep.y + sy, xi_keep.z + sz, xi_keep.w);
             continue;
         }
 
         // ---- logits^T[head][edge] = sum_k U_i[k][head] z[k][edge];  A = U_i built from q_i: lane (head lo, group g) ----
-        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
-        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
-        floatx4_t lg[2];
+        auto logits = [&](const floatx4_t (&acc)[2][8], floatx4_t (&lg)[2]) {
+            // fetched after the first layer: eight fewer live registers while it runs
+            const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+            const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int hb = 0; hb < 8; ++hb)
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
+                    const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+                    float u = w0.x * q0.x;
+                    u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                    u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                    lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
+                    lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+                }
+        };
+
+        if (!CHUNKED || nch == 1) {
+            floatx4_t acc[2][8], lg[2];
+            Edge2 ed;
+            first_layer(i, c0, acc, ed);
+            logits(acc, lg);
+            if (CHUNKED) {
+                ed.ew[0] = a.ew[c0 * TD_K + lo];
+                ed.ew[1] = a.ew[c0 * TD_K + 16 + lo];
+            }
+            // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate ---------------------
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
-                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
-                float u = w0.x * q0.x;
-                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
-                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
-                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+                float mx = td_max16(fmaxf(x0, x1));
+                if (mx == -INFINITY) mx = 0.f;
+                const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
+                const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
+                const float sm = td_sum16(p0 + p1);
+                const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
+                float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
+                dst[0] = p0 * inv * ed.ew[0];
+                dst[16] = p1 * inv * ed.ew[1];
             }
+            continue;
+        }
 
-        // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate -------------------------
+        // ---- several chunks: sweep 1 stores the scaled logits and keeps a running (max, sum) per head ---------------------
+        float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, srun[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t c = c0; c < c0 + nch; ++c) {
+            floatx4_t acc[2][8], lg[2];
+            Edge2 ed;
+            first_layer(i, c, acc, ed);
+            logits(acc, lg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-            const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
-            if (RAW) {
+            for (int r = 0; r < 4; ++r) {
+                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
                 float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
                 dst[0] = x0;
                 dst[16] = x1;
-                continue;
+                const float mn = fmaxf(mrun[r], td_max16(fmaxf(x0, x1)));
+                if (mn != -INFINITY) {                    // wave-uniform per row of 16 lanes; exp(-inf - mn) = 0 on the first hit
+                    srun[r] = srun[r] * __expf(mrun[r] - mn) + td_sum16(__expf(x0 - mn) + __expf(x1 - mn));
+                    mrun[r] = mn;
+                }
             }
-            float mx = td_max16(fmaxf(x0, x1));
-            if (mx == -INFINITY) mx = 0.f;
-            const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
-            const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
-            const float sm = td_sum16(p0 + p1);
-            const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
-            float *dst = a.alpha + ((size_t)i * TD_HEADS + 4 * g + r) * TD_K + lo;
-            dst[0] = p0 * inv * ed.ew[0];
-            dst[16] = p1 * inv * ed.ew[1];
+        }
+        float inv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            inv[r] = srun[r] > 0.f ? __frcp_rn(srun[r]) : 0.f;
+            if (mrun[r] == -INFINITY) mrun[r] = 0.f;
+        }
+        // ---- sweep 2: every lane re-reads the entries it wrote (same thread, same addresses) and normalises them -----------
+        for (int64_t c = c0; c < c0 + nch; ++c) {
+            const float ew0 = a.ew[c * TD_K + lo], ew1 = a.ew[c * TD_K + 16 + lo];       // 0 on pads
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                const float x0 = dst[0], x1 = dst[16];
+                dst[0] = __expf(x0 - mrun[r]) * inv[r] * ew0;
+                dst[16] = __expf(x1 - mrun[r]) * inv[r] * ew1;
+            }
         }
     }
 }
@@ -646,7 +714,9 @@ constexpr size_t V16S_LDS_BYTES =
 // its first layer).
 // A wave looks at 64 candidate rows at a time (lane t reads the class of candidate t) and walks the ones of its class.
 constexpr int TD_LIG_ROW_COST_X4 = 5;      // 1.25, in quarters (measured: 8.7 us against 7.0 us per row and wave at C2)
-template <bool SPLIT>
+// CHUNKED = true (general graphs): a dst node's in-edges are the chunks cptr[i] .. cptr[i+1]-1; alpha (already normalised over
+// the whole node and gated by the key pass) is indexed by chunk; Zbar accumulates over the chunks, then one output product.
+template <bool SPLIT, bool CHUNKED = false>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
@@ -666,7 +736,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         n_rows = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
         const int64_t G = gridDim.x, nl = a.lig_count, np = n_rows > nl ? n_rows - nl : 0;
         if (nl > 0) {
-            const int64_t wl = TD_LIG_ROW_COST_X4 * nl, wp = 4 * np;
+            const int64_t wl = TD_LIG_ROW_COST_X4 * (CHUNKED ? a.lig_chunks : nl), wp = 4 * (CHUNKED ? np * a.cpn_p : np);
             GL = (int)((wl * G + (wl + wp) / 2) / (wl + wp));
             const int cap = (int)G - (np > 0 ? 1 : 0);
             GL = GL < 1 ? 1 : (GL > cap ? cap : GL);
@@ -742,6 +812,75 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         h0 = a.h[(size_t)ix * TD_H + lane];
         h1 = a.h[(size_t)ix * TD_H + 64 + lane];
     };
+    if constexpr (CHUNKED) {
+        for (int64_t i = next_row(); i >= 0; i = next_row()) {
+            const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
+            const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
+            floatx4_t zb[8];
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            float asum = 0.f;
+            for (int c = c0; c < c1; ++c) {
+                RowIn16 rin;
+                floatx4_t acc[2][8];
+                Edge2 ed;
+                td_row_index16(a, i, c, lane, rin);
+                td_row_gather16<false>(a, i, c, lane, rin, acc);
+                float al[8];
+                {   // A operand of the aggregation product: alpha[edge 8g + s][head lo] of this chunk
+                    const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+                    al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
+                }
+                if constexpr (SPLIT)
+                    td_first_layer_split16<false, true, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+                else
+                    td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+                asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
+                auto flip_store = [&](int hb) {
+                    float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+#pragma unroll
+                    for (int eb = 0; eb < 2; ++eb)
+                        *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                            make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+                };
+                flip_store(0);
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb) {
+                    if (hb + 1 < 8) flip_store(hb + 1);
+                    const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+                    float bv[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
+                }
+            }
+            const float ssum = td_sum_groups(asum);
+            if (lane < TD_HEADS) SB[lane] = ssum;
+            float *ZB = TB;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                if ((g >> 1) == ph) {
+#pragma unroll
+                    for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
+                }
+                const int n = 64 * ph + lane;
+                const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
+                float o = B2[n] * SB[8 * ph + (lane >> 3)];
+#pragma unroll 8
+                for (int kq = 0; kq < 32; ++kq) {
+                    const float4 w = Wv[kq * TD_H + n];
+                    const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
+                    o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
+                }
+                a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+            }
+        }
+        return;
+    }
     int64_t i = next_row();
     RowIn16 rin;
     floatx4_t acc[2][8];
@@ -921,217 +1060,6 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
     }
 }
 
-// ================================================================================================ general graphs
-// Rows that are not exactly 32 wide (k-NN with k != 32, `hybrid`, radius with a fan-out cap): the in-edges of node i are
-// the chunks cptr[i] .. cptr[i+1]-1 of 32 slots (-1 padded; graph.hip).  The per-chunk arithmetic is the one above; what
-// changes is the softmax over ALL slots of a node, so the passes split differently:
-//   * edge_key16_kernel<RAW> one wave per chunk: first layer -> z, logits = z . U_i, scaled logits to alpha[c] (-inf on pads)
-//   * edge_value16_ragged    one wave per node: max / sum of its logits, then per chunk alpha = softmax * gate,
-//                            Zbar += alpha^T z across the chunks, one output product W2v . Zbar, residual
-//   * edge_xv16_ragged       one wave per ligand node: same statistics, delta_x accumulated over the chunks
-// (scatter_softmax / scatter_sum over arbitrary segments, models/uni_transformer.py:73,78,135,139).
-__global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_ragged_kernel(Args16 a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wv = reinterpret_cast<const float4 *>(lds + E16_R_FLOATS);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int lo = lane & 15, g = lane >> 4;
-    float *TB = lds + E16_R_FLOATS + V16_W_FLOATS + wid * V16_WAVE_FLOATS;
-    float *SB = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
-    float *B2 = lds + E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
-    const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
-    {
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, V16_WAVES * 64);
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), V16_W_FLOATS / 4, tid,
-                       V16_WAVES * 64);
-        if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
-        else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
-        else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
-    }
-    float offk[E16_STEPS];
-#pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
-    __syncthreads();
-    int64_t begin, end;
-    td_node_range16(a.count, a.count_ptr, begin, end);
-    // the 8 logits a lane owns in a chunk: head lo, slots 8g .. 8g + 7 (the A-operand layout of the aggregation product)
-    auto load8 = [&](const float *base, int64_t c, float (&v)[8]) {
-        const float *ap = base + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
-        const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    };
-    for (int64_t it = begin + wid; it < end; it += V16_WAVES) {
-        const int64_t i = __builtin_amdgcn_readfirstlane(a.rows ? a.rows[it] : (int32_t)it);
-        const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
-        float xs[8];
-        float m = -INFINITY;
-        for (int c = c0; c < c1; ++c) {
-            load8(a.alpha, c, xs);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) m = fmaxf(m, xs[s]);
-        }
-        m = td_max_groups(m);
-        if (m == -INFINITY) m = 0.f;
-        float den = 0.f;
-        for (int c = c0; c < c1; ++c) {
-            load8(a.alpha, c, xs);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) den += __expf(xs[s] - m);
-        }
-        den = td_sum_groups(den);
-        const float inv = den > 0.f ? __frcp_rn(den) : 0.f;
-        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
-
-        floatx4_t zb[8];
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-        float asum = 0.f;
-        for (int c = c0; c < c1; ++c) {
-            RowIn16 rin;
-            floatx4_t acc[2][8];
-            Edge2 ed;
-            td_row_index16(a, i, c, lane, rin);
-            td_row_gather16<false>(a, i, c, lane, rin, acc);
-            td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
-            float al[8];
-            load8(a.alpha, c, xs);
-            {
-                const float *ep = a.ew + (size_t)c * TD_K + 8 * g;        // gate of slots 8g .. 8g + 7 (0 on pads)
-                const float4 e0 = *reinterpret_cast<const float4 *>(ep), e1 = *reinterpret_cast<const float4 *>(ep + 4);
-                const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    al[s] = (__expf(xs[s] - m) * inv) * ev[s];
-                    asum += al[s];
-                }
-            }
-            auto flip_store = [&](int hb) {
-                float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
-#pragma unroll
-                for (int eb = 0; eb < 2; ++eb)
-                    *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
-                        make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
-            };
-            flip_store(0);
-#pragma unroll
-            for (int hb = 0; hb < 8; ++hb) {
-                if (hb + 1 < 8) flip_store(hb + 1);
-                const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
-                float bv[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
-            }
-        }
-        const float ssum = td_sum_groups(asum);
-        if (lane < TD_HEADS) SB[lane] = ssum;
-        float *ZB = TB;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            if ((g >> 1) == ph) {
-#pragma unroll
-                for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
-            }
-            const int n = 64 * ph + lane;
-            const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
-            float o = B2[n] * SB[8 * ph + (lane >> 3)];
-#pragma unroll 8
-            for (int kq = 0; kq < 32; ++kq) {
-                const float4 w = Wv[kq * TD_H + n];
-                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
-            }
-            a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
-        }
-    }
-}
-
-__global__ __launch_bounds__(XV16_WAVES * 64) void edge_xv16_ragged_kernel(Args16 a) {
-    constexpr int WAVES = XV16_WAVES;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float *Wx = lds + E16_R_FLOATS;                     // [hb][r][lane]: W2xv[head lo][16hb + 4g + r]
-    const float *GAM = lds + E16_R_FLOATS + E16_WQ_FLOATS, *BET = GAM + TD_H;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int lo = lane & 15, g = lane >> 4;
-    td_stage_tables16<WAVES>(lds, a.mlp, 8 * 4 * 64 / 4, tid);
-    float offk[E16_STEPS];
-#pragma unroll
-    for (int s = 0; s < E16_STEPS; ++s) offk[s] = (4 * s + g) < TD_NG ? a.offsets[4 * s + g] : 0.f;
-    const float b2 = a.mlp.b2[lo];
-    __syncthreads();
-    int64_t begin, end;
-    td_node_range16(a.count, a.count_ptr, begin, end);
-    for (int64_t it = begin + wid; it < end; it += WAVES) {
-        const int64_t i = __builtin_amdgcn_readfirstlane(a.rows ? a.rows[it] : (int32_t)it);
-        const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
-        // softmax statistics of heads 4g .. 4g + 3 over every slot of the node
-        float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, inv[4];
-        for (int c = c0; c < c1; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
-                m[r] = fmaxf(m[r], fmaxf(ap[0], ap[16]));
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            m[r] = td_max16(m[r]);
-            if (m[r] == -INFINITY) m[r] = 0.f;
-            inv[r] = 0.f;
-        }
-        for (int c = c0; c < c1; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
-                inv[r] += __expf(ap[0] - m[r]) + __expf(ap[16] - m[r]);
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float sm = td_sum16(inv[r]);
-            inv[r] = sm > 0.f ? __frcp_rn(sm) : 0.f;
-        }
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        float4 xi_keep = a.x4[i];
-        for (int c = c0; c < c1; ++c) {
-            floatx4_t acc[2][8];
-            Edge2 ed;
-            td_first_layer16<false>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
-            floatx4_t xv[2];
-#pragma unroll
-            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float u = Wx[(hb * 4 + r) * 64 + lane];
-                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
-                    xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
-                }
-            const float ew0 = a.ew[(size_t)c * TD_K + lo], ew1 = a.ew[(size_t)c * TD_K + 16 + lo];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float bias = __shfl(b2, 4 * g + r);
-                const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
-#pragma unroll
-                for (int eb = 0; eb < 2; ++eb) {
-                    const float al = (__expf(ap[16 * eb] - m[r]) * inv[r]) * (eb == 0 ? ew0 : ew1);
-                    const float wgt = ed.valid[eb] ? al * (xv[eb][r] + bias) : 0.f;
-                    sx = fmaf(wgt, ed.rel[eb][0], sx);
-                    sy = fmaf(wgt, ed.rel[eb][1], sy);
-                    sz = fmaf(wgt, ed.rel[eb][2], sz);
-                }
-            }
-        }
-        sx = td_sum64(sx) * (1.0f / TD_HEADS);
-        sy = td_sum64(sy) * (1.0f / TD_HEADS);
-        sz = td_sum64(sz) * (1.0f / TD_HEADS);
-        if (lane == 0) a.x4_out[i] = make_float4(xi_keep.x + sx, xi_keep.y + sy, xi_keep.z + sz, xi_keep.w);
-    }
-}
-
 // ================================================================================================ launchers
 // Workgroups of a row-loop kernel: one per CU (256) when there is a row per wave for all of them.  With fewer rows the
 // waves of a workgroup would queue on their SIMD's shared matrix / vector pipe while other CUs idle, so small launches
@@ -1146,76 +1074,85 @@ static int grid16(int64_t count, int waves) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                         float *alpha, hipStream_t s) {
+                         float *alpha, hipStream_t s, const int32_t *cptr) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    a.cptr = cptr;
     const bool h2x = rows && !count_ptr;      // h2x key pass (ligand row list of known length): STAGE tag 1
+#define TD_KEY_LAUNCH(WAVES, STAGE, CH, SP, BYTES)                                                            \
+    do {                                                                                                      \
+        TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
+        edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
+    } while (0)
     if (mlp.use_split) {                      // first layer on bf16 piece triples
-        const dim3 grid(grid16(count, K16S_WAVES)), block(K16S_WAVES * 64);
-        if (h2x) {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, false, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 1, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
-        } else {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, false, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 0, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
-        }
+        if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, true, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, true, true, K16S_LDS_BYTES); }
+        else { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, false, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, false, true, K16S_LDS_BYTES); }
     } else {
-        const dim3 grid(grid16(count, K16_WAVES)), block(K16_WAVES * 64);
-        if (h2x) {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 1>), K16_LDS_BYTES);
-            edge_key16_kernel<false, K16_WAVES, 1><<<grid, block, K16_LDS_BYTES, s>>>(a);
-        } else {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 0>), K16_LDS_BYTES);
-            edge_key16_kernel<false, K16_WAVES, 0><<<grid, block, K16_LDS_BYTES, s>>>(a);
-        }
+        if (cptr) { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, true, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, true, false, K16_LDS_BYTES); }
+        else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, false, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, false, false, K16_LDS_BYTES); }
     }
+#undef TD_KEY_LAUNCH
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
 // h2x value pass (xv MLP + coordinate update) on the listed ligand rows; reads alpha written by the h2x key pass.
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
-                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s) {
+                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s,
+                        const int32_t *cptr) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4_in; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
-    a.coeff = L.coeff; a.p_off = 2 * TD_H;
+    a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr;
     const dim3 grid(grid16(count, XV16_WAVES)), block(XV16_WAVES * 64);
-    if (mlp.use_split) {
-        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, false, true>), K16S_LDS_BYTES);
-        edge_key16_kernel<true, XV16_WAVES, 1, false, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
-    } else {
-        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1>), K16_LDS_BYTES);
-        edge_key16_kernel<true, XV16_WAVES, 1><<<grid, block, K16_LDS_BYTES, s>>>(a);
-    }
+#define TD_XV_LAUNCH(CH, SP, BYTES)                                                            \
+    do {                                                                                       \
+        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, CH, SP>), BYTES);                  \
+        edge_key16_kernel<true, XV16_WAVES, 1, CH, SP><<<grid, block, BYTES, s>>>(a);          \
+    } while (0)
+    if (mlp.use_split) { if (cptr) TD_XV_LAUNCH(true, true, K16S_LDS_BYTES); else TD_XV_LAUNCH(false, true, K16S_LDS_BYTES); }
+    else { if (cptr) TD_XV_LAUNCH(true, false, K16_LDS_BYTES); else TD_XV_LAUNCH(false, false, K16_LDS_BYTES); }
+#undef TD_XV_LAUNCH
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
 
 // lig_rows / lig_count: the ligand rows among `rows` (all of them: every row list of a forward pass or sampling step holds
-// the ligand atoms); nullptr / 0 for a list without ligand rows.
+// the ligand atoms); nullptr / 0 for a list without ligand rows.  General graphs: cptr, the chunks per protein row and the
+// chunks of all ligand rows together (the class split of the bf16 kernel is sized from chunk counts).
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
-                           const int32_t *lig_rows, int64_t lig_count, hipStream_t s) {
+                           const int32_t *lig_rows, int64_t lig_count, hipStream_t s, const int32_t *cptr, int cpn_p,
+                           int64_t lig_chunks) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
-    a.coeff = L.coeff; a.p_off = 2 * TD_H;
+    a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr; a.cpn_p = cpn_p > 0 ? cpn_p : 1; a.lig_chunks = lig_chunks;
     int G = grid16(count, V16_WAVES);
+    const dim3 block(V16_WAVES * 64);
     if (mlp.use_split) {
-        TD_LDS_ONCE((edge_value16_kernel<true>), V16S_LDS_BYTES);
         a.lig_rows = lig_rows; a.lig_count = lig_rows ? lig_count : 0;
         if (G < 2 && a.lig_count > 0) G = 2;       // a workgroup for each destination class
-        edge_value16_kernel<true><<<dim3(G), dim3(V16_WAVES * 64), V16S_LDS_BYTES, s>>>(a);
+        if (cptr) {
+            TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+        } else {
+            TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+        }
+    } else if (cptr) {
+        TD_LDS_ONCE((edge_value16_kernel<false, true>), V16_LDS_BYTES);
+        edge_value16_kernel<false, true><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);
     } else {
-        TD_LDS_ONCE((edge_value16_kernel<false>), V16_LDS_BYTES);
-        edge_value16_kernel<false><<<dim3(G), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
+        TD_LDS_ONCE((edge_value16_kernel<false, false>), V16_LDS_BYTES);
+        edge_value16_kernel<false, false><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);
     }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
@@ -1239,62 +1176,6 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
         TD_LDS_ONCE((edge_h2x16_kernel<false>), h2x16_lds_bytes<false>());
         edge_h2x16_kernel<false><<<grid, block, h2x16_lds_bytes<false>(), s>>>(ar);
     }
-    TD_CHECK_HIP(hipGetLastError());
-    return TD_OK;
-}
-
-// ---- general graphs: chunk-indexed nbr / ew / alpha (see the ragged kernels above) --------------------------------
-
-// stage 0: x2h keys, 1: h2x keys.  `chunks`: optional list of chunk ids (count = its length), else all NC chunks.
-int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr,
-                            const float *P, const float *q, const int32_t *chunk_node, const int32_t *chunks, int64_t count,
-                            float *alpha, hipStream_t s) {
-    if (count == 0) return TD_OK;
-    Args16 a = {};
-    a.x4 = x4; a.nbr = cnbr; a.P = P; a.q = q; a.rows = chunks; a.alpha = alpha; a.count = count; a.mlp = mlp;
-    a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0; a.chunk_node = chunk_node;
-    if (mlp.use_split) {
-        const dim3 grid(grid16(count, K16S_WAVES)), block(K16S_WAVES * 64);
-        if (stage == 0) {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, true, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 0, true, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
-        } else {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, true, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 1, true, true><<<grid, block, K16S_LDS_BYTES, s>>>(a);
-        }
-    } else if (stage == 0) {
-        TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 0, true>), K16_LDS_BYTES);
-        edge_key16_kernel<false, K16_WAVES, 0, true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
-    } else {
-        TD_LDS_ONCE((edge_key16_kernel<false, K16_WAVES, 1, true>), K16_LDS_BYTES);
-        edge_key16_kernel<false, K16_WAVES, 1, true><<<dim3(grid16(count, K16_WAVES)), dim3(K16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
-    }
-    TD_CHECK_HIP(hipGetLastError());
-    return TD_OK;
-}
-
-int td_launch_edge_value16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr, const float *ew,
-                                  const float *P, const int32_t *cptr, const int32_t *rows, int64_t count, float *h,
-                                  const float *alpha, hipStream_t s) {
-    if (count == 0) return TD_OK;
-    TD_LDS_ONCE((edge_value16_ragged_kernel), V16_LDS_BYTES);
-    Args16 a = {};
-    a.x4 = x4; a.nbr = cnbr; a.ew = ew; a.P = P; a.rows = rows; a.h = h; a.alpha = const_cast<float *>(alpha); a.count = count;
-    a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr;
-    edge_value16_ragged_kernel<<<dim3(grid16(count, V16_WAVES)), dim3(V16_WAVES * 64), V16_LDS_BYTES, s>>>(a);
-    TD_CHECK_HIP(hipGetLastError());
-    return TD_OK;
-}
-
-int td_launch_edge_xv16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *cnbr,
-                               const float *ew, const float *P, const int32_t *cptr, const int32_t *rows, int64_t count,
-                               const float *alpha, hipStream_t s) {
-    if (count == 0) return TD_OK;
-    TD_LDS_ONCE((edge_xv16_ragged_kernel), K16_LDS_BYTES);
-    Args16 a = {};
-    a.x4 = x4_in; a.nbr = cnbr; a.ew = ew; a.P = P; a.rows = rows; a.alpha = const_cast<float *>(alpha); a.x4_out = x4_out;
-    a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr;
-    edge_xv16_ragged_kernel<<<dim3(grid16(count, XV16_WAVES)), dim3(XV16_WAVES * 64), K16_LDS_BYTES, s>>>(a);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

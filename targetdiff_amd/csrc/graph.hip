@@ -299,6 +299,91 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
     return TD_OK;
 }
 
+// The same merge on general graphs (k-NN with 32 < k <= 64, and the protein rows of `hybrid`): 64 sorted static keys per
+// protein row (one per lane), neighbour table / gate rows indexed by chunk (cpn chunks of 32 slots per protein row, contiguous
+// from chunk cptr[i]).  Clean rows copy their cached chunks; the others are merged with the graph's ligand atoms, k rounds.
+__global__ __launch_bounds__(256) void knn_merge_general_kernel(
+    const float4 *__restrict__ x4, const int32_t *__restrict__ ptr, const int32_t *__restrict__ pptr,
+    const int32_t *__restrict__ gid, const int32_t *__restrict__ prot_rows, int64_t Np,
+    const unsigned long long *__restrict__ skeys, const int32_t *__restrict__ snbr, const float *__restrict__ h0,
+    const float *__restrict__ h1s, const float *__restrict__ ews, const int32_t *__restrict__ cptr, int cpn,
+    int32_t *__restrict__ nbr, float *__restrict__ h, float *__restrict__ ew, uint8_t *__restrict__ clean,
+    uint8_t *__restrict__ flags2, int k) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= Np) return;
+    const int64_t i = prot_rows[qi];
+    const int g = gid[i];
+    const int lbeg = ptr[g] + (pptr[g + 1] - pptr[g]), lend = ptr[g + 1];
+    const float4 xi = x4[i];
+    const int64_t c0 = cptr[i];
+    const unsigned long long ks = skeys[i * 64 + lane];
+    const unsigned long long thr = __shfl(ks, k - 1);             // k-th static neighbour (MAX if fewer exist)
+    bool closer = false;
+    for (int base = lbeg; base < lend; base += 64) {
+        const int j = base + lane;
+        if (j < lend) {
+            const float4 xj = x4[j];
+            const float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+            closer |= (((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j) < thr;
+        }
+    }
+    bool is_clean = __ballot(closer) == 0ull;
+    if (!is_clean) {
+        unsigned long long best = ks;
+        for (int base = lbeg; base < lend; base += 128) {
+            unsigned long long kl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = base + lane + 64 * u;
+                kl[u] = TD_KEY_MAX;
+                if (j < lend) {
+                    const float4 xj = x4[j];
+                    const float d2 = td_dist2(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z);
+                    kl[u] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)j;
+                }
+            }
+            unsigned long long carry = best, out = TD_KEY_MAX;
+            for (int r = 0; r < k; ++r) {
+                unsigned long long lmin = carry;
+                lmin = kl[0] < lmin ? kl[0] : lmin;
+                lmin = kl[1] < lmin ? kl[1] : lmin;
+                const unsigned long long wmin = td_wave_min_u64(lmin);
+                if (wmin != TD_KEY_MAX) {
+                    if (carry == wmin) carry = TD_KEY_MAX;
+                    if (kl[0] == wmin) kl[0] = TD_KEY_MAX;
+                    if (kl[1] == wmin) kl[1] = TD_KEY_MAX;
+                }
+                if (lane == r) out = wmin;
+            }
+            best = out;
+        }
+        if (lane < cpn * TD_K) nbr[c0 * TD_K + lane] = (best == TD_KEY_MAX || lane >= k) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
+        const bool lig_in = lane < k && best != TD_KEY_MAX && (int)(unsigned)(best & 0xffffffffull) >= lbeg;
+        is_clean = __ballot(lig_in) == 0ull;
+    } else if (lane < cpn * TD_K) {
+        nbr[c0 * TD_K + lane] = snbr[c0 * TD_K + lane];
+    }
+    const float2 hv = *reinterpret_cast<const float2 *>((is_clean ? h1s : h0) + i * TD_H + 2 * lane);
+    *reinterpret_cast<float2 *>(h + i * TD_H + 2 * lane) = hv;
+    if (is_clean && lane < cpn * TD_K) ew[c0 * TD_K + lane] = ews[c0 * TD_K + lane];
+    if (lane == 0) {
+        clean[i] = is_clean ? 1 : 0;
+        if (flags2) flags2[i] = 0;
+    }
+}
+
+int td_launch_knn_merge_general(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
+                                const float *h0, const float *h1s, const float *ews, const int32_t *cptr, int cpn, int32_t *nbr,
+                                float *h, float *ew, uint8_t *clean, uint8_t *flags2, hipStream_t s, int k) {
+    if (Np == 0) return TD_OK;
+    knn_merge_general_kernel<<<dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, pptr, gid, prot_rows, Np, skeys, snbr,
+                                                                                h0, h1s, ews, cptr, cpn, nbr, h, ew, clean, flags2, k);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
 // Slots of a block-wide compaction into up to L lists at once: one atomicAdd per block and list (a wave-level ballot per
 // list, wave totals through LDS).  flag[l] -> slot[l] = index in list l (valid where flag[l]).  blockDim.x = 256 (4 waves).
 // Order inside a list is irrelevant to the arithmetic (rows are independent); the atomics only hand out slots.
@@ -524,14 +609,20 @@ __device__ __forceinline__ void td_block_slots_each(const bool (&flag)[L], int32
 
 constexpr int TD_LISTS_THREADS = 1024;
 
+// CHUNKED (general graphs): the neighbour table is chunk-indexed -- the graph's chunks are cptr[n0] .. cptr[n0 + n) - 1, chunk c
+// belongs to dst node chunk_node[c] -- and one more list comes out: the chunks of the dirty rows (what the edge gate recomputes).
+template <bool CHUNKED>
 __global__ __launch_bounds__(TD_LISTS_THREADS) void step_lists_kernel(const uint8_t *__restrict__ clean, const float4 *__restrict__ x4,
                                                                       const int32_t *__restrict__ nbr, const int32_t *__restrict__ node_ptr,
+                                                                      const int32_t *__restrict__ cptr, const int32_t *__restrict__ chunk_node,
                                                                       int64_t N, int cap, TdStepLists out) {
     constexpr int T = TD_LISTS_THREADS, RPT = T / TD_K;      // rows per trip: thread = (row a0 + tid / 32, slot tid % 32)
     extern __shared__ uint8_t s_flags[];
     uint8_t *dirty = s_flags, *reach = s_flags + cap, *level = s_flags + 2 * cap, *lig = s_flags + 3 * cap;
     const int n0 = node_ptr[blockIdx.x], n = node_ptr[blockIdx.x + 1] - n0;
     const int tid = threadIdx.x, e = tid & 31, r0 = tid >> 5;
+    // "rows" of the table: the graph's nodes, or (CHUNKED) its chunks
+    const int t0 = CHUNKED ? cptr[n0] : n0, nt = CHUNKED ? cptr[n0 + n] - t0 : n;
     for (int a = tid; a < n; a += T) {
         const bool l = x4[n0 + a].w > 0.5f;
         const bool d = l || !clean[n0 + a];
@@ -541,32 +632,33 @@ __global__ __launch_bounds__(TD_LISTS_THREADS) void step_lists_kernel(const uint
         level[a] = l ? 1 : 0;                           // level 1 starts from the ligand atoms
     }
     __syncthreads();
-    const int32_t *row0 = nbr + (int64_t)n0 * TD_K + e;
+    const int32_t *row0 = nbr + (int64_t)t0 * TD_K + e;
+    auto dst_of = [&](int t) -> int { return CHUNKED ? chunk_node[t0 + t] - n0 : t; };
     // forward reach = rows with a dirty in-neighbour; level 1 = the ligand rows' in-neighbours
-    for (int a0 = r0; a0 < n; a0 += 4 * RPT) {
-        int j[4];
+    for (int a0 = r0; a0 < nt; a0 += 4 * RPT) {
+        int j[4], dn[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int a = a0 + u * RPT;
-            j[u] = a < n ? row0[(int64_t)a * TD_K] : -1;
+            const int t = a0 + u * RPT;
+            j[u] = t < nt ? row0[(int64_t)t * TD_K] : -1;
+            dn[u] = t < nt ? dst_of(t) : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int a = a0 + u * RPT;
             if (j[u] < 0) continue;
-            if (dirty[j[u] - n0]) reach[a] = 1;                               // racing writers store the same value
-            if (lig[a] && level[j[u] - n0] == 0) level[j[u] - n0] = 1;
+            if (dirty[j[u] - n0]) reach[dn[u]] = 1;                           // racing writers store the same value
+            if (lig[dn[u]] && level[j[u] - n0] == 0) level[j[u] - n0] = 1;
         }
     }
     __syncthreads();
     for (int k = 2; k <= out.levels; ++k) {
         // rows reached at level k - 1 mark their still unreached in-neighbours with k (earlier levels did so in earlier passes)
-        for (int a0 = r0; a0 < n; a0 += 4 * RPT) {
+        for (int a0 = r0; a0 < nt; a0 += 4 * RPT) {
             int j[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int a = a0 + u * RPT;
-                j[u] = (a < n && level[a] == k - 1) ? row0[(int64_t)a * TD_K] : -1;
+                const int t = a0 + u * RPT;
+                j[u] = (t < nt && level[dst_of(t)] == k - 1) ? row0[(int64_t)t * TD_K] : -1;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -597,17 +689,31 @@ __global__ __launch_bounds__(TD_LISTS_THREADS) void step_lists_kernel(const uint
         for (int k = 0; k < TD_HOP_LEVELS; ++k)
             if (flag[3 + k]) out.level_rows[(size_t)k * N + slot[3 + k]] = i;
     }
+    if (CHUNKED && out.dirty_chunks) {
+        int32_t *const cc[1] = {out.dirty_chunk_count};
+        for (int base = 0; base < nt; base += T) {
+            const int t = base + tid;
+            const bool flag[1] = {t < nt && dirty[dst_of(t < nt ? t : 0)]};
+            int slot[1];
+            td_block_slots_each<1, T / 64>(flag, cc, slot);
+            if (flag[0]) out.dirty_chunks[slot[0]] = t0 + t;
+        }
+    }
 }
 
 // `max_nodes`: an upper bound on the nodes of one graph (exact, not a hint: it sizes the LDS flag arrays).  Counters are zeroed
 // by the step's first kernel.  Returns TD_EINVAL when a graph is too large for LDS (the caller then uses the separate kernels).
 int td_launch_step_lists(const uint8_t *clean, const float4 *x4, const int32_t *nbr, const int32_t *node_ptr, int64_t N,
-                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s) {
+                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s, const int32_t *cptr,
+                         const int32_t *chunk_node) {
     if (N == 0 || B == 0) return TD_OK;
     const int cap = (max_nodes + 15) & ~15;
     const size_t bytes = (size_t)4 * cap;
     if (bytes > 48 * 1024 || out.levels > TD_HOP_LEVELS) return TD_EINVAL;
-    step_lists_kernel<<<dim3((unsigned)B), dim3(TD_LISTS_THREADS), bytes, s>>>(clean, x4, nbr, node_ptr, N, cap, out);
+    if (cptr)
+        step_lists_kernel<true><<<dim3((unsigned)B), dim3(TD_LISTS_THREADS), bytes, s>>>(clean, x4, nbr, node_ptr, cptr, chunk_node, N, cap, out);
+    else
+        step_lists_kernel<false><<<dim3((unsigned)B), dim3(TD_LISTS_THREADS), bytes, s>>>(clean, x4, nbr, node_ptr, nullptr, nullptr, N, cap, out);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -779,13 +885,17 @@ int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t
 }
 
 // k nearest same-graph nodes for any k <= 64, written into the node's slot array (ascending (d2, index), like knn_kernel).
-// PROT_ONLY: candidates are the protein atoms of the graph only and the winners go to slots slot0 .. slot0 + k - 1 where
-// slot0 = (number of ligand atoms of the graph) - 1: the protein half of a hybrid ligand row.
-template <int CH, bool PROT_ONLY>
+// MODE 1 (PROT_ONLY): candidates are the protein atoms of the graph only and the winners go to slots slot0 .. slot0 + k - 1
+//         where slot0 = (number of ligand atoms of the graph) - 1: the protein half of a hybrid ligand row.
+// MODE 2 (STATIC): the protein-only lists of a sampling session: ligand candidates are skipped, all 64 rounds run and the
+//         sorted keys are kept (skeys[i][64]) so that later steps only merge the graph's ligand atoms in.
+template <int CH, int MODE>
 __global__ __launch_bounds__(256) void knn_general_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
                                                           const int32_t *__restrict__ pptr, const int32_t *__restrict__ gid,
                                                           const int32_t *__restrict__ rows, int64_t count, int k,
-                                                          const int32_t *__restrict__ cptr, int32_t *__restrict__ cnbr) {
+                                                          const int32_t *__restrict__ cptr, int32_t *__restrict__ cnbr,
+                                                          unsigned long long *__restrict__ skeys) {
+    constexpr bool PROT_ONLY = MODE == 1, STATIC = MODE == 2;
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qi >= count) return;
@@ -793,10 +903,11 @@ __global__ __launch_bounds__(256) void knn_general_kernel(const float4 *__restri
     const int g = gid[i];
     const int beg = ptr[g];
     const int np = pptr[g + 1] - pptr[g];
-    const int end = PROT_ONLY ? beg + np : ptr[g + 1];
+    const int end = (PROT_ONLY || STATIC) ? beg + np : ptr[g + 1];
     const int slot0 = PROT_ONLY ? (ptr[g + 1] - beg - np) - 1 : 0;
+    const int rounds = STATIC ? 64 : k;
     const float4 xi = x4[i];
-    unsigned long long best = TD_KEY_MAX;    // lanes 0..k-1: current r-th smallest key
+    unsigned long long best = TD_KEY_MAX;    // lanes 0..rounds-1: current r-th smallest key
     for (int base = beg; base < end; base += 64 * CH) {
         unsigned long long key[CH];
 #pragma unroll
@@ -810,7 +921,7 @@ __global__ __launch_bounds__(256) void knn_general_kernel(const float4 *__restri
             }
         }
         unsigned long long carry = best, out = TD_KEY_MAX;
-        for (int r = 0; r < k; ++r) {
+        for (int r = 0; r < rounds; ++r) {
             unsigned long long lmin = carry;
 #pragma unroll
             for (int u = 0; u < CH; ++u) lmin = key[u] < lmin ? key[u] : lmin;
@@ -826,6 +937,7 @@ __global__ __launch_bounds__(256) void knn_general_kernel(const float4 *__restri
         best = out;
     }
     if (lane < k && best != TD_KEY_MAX) cnbr[(int64_t)cptr[i] * TD_K + slot0 + lane] = (int32_t)(unsigned)(best & 0xffffffffull);
+    if (STATIC) skeys[i * 64 + lane] = best;
 }
 
 // ligand half of a hybrid ligand row (models/common.py:166-171): every other ligand atom of the graph, ascending index
@@ -843,6 +955,14 @@ __global__ void hybrid_ligand_kernel(const int32_t *__restrict__ ptr, const int3
         const int j = lbeg + s;
         row[s] = j >= i ? j + 1 : j;
     }
+}
+
+int td_launch_hybrid_ligand_half(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *lig_node,
+                                 int64_t Nl, const int32_t *cptr, int32_t *cnbr, hipStream_t s) {
+    if (Nl == 0) return TD_OK;
+    hybrid_ligand_kernel<<<dim3((unsigned)((Nl + 3) / 4)), dim3(256), 0, s>>>(node_ptr, pptr, gid, lig_node, Nl, cptr, cnbr);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
 }
 
 // radius graph with a fan-out cap (rule: oracle/shims.py radius_neighbours): the first `cap` nodes j != i of the same
@@ -872,20 +992,37 @@ __global__ __launch_bounds__(256) void radius_kernel(const float4 *__restrict__ 
     }
 }
 
-template <bool PROT_ONLY>
+template <int MODE>
 static int launch_knn_general(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                               const int32_t *rows, int64_t count, int k, int max_graph_nodes, const int32_t *cptr,
-                              int32_t *cnbr, hipStream_t s) {
+                              int32_t *cnbr, hipStream_t s, unsigned long long *skeys = nullptr) {
     if (count == 0) return TD_OK;
     dim3 grid((unsigned)((count + 3) / 4)), block(256);
     if (max_graph_nodes > 0 && max_graph_nodes <= 384)
-        knn_general_kernel<6, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+        knn_general_kernel<6, MODE><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr, skeys);
     else if (max_graph_nodes <= 704)
-        knn_general_kernel<11, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+        knn_general_kernel<11, MODE><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr, skeys);
     else
-        knn_general_kernel<17, PROT_ONLY><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr);
+        knn_general_kernel<17, MODE><<<grid, block, 0, s>>>(x4, node_ptr, pptr, gid, rows, count, k, cptr, cnbr, skeys);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
+}
+
+// Session of a general k-NN / hybrid graph: the protein-only lists (sorted keys kept) of the listed protein rows
+int td_launch_knn_general_static(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                 const int32_t *prot_rows, int64_t Np, int k, int max_graph_nodes, const int32_t *cptr,
+                                 int32_t *snbr, unsigned long long *skeys, hipStream_t s) {
+    return launch_knn_general<2>(x4, node_ptr, pptr, gid, prot_rows, Np, k, max_graph_nodes, cptr, snbr, s, skeys);
+}
+
+// Per-step neighbour rows of the ligand atoms on a general graph: k-NN rows over the whole graph, or (hybrid) the k nearest
+// protein atoms behind the other ligand atoms of the graph (that half is step-invariant and written once by
+// td_launch_hybrid_ligand_half).  The rows' slots must hold -1 where nothing is written (k-NN: fewer than k candidates).
+int td_launch_ligand_rows_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                  const int32_t *lig_node, int64_t Nl, int k, int max_graph_nodes, const int32_t *cptr,
+                                  int32_t *cnbr, hipStream_t s) {
+    if (mode == 1) return launch_knn_general<1>(x4, node_ptr, pptr, gid, lig_node, Nl, k, max_graph_nodes, cptr, cnbr, s);
+    return launch_knn_general<0>(x4, node_ptr, pptr, gid, lig_node, Nl, k, max_graph_nodes, cptr, cnbr, s);
 }
 
 // Fill the chunk table of a general graph.  mode 0: k-NN (any k <= 64) on every row; 1: hybrid (protein rows: k-NN over
@@ -896,13 +1033,12 @@ int td_launch_graph_general(int mode, const float4 *x4, const int32_t *node_ptr,
     TD_CHECK_HIP(hipMemsetAsync(cnbr, 0xff, (size_t)NC * TD_K * sizeof(int32_t), s));
     int rc = TD_OK;
     if (mode == 0) {
-        rc = launch_knn_general<false>(x4, node_ptr, pptr, gid, nullptr, N, k, max_graph_nodes, cptr, cnbr, s);
+        rc = launch_knn_general<0>(x4, node_ptr, pptr, gid, nullptr, N, k, max_graph_nodes, cptr, cnbr, s);
     } else if (mode == 1) {
-        rc = launch_knn_general<false>(x4, node_ptr, pptr, gid, prot_node, Np, k, max_graph_nodes, cptr, cnbr, s);
+        rc = launch_knn_general<0>(x4, node_ptr, pptr, gid, prot_node, Np, k, max_graph_nodes, cptr, cnbr, s);
         if (rc == TD_OK && Nl > 0) {
-            hybrid_ligand_kernel<<<dim3((unsigned)((Nl + 3) / 4)), dim3(256), 0, s>>>(node_ptr, pptr, gid, lig_node, Nl, cptr, cnbr);
-            TD_CHECK_HIP(hipGetLastError());
-            rc = launch_knn_general<true>(x4, node_ptr, pptr, gid, lig_node, Nl, k, max_graph_nodes, cptr, cnbr, s);
+            rc = td_launch_hybrid_ligand_half(node_ptr, pptr, gid, lig_node, Nl, cptr, cnbr, s);
+            if (rc == TD_OK) rc = launch_knn_general<1>(x4, node_ptr, pptr, gid, lig_node, Nl, k, max_graph_nodes, cptr, cnbr, s);
         }
     } else {
         if (N > 0) {

@@ -102,7 +102,10 @@ __device__ __forceinline__ void td_split_tile(const float4 (&a)[16], uint4 (&ap)
 //   grid was sized for, workgroups beyond the count exit before any barrier)
 //   units > 1: one unit (a projection, or the two-GEMM query MLP) per workgroup, so that a 2 k-row segment spreads over
 //   many CUs instead of walking five matrices on a few
-// Segments are laid out along blockIdx.x in the order given (small segments first so that they start early).  This is
+// Segments are laid out along blockIdx.x in the order given: the segment with the long workgroups (six GEMMs per 128 rows)
+// first, the short ones (one or two GEMMs) after it.  A full-size launch at C2 is 475 long + ~210 short workgroups for 512
+// slots (2 per CU): dispatched in this order the short ones fill the slots the long ones leave, and the launch lasts about
+// one long workgroup; with the short ones first (rounds 1-2) a third of the long workgroups started late (1.33 x).  This is
 // how the h2x stage's projections (neighbourhood rows + ligand rows, h2x weights) ride in the same launch as the next
 // layer's x2h-stage projections: all of them read the same h.
 struct NpSeg {
@@ -257,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
 // 24 rounds then starts by waiting out a full L2 round trip (98 us per full-size launch against 33 us of MFMA time, round 2).
 // (Staging through registers instead costs 24 VGPRs the kernel does not have: the chunk lands in scratch.)
 __device__ __forceinline__ void td_glds16_asm(const uint4 *gsrc_lane, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory");      // m0 is a reserved register: the compiler keeps nothing live in it across the statement
 }
-template <bool ASYNC>
+template <bool ASYNC, bool BPIPE>
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, const float *__restrict__ h) {
     int bx = blockIdx.x, si = 0;
     while (si + 1 < args.nseg && bx >= args.seg[si].blocks) { bx -= args.seg[si].blocks; ++si; }
@@ -355,27 +358,40 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
                         td_glds16(reinterpret_cast<const float4 *>(src + u + tid), reinterpret_cast<float4 *>(dst + u));
                 }
                 const uint4 *bl = bufs + cur * NPS_CHUNK_U4 + lane;
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) {
-                    const int s = 4 * kc + ss;
-                    uint4 b[3][2];
+                // B fragments of k-step ss + 1 are read from LDS BEFORE the 12 MFMAs of k-step ss are issued (BPIPE: two
+                // register sets; left to itself the scheduler issues the reads after them and the wave then waits out the
+                // LDS latency with an empty matrix pipe)
+                uint4 b[2][3][2];
+                auto load_b = [&](int ss, uint4 (&bb)[3][2]) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) b[p][t] = bl[((ss * 3 + p) * 2 + t) * 64];
+                        for (int t = 0; t < 2; ++t) bb[p][t] = bl[((ss * 3 + p) * 2 + t) * 64];
+                };
+                if constexpr (BPIPE) load_b(0, b[0]);
+#pragma unroll
+                for (int ss = 0; ss < 4; ++ss) {
+                    const int s = 4 * kc + ss;
+                    uint4 (&bc)[3][2] = b[BPIPE ? (ss & 1) : 0];
+                    if constexpr (BPIPE) {
+                        if (ss + 1 < 4) load_b(ss + 1, b[(ss + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else
+                        load_b(ss, bc);
                     // low-order products first
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[1][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], bc[1][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[2][s], b[0][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[2][s], bc[0][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[2][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], bc[2][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], b[0][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[1][s], bc[0][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[1][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], bc[1][t], acc[t]);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], b[0][t], acc[t]);
+                    for (int t = 0; t < 2; ++t) acc[t] = td_mfma_bf16(ap[0][s], bc[0][t], acc[t]);
+                    if constexpr (BPIPE) __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // the copy the compiler does not know about
                 __syncthreads();
@@ -442,7 +458,7 @@ static int np_fill(NpSeg &g, const TdNodeStage &st, const int32_t *rows, const i
     return g.blocks;
 }
 
-static TdLdsOnce g_np_lds, g_nps_lds, g_npsa_lds, g_egnn_node_lds;
+static TdLdsOnce g_np_lds, g_nps_lds, g_npsa_lds, g_npsb_lds, g_egnn_node_lds;
 
 static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, hipStream_t s) {
     int rc;
@@ -450,12 +466,15 @@ static int np_launch(const NpArgs &a, const float *h, unsigned total_blocks, hip
     // launch carries the pre-split weights and the model option asks for it
     bool split = true;
     for (int i = 0; i < a.nseg; ++i) split = split && a.seg[i].st.use_split && a.seg[i].st.projB3 != nullptr;
-    if (split && a.seg[0].st.async_copy) {
-        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel<true>), NPS_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_split_kernel<true><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
+    if (split && a.seg[0].st.async_copy && a.seg[0].st.bpipe) {
+        if ((rc = td_set_lds(g_nps_lds, reinterpret_cast<const void *>(node_proj_split_kernel<true, true>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<true, true><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
+    } else if (split && a.seg[0].st.async_copy) {
+        if ((rc = td_set_lds(g_npsb_lds, reinterpret_cast<const void *>(node_proj_split_kernel<true, false>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<true, false><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
     } else if (split) {
-        if ((rc = td_set_lds(g_npsa_lds, reinterpret_cast<const void *>(node_proj_split_kernel<false>), NPS_LDS_BYTES)) != TD_OK) return rc;
-        node_proj_split_kernel<false><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
+        if ((rc = td_set_lds(g_npsa_lds, reinterpret_cast<const void *>(node_proj_split_kernel<false, false>), NPS_LDS_BYTES)) != TD_OK) return rc;
+        node_proj_split_kernel<false, false><<<dim3(total_blocks), dim3(256), NPS_LDS_BYTES, s>>>(a, h);
     } else {
         if ((rc = td_set_lds(g_np_lds, reinterpret_cast<const void *>(node_proj_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
         node_proj_kernel<<<dim3(total_blocks), dim3(256), NP_LDS_BYTES, s>>>(a, h);
@@ -472,10 +491,10 @@ int td_launch_node_proj(const TdNodeStage &st, const float *h, int64_t N, const 
     NpArgs a;
     a.nseg = 0;
     unsigned total = 0;
-    if (rows2) total += np_fill(a.seg[a.nseg++], st, rows2, nullptr, N2, mask2, P, q, true, 128);
     // a small batch (N bounds the device-side count) cannot fill the chip with one workgroup per 128 rows walking through
     // all six GEMMs: one workgroup per (128 rows, matrix unit) instead -- 5x the parallelism, same arithmetic
     total += np_fill(a.seg[a.nseg++], st, rows, count_ptr, N, mat_mask, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
+    if (rows2) total += np_fill(a.seg[a.nseg++], st, rows2, nullptr, N2, mask2, P, q, true, 128);
     return np_launch(a, h, total, s);
 }
 
@@ -490,9 +509,9 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
     NpArgs a;
     a.nseg = 0;
     unsigned total = 0;
-    if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
-    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, N <= TD_SMALL_BATCH_ROWS, 128);
     total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
+    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, N <= TD_SMALL_BATCH_ROWS, 128);
+    if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
     return np_launch(a, h, total, s);
 }
 

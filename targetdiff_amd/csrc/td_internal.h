@@ -74,6 +74,7 @@ struct TdNodeStage {
     const float *projB3;   // optional: the same 5 matrices as bf16 piece triples [mat][8 kstep][3 piece][64 lane][4 ntile] x 8 bf16
     const float *q3B3;     // optional: q.net.3 likewise (nullptr: the fp32 path is the only one)
     bool use_split;        // run the GEMMs on the exact 3-way bf16 operand split (model option "node_proj_split")
+    bool bpipe;            // split kernel: B fragments of the next k-step read ahead of the current k-step's MFMAs ("node_proj_bpipe")
     bool async_copy;         // split kernel: B chunks by inline-asm global_load_lds + explicit wait (model option "node_proj_async", default)
 };
 
@@ -131,6 +132,7 @@ struct TdOptions {
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
+    int node_proj_bpipe = 1;       // split node GEMMs: register double-buffering of the B fragments (LDS reads ahead of the MFMAs)
     int node_proj_async = 1;    // split node GEMMs: B chunks by inline-asm global_load_lds + an explicit wait per round (0: the builtin, which the compiler serialises)
     int session_step_lists = 1;    // a step's row lists from one launch (a workgroup per graph; 0: the separate kernels, which
                                    // graphs too large for its LDS flags use anyway)
@@ -187,9 +189,12 @@ struct TdStepLists {
     int32_t *reach_rows, *rest_rows, *reach_counts;
     int32_t *level_rows, *level_counts;
     int levels;
+    int32_t *dirty_chunks = nullptr, *dirty_chunk_count = nullptr;     // general graphs: the chunks of the dirty rows
 };
+// cptr / chunk_node (general graphs): chunk-indexed neighbour table
 int td_launch_step_lists(const uint8_t *clean, const float4 *x4, const int32_t *nbr, const int32_t *node_ptr, int64_t N,
-                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s);
+                         int64_t B, int max_nodes, const TdStepLists &out, hipStream_t s, const int32_t *cptr = nullptr,
+                         const int32_t *chunk_node = nullptr);
 // bookkeeping a session step resets in its first kernel: up to three counter arrays and the ligand rows' forward-reach flags
 struct TdStepReset {
     int32_t *c0 = nullptr, *c1 = nullptr, *c2 = nullptr;
@@ -211,28 +216,20 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
 // gate.hip -- rows: optional row list; chunk_node: dst node of every row of nbr / ew on general graphs (nullptr: row == node)
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node = nullptr);
-// edge16.hip (16x16x4 MFMA variants of the two passes; default)
+// edge16.hip.  cptr (general graphs): the in-edges of dst node i are the chunks cptr[i] .. cptr[i+1]-1 (32 slots each) of
+// nbr / ew / alpha; nullptr on the default graph (one 32-slot row per node, chunk == node)
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                         float *alpha, hipStream_t s);
+                         float *alpha, hipStream_t s, const int32_t *cptr = nullptr);
 int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
                          int64_t count, hipStream_t s);
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
-                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s);
+                        const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s,
+                        const int32_t *cptr = nullptr);
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig_rows, int64_t lig_count,
-                           hipStream_t s);
-// edge16.hip, general graphs (chunked neighbour table, see graph.hip)
-int td_launch_edge_logits16(int stage, const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr,
-                            const float *P, const float *q, const int32_t *chunk_node, const int32_t *chunks, int64_t count,
-                            float *alpha, hipStream_t s);
-int td_launch_edge_value16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *cnbr, const float *ew,
-                                  const float *P, const int32_t *cptr, const int32_t *rows, int64_t count, float *h,
-                                  const float *alpha, hipStream_t s);
-int td_launch_edge_xv16_ragged(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *cnbr,
-                               const float *ew, const float *P, const int32_t *cptr, const int32_t *rows, int64_t count,
-                               const float *alpha, hipStream_t s);
+                           hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0);
 // graph.hip, general graphs
 int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *g_cbase,
                      const int32_t *g_cl, const int32_t *g_lbase, int cpn_p, int64_t N, int32_t *cptr, int32_t *chunk_node,
@@ -240,6 +237,18 @@ int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t
 int td_launch_graph_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                             const int32_t *prot_node, int64_t Np, const int32_t *lig_node, int64_t Nl, int64_t N, int k,
                             float radius, int max_graph_nodes, const int32_t *cptr, int32_t *cnbr, int64_t NC, hipStream_t s);
+int td_launch_knn_general_static(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                 const int32_t *prot_rows, int64_t Np, int k, int max_graph_nodes, const int32_t *cptr,
+                                 int32_t *snbr, unsigned long long *skeys, hipStream_t s);
+int td_launch_ligand_rows_general(int mode, const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                  const int32_t *lig_node, int64_t Nl, int k, int max_graph_nodes, const int32_t *cptr,
+                                  int32_t *cnbr, hipStream_t s);
+int td_launch_hybrid_ligand_half(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *lig_node,
+                                 int64_t Nl, const int32_t *cptr, int32_t *cnbr, hipStream_t s);
+int td_launch_knn_merge_general(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
+                                const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
+                                const float *h0, const float *h1s, const float *ews, const int32_t *cptr, int cpn, int32_t *nbr,
+                                float *h, float *ew, uint8_t *clean, uint8_t *flags2, hipStream_t s, int k);
 int td_launch_radius32(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, int64_t N, float radius, int cap,
                        int32_t *nbr, hipStream_t s);
 int td_launch_slots_to_dense(const int32_t *cptr, const int32_t *cnbr, int64_t N, int width, int32_t *out, hipStream_t s);
