@@ -88,6 +88,7 @@ __device__ __forceinline__ float td_max16(float v) {
 // ---- first layer + LayerNorm + ReLU of one dst node: z^T in acc[eb][hb] ------------------------------------------------
 struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
     bool valid[2];
+    bool any[2];       // wave-uniform: does the 16-edge block hold any edge at all (false: all pads, e.g. slots 48 .. 63 at k = 48)
     float ew[2];
     float rel[2][3];   // x_i - x_j
     float4 xi;
@@ -134,10 +135,17 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
 
 // LayerNorm over the 128 hidden units of each edge + ReLU, in the transposed accumulator layout (a lane owns 32 of an edge's
 // 128 hidden units for each of its two edges; the other 96 sit in the lanes lo + 16 g')
+// SKIP_EMPTY: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 instead of the LayerNorm of its padding
+template <bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_ln_relu16(const float *__restrict__ GAM, const float *__restrict__ BET, int g,
-                                             floatx4_t (&acc)[2][8]) {
+                                             floatx4_t (&acc)[2][8], const bool (&any)[2] = {true, true}) {
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
+        if (SKIP_EMPTY && !any[eb]) {
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) acc[eb][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         float s1 = 0.f;
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
@@ -166,7 +174,7 @@ __device__ __forceinline__ void td_ln_relu16(const float *__restrict__ GAM, cons
 
 
 // radial / type first layer on the gathered operands + LayerNorm + ReLU: z^T in acc[eb][hb]
-template <bool LOAD_EW>
+template <bool LOAD_EW, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const float4 *__restrict__ Rt,
                                                          const float *__restrict__ GAM, const float *__restrict__ BET,
                                                          const float (&offk)[E16_STEPS], const RowIn16 &r, int lane,
@@ -189,6 +197,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
         has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
+        ed.any[eb] = has[0][eb] || has[1][eb];
     }
     const bool has_a = has[0][0] || has[0][1], has_b = has[1][0] || has[1][1];
     // dst-side projection P_i rides in the table's padding column k = 21 (k-step 5, lane group 1)
@@ -222,7 +231,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    td_ln_relu16(GAM, BET, g, acc);
+    td_ln_relu16<SKIP_EMPTY>(GAM, BET, g, acc, ed.any);
 }
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
@@ -256,7 +265,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 // offj[j] = Gaussian centre of k = 8g + j.  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
 // PI_LATE: the P_i loads are issued first and consumed after the products (their latency hides behind the MFMAs at the
 // price of 32 registers); otherwise P_i is added up front.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE>
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ GAM, const float *__restrict__ BET,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
@@ -296,6 +305,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
         has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
+        ed.any[eb] = has[0][eb] || has[1][eb];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * g + j;
@@ -337,10 +347,10 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         }
     }
     if (PI_LATE) add_pi();
-    td_ln_relu16(GAM, BET, g, acc);
+    td_ln_relu16<SKIP_EMPTY>(GAM, BET, g, acc, ed.any);
 }
 
-template <bool LOAD_EW>
+template <bool LOAD_EW, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
                                                  const float *__restrict__ GAM, const float *__restrict__ BET,
                                                  const float (&offk)[E16_STEPS], int64_t i, int lane,
@@ -349,7 +359,7 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
     if (c < 0) c = i;
     td_row_index16(a, i, c, lane, r);
     td_row_gather16<LOAD_EW>(a, i, c, lane, r, acc);
-    td_first_layer_compute16<LOAD_EW>(a, Rt, GAM, BET, offk, r, lane, acc, ed);
+    td_first_layer_compute16<LOAD_EW, SKIP_EMPTY>(a, Rt, GAM, BET, offk, r, lane, acc, ed);
 }
 
 // ================================================================================================ key pass
@@ -406,9 +416,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             RowIn16 rin;
             td_row_index16(a, i, c, lane, rin);
             td_row_gather16<EW>(a, i, c, lane, rin, acc);
-            td_first_layer_split16<EW, false, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
         } else
-            td_first_layer16<EW>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+            td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
 
     for (int64_t it = begin + wid; it < end; it += WAVES) {
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                     for (int r = 0; r < 4; ++r) {
                         const float u = Wx[(hb * 4 + r) * 64 + lane];
                         xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
-                        xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                        if (!CHUNKED || ed.any[1]) xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);     // blocks fill from slot 0: only the second can be empty
                     }
                 // xv[eb][r] = xv of edge 16eb + lo, head 4g + r (bias: b2 of that head, fetched through the head's lane)
 #pragma unroll
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         }
 
         // ---- logits^T[head][edge] = sum_k U_i[k][head] z[k][edge];  A = U_i built from q_i: lane (head lo, group g) ----
-        auto logits = [&](const floatx4_t (&acc)[2][8], floatx4_t (&lg)[2]) {
+        auto logits = [&](const floatx4_t (&acc)[2][8], floatx4_t (&lg)[2], const Edge2 &ed) {
             // fetched after the first layer: eight fewer live registers while it runs
             const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
             const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                     u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
                     u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
                     lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                    lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+                    if (!CHUNKED || ed.any[1]) lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);       // an all-pad second block is skipped
                 }
         };
 
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             floatx4_t acc[2][8], lg[2];
             Edge2 ed;
             first_layer(i, c0, acc, ed);
-            logits(acc, lg);
+            logits(acc, lg, ed);
             if (CHUNKED) {
                 ed.ew[0] = a.ew[c0 * TD_K + lo];
                 ed.ew[1] = a.ew[c0 * TD_K + 16 + lo];
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             floatx4_t acc[2][8], lg[2];
             Edge2 ed;
             first_layer(i, c, acc, ed);
-            logits(acc, lg);
+            logits(acc, lg, ed);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
@@ -833,9 +843,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
                 }
                 if constexpr (SPLIT)
-                    td_first_layer_split16<false, true, false>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+                    td_first_layer_split16<false, true, false, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
                 else
-                    td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+                    td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
                 asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
                 auto flip_store = [&](int hb) {
                     float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
