@@ -214,10 +214,10 @@ def build_model(dev, args=None):
     model.load_state_dict(seeded_state_dict(model), strict=False)
     model = model.to(dev).eval()
     if args is not None and args.fp32_node_gemms:
-        model._native(dev).set_option('node_proj_split', 0)
+        model.set_native_option('node_proj_split', 0)
     for kv in (args.option if args is not None else []):
         name, value = kv.split('=')
-        model._native(dev).set_option(name, int(value))
+        model.set_native_option(name, int(value))
     return model
 
 

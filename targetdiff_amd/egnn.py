@@ -84,6 +84,8 @@ class EGNN(nn.Module):
     @torch.no_grad()
     def forward(self, h, x, mask_ligand, batch, return_all=False):
         native = self._get_native(h.device)
+        from .models import _check_sorted
+        _check_sorted(batch)
         B = int(batch.max().item()) + 1 if batch.numel() else 0
         node_ptr = capi.graph_ptr(batch.contiguous(), B)
         h, x = h.contiguous().float(), x.contiguous().float()

@@ -4,8 +4,10 @@ The reference's multi-GPU recipe is "run N shells" (README.md:96-102: ``CUDA_VIS
 scripts/batch_sample_diffusion.sh <cfg> <out> N k 0``).  :func:`spawn_ranks` is that recipe as a function: it starts N
 copies of a command with the ``torch.distributed`` environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
 MASTER_PORT) set exactly as ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` would, so a script that
-reads that environment behaves the same under either launcher.  All GPUs stay visible to every rank; a rank selects its
-device with ``torch.cuda.set_device(LOCAL_RANK)`` (the torchrun convention).
+reads that environment behaves the same under either launcher.  By default all GPUs stay visible to every rank and a rank
+selects its device with ``torch.cuda.set_device(LOCAL_RANK)`` (the torchrun convention); ``pin_devices=True`` (or
+``TD_PIN_DEVICES=1``) is the reference's own recipe instead: rank r sees GPU r only (``HIP_VISIBLE_DEVICES=r``,
+LOCAL_RANK = 0), so nothing a rank allocates can land on another rank's device.
 """
 from __future__ import annotations
 
@@ -26,46 +28,95 @@ def under_launcher() -> bool:
     return 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
 
 
-def rank_env(rank: int, world: int, port: int, base=None) -> dict:
+def rank_env(rank: int, world: int, port: int, base=None, pin_devices: bool = False) -> dict:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if pin_devices:
+        # the reference's recipe (README.md:96-102, CUDA_VISIBLE_DEVICES=k per shell): rank r sees one GPU, as device 0.
+        # An outer HIP_VISIBLE_DEVICES list is honoured: rank r gets its r-th entry.
+        outer = [d for d in env.get('HIP_VISIBLE_DEVICES', '').split(',') if d != '']
+        env['HIP_VISIBLE_DEVICES'] = outer[rank] if rank < len(outer) else str(rank)
+        env.pop('CUDA_VISIBLE_DEVICES', None)
+        env['LOCAL_RANK'] = '0'
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this driver
     return env
 
 
-def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None) -> int:
+def _stop(procs, grace: float = 3.0):
+    """terminate, then kill, every rank that is still running (their process groups: a rank may have children)"""
+    import signal
+    import time
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except (ProcessLookupError, PermissionError):
+            p.terminate()
+    t_end = time.monotonic() + grace
+    while any(p.poll() is None for p in live) and time.monotonic() < t_end:
+        time.sleep(0.05)
+    for p in live:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                p.kill()
+
+
+def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=None, _retries: int = 1) -> int:
     """Run ``argv`` (a full command line, e.g. ``[sys.executable, 'bench.py', ...]``) as ``nprocs`` ranks.  Rank 0
     inherits stdout (so its single JSON line is the job's output); every rank inherits stderr.  Returns the first
-    non-zero exit code (0 if all ranks succeeded); on a failure the remaining ranks are terminated."""
+    non-zero exit code (0 if all ranks succeeded; 124 on a timeout).  Whatever ends the supervision -- a failing rank, the
+    timeout, KeyboardInterrupt / SIGTERM in this process, an exception while starting rank k > 0 -- every rank still
+    running is terminated (each rank is its own session, so its children go with it): no orphan keeps a GPU or the
+    rendezvous port.  The port is picked free at start; a rank that fails within the first seconds because another job
+    took it in between is retried once on a new port."""
+    import time
+    if pin_devices is None:
+        pin_devices = os.environ.get('TD_PIN_DEVICES', '0') not in ('', '0')
     port = free_port()
     procs = []
-    for r in range(nprocs):
-        env = rank_env(r, nprocs, port)
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    import time
     rc = 0
-    deadline = None if timeout is None else time.monotonic() + timeout
-    live = list(procs)
-    while live:                       # poll all ranks: one that dies must not leave the others waiting in a rendezvous
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in live:
-                    q.terminate()
-        if live and deadline is not None and time.monotonic() > deadline:
-            rc = rc or 124
-            for q in live:
-                q.kill()
-        if live:
-            time.sleep(0.05)
+    timed_out = False
+    t_start = time.monotonic()
+    try:
+        for r in range(nprocs):
+            env = rank_env(r, nprocs, port, pin_devices=pin_devices)
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL,
+                                          start_new_session=True))
+        deadline = None if timeout is None else t_start + timeout
+        live = list(procs)
+        while live:                   # poll all ranks: one that dies must not leave the others waiting in a rendezvous
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    _stop(live)
+            if live and deadline is not None and time.monotonic() > deadline:
+                timed_out = True
+                _stop(live)
+            if live:
+                time.sleep(0.05)
+    finally:
+        _stop(procs)
+    if timed_out:
+        return 124
+    if rc != 0 and _retries > 0 and time.monotonic() - t_start < 20.0 and _port_in_use(port):
+        return spawn_ranks(argv, nprocs, timeout, extra_env, pin_devices, _retries - 1)
     return rc
+
+
+def _port_in_use(port: int) -> bool:
+    """after a failed start: is someone (else) listening on the rendezvous port?"""
+    with socket.socket() as s:
+        s.settimeout(0.2)
+        return s.connect_ex(('127.0.0.1', port)) == 0
 
 
 def self_spawn_if_needed(n_gpus: int) -> bool:

@@ -39,14 +39,25 @@ def _check_graph_inputs(batch_protein, batch_ligand, ligand_v, num_classes):
       there; the HIP path builds CSR offsets from sorted vectors (td_graph_ptr) -> refuse unsorted input loudly;
     * ``F.one_hot(ligand_v, num_classes)`` (models/molopt_score_model.py:317) and ``index_to_log_onehot`` (:125) raise
       on out-of-range atom types; the kernels would clamp them silently -> same check here.
-    One host sync per call (the reference syncs at :316 anyway)."""
-    for name, b in (('batch_protein', batch_protein), ('batch_ligand', batch_ligand)):
-        if b.numel() > 1 and not bool((b[1:] >= b[:-1]).all()):
+    One host sync per call (the reference syncs at :316 anyway): the checks reduce to one small device tensor."""
+    flags = []
+    for b in (batch_protein, batch_ligand):
+        flags.append((b[1:] < b[:-1]).any() if b.numel() > 1 else torch.zeros((), dtype=torch.bool, device=b.device))
+    if ligand_v is not None and ligand_v.numel():
+        flags.append(((ligand_v < 0) | (ligand_v >= num_classes)).any())
+    bad = torch.stack([f.to(flags[0].device) for f in flags]).tolist()             # the one synchronisation
+    for name, is_bad in zip(('batch_protein', 'batch_ligand'), bad[:2]):
+        if is_bad:
             raise ValueError(f'{name} must be sorted by graph id (PyG batch vectors are); got an unsorted vector')
-    if ligand_v.numel():
-        lo, hi = int(ligand_v.min()), int(ligand_v.max())
-        if lo < 0 or hi >= num_classes:
-            raise ValueError(f'ligand_v must be in [0, {num_classes}); got values in [{lo}, {hi}]')
+    if len(bad) > 2 and bad[2]:
+        raise ValueError(f'ligand_v must be in [0, {num_classes}); got values in '
+                         f'[{int(ligand_v.min())}, {int(ligand_v.max())}]')
+
+
+def _check_sorted(batch, name='batch'):
+    """The refine_net / likelihood / EGNN seams build CSR offsets from ``batch`` as well: refuse an unsorted vector there too."""
+    if batch.numel() > 1 and bool((batch[1:] < batch[:-1]).any()):
+        raise ValueError(f'{name} must be sorted by graph id (PyG batch vectors are); got an unsorted vector')
 
 
 # ------------------------------------------------------------------------------------------ parameter holders
@@ -123,6 +134,12 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         # :278 -- here r defaults to r_max and the fan-out is capped at max_num_neighbors, torch_geometric's default 32)
         self.r = float(r if r is not None else r_max)
         self.max_num_neighbors = int(max_num_neighbors)
+        if cutoff_mode == 'radius':
+            import warnings
+            warnings.warn("cutoff_mode='radius' has no counterpart in the reference (it raises there: `self.r` is never "
+                          'assigned, models/uni_transformer.py:278).  Here: the first max_num_neighbors same-graph nodes in '
+                          f'index order within r = {self.r} A (r defaults to r_max) -- the project\'s own rule, held to '
+                          'oracle/shims.py only, not to torch_cluster.radius_graph.', stacklevel=3)
         self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
         self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
         self.cutoff_mode, self.ew_net_type = cutoff_mode, ew_net_type
@@ -148,6 +165,7 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         if self._owner is None:
             raise RuntimeError('refine_net must be owned by a ScorePosNet3D (it packs the weights for the HIP library)')
         native = self._owner()._native(h.device)
+        _check_sorted(batch)
         B = int(batch.max().item()) + 1 if batch.numel() else 0
         node_ptr = native.graph_ptr(batch.contiguous(), B)
         h_in, x_in = h.contiguous().float(), x.contiguous().float()
@@ -284,6 +302,15 @@ class ScorePosNet3D(nn.Module):
                                          nn.Linear(self.hidden_dim, ligand_atom_feature_dim))
         self._native_model = None
         self._native_key = None
+        self._native_options = {}        # td_model_set_option values: re-applied whenever the native handle is rebuilt
+
+    def set_native_option(self, name: str, value: int):
+        """Per-model switch of libtargetdiff_hip.so (td_model_set_option: node_proj_split, edge_key_split, h2x_fused,
+        session_* ...).  Kept on the module, so it survives every rebuild of the native handle (load_state_dict, .to(),
+        an optimizer step, deepcopy / pickle) -- options set directly on ``_native(dev)`` would be lost there."""
+        self._native_options[str(name)] = int(value)
+        if self._native_model is not None:
+            self._native_model.set_option(name, int(value))
 
     # ------------------------------------------------------------------------------------------ copy / pickle
     def __getstate__(self):
@@ -325,6 +352,8 @@ class ScorePosNet3D(nn.Module):
                        max_num_neighbors=rn.max_num_neighbors)
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             self._native_model = capi.NativeModel(cfg, self.state_dict(), sched, device=device)
+            for name, value in getattr(self, '_native_options', {}).items():
+                self._native_model.set_option(name, value)
             self._native_key = key
         return self._native_model
 
@@ -356,6 +385,7 @@ class ScorePosNet3D(nn.Module):
         like)`` may inject the Gaussian / uniform draws (parity tests); default: torch RNG in the reference's order."""
         native = self._native(protein_pos.device)
         T = self.num_timesteps
+        _check_graph_inputs(batch_protein, batch_ligand, ligand_v, self.num_classes)
         B = int(batch_protein.max().item()) + 1
         pptr = native.graph_ptr(batch_protein.contiguous(), B)
         lptr = native.graph_ptr(batch_ligand.contiguous(), B)

@@ -51,7 +51,7 @@ def unbatch_v_traj(ligand_v_traj, n_data, ligand_cum_atoms):
 def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cuda:0', num_steps=None,
                             pos_only=False, center_pos_mode='protein', sample_num_atoms='prior',
                             atom_num_sampler=None, ligand_num_atoms=None, generator=None, noise_source=None,
-                            overlap_batches=False):
+                            overlap_batches=None):
     """Returns (pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj, time_list).
 
     Extra keyword arguments (not in the reference signature; all optional): ``atom_num_sampler`` / ``ligand_num_atoms``
@@ -59,7 +59,8 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
     name, like)`` injects every Gaussian / uniform draw (``step == -1``: the initial positions / types of :60-70; ``step
     >= 0``: the sampler's per-step draws) -- the parity tests use it to replay the reference's draws.
 
-    ``overlap_batches=True``: the sample batches of the pocket (independent of each other, :40) advance together, each
+    ``overlap_batches`` (default None = automatic: on when the pocket takes several batches and the draws come from torch's
+    generator, off when they are injected): the sample batches of the pocket (independent of each other, :40) advance together, each
     on its own HIP stream, instead of one after the other.  A small batch (the signature's default batch_size=16 is ~10 k
     nodes) cannot fill the GPU -- its step is a chain of ~60 dependent launches -- so overlapping the chains of several
     batches raises throughput several-fold.  Results per batch are the same bits as in the sequential order when the draws
@@ -69,6 +70,9 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
     pocket_dev = None
     time_list = []
     num_batch = int(np.ceil(num_samples / batch_size))
+    if overlap_batches is None:
+        overlap_batches = (noise_source is None and num_batch > 1 and hasattr(model, 'begin_sampling')
+                           and torch.device(device).type == 'cuda')
     current_i = 0
     jobs = []                      # overlap_batches: (n_data, sizes, sampler) per sample batch
     parts = None                   # the six result lists accumulated so far
@@ -171,10 +175,11 @@ def _unbatch(collected, pos_only):
 
 # ------------------------------------------------------------------------------------------ multi-GPU
 def run_sharded(model, pockets, num_samples, rank=0, world_size=1, start_idx=0, result_path=None, skip_existing=True,
-                keep_results=None, on_pocket=None, **kwargs):
+                keep_results=None, on_pocket=None, balance=False, **kwargs):
     """Pocket-level data parallelism: pocket i is sampled by rank i % world_size, from ``start_idx`` on
     (scripts/batch_sample_diffusion.sh:13-20).  No data-path collective exists on this path; the caller may gather the
-    per-rank result metadata (see ``gather_metadata``).
+    per-rank result metadata (see ``gather_metadata``).  ``balance=True`` (opt-in): size-balanced assignment by protein
+    atom count instead of the round-robin (``workloads.partition_pockets(costs=...)``).
 
     ``result_path``: write ``result_{i}.pt`` per pocket in the reference layout (scripts/sample_diffusion.py:175-188)
     from a background thread, and -- ``skip_existing`` -- skip pockets whose file is already there (idempotent re-runs;
@@ -187,7 +192,8 @@ def run_sharded(model, pockets, num_samples, rank=0, world_size=1, start_idx=0, 
     out = {}
     writer = _results.AsyncResultWriter() if result_path is not None else None
     try:
-        for idx in workloads.partition_pockets(len(pockets), world_size, rank, start_idx):
+        costs = [_as_pocket(p).num_atoms for p in pockets] if balance else None
+        for idx in workloads.partition_pockets(len(pockets), world_size, rank, start_idx, costs=costs):
             path = _results.result_file(result_path, idx) if result_path is not None else None
             if path is not None and skip_existing and os.path.exists(path):
                 if on_pocket:

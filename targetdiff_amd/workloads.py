@@ -204,7 +204,36 @@ def init_ligand(batch: PackedBatch, num_classes: int = NUM_LIGAND_CLASSES, gener
     return pos, v
 
 
-def partition_pockets(num_pockets: int, world_size: int, rank: int, start_idx: int = 0):
+def partition_pockets(num_pockets: int, world_size: int, rank: int, start_idx: int = 0, costs=None):
     """The reference's only parallelism: pocket i goes to worker i % NODE_ALL
-    (scripts/batch_sample_diffusion.sh:15-20)."""
-    return [i for i in range(start_idx, num_pockets) if i % world_size == rank]
+    (scripts/batch_sample_diffusion.sh:15-20) -- the default.
+
+    ``costs`` (opt-in; one number per pocket, e.g. its node count = protein atoms + expected ligand atoms): size-balanced
+    assignment instead -- longest-processing-time-first: pockets in descending cost order, each to the currently least
+    loaded rank (ties: lower rank).  Deterministic, every rank computes the same table, still no communication."""
+    if costs is None:
+        return [i for i in range(start_idx, num_pockets) if i % world_size == rank]
+    return lpt_assignment(costs, world_size, start_idx)[rank]
+
+
+def lpt_assignment(costs, world_size: int, start_idx: int = 0):
+    """-> per rank, the ascending list of pocket indices under longest-processing-time-first."""
+    order = sorted(range(start_idx, len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(v) for v in out]
+
+
+def predicted_imbalance(costs, world_size: int, balanced: bool = False, start_idx: int = 0):
+    """max / mean of the per-rank cost sums under the round-robin (default) or the LPT assignment"""
+    if balanced:
+        parts = lpt_assignment(costs, world_size, start_idx)
+    else:
+        parts = [[i for i in range(start_idx, len(costs)) if i % world_size == r] for r in range(world_size)]
+    sums = [sum(float(costs[i]) for i in p) for p in parts]
+    mean = sum(sums) / max(len(sums), 1)
+    return max(sums) / mean if mean > 0 else 1.0

@@ -491,3 +491,53 @@ def test_bench_through_the_launcher_initialises_rccl(tmp_path):
     line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 1 and d['value'] > 0 and d['unit'] == 'ligands/s' and d['roofline'] is not None
+
+
+def test_c4_bench_and_batch_sample_through_the_launcher_with_the_real_model(tmp_path):
+    """What a multi-GPU run executes per rank, on this box's one GPU and with the real model: `bench.py --workload c4` (the
+    100-pocket test-set job; every pocket's session alive at once) and `tools/batch_sample.py` (result_{i}.pt files, summary,
+    size-balanced assignment flag), both started through targetdiff_amd.launch with pinned devices (HIP_VISIBLE_DEVICES = rank,
+    the reference's recipe) -- so a SCALE run needs no flag that has not been exercised."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from targetdiff_amd import launch, results
+    _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = launch.rank_env(0, 1, launch.free_port(), pin_devices=True)
+    assert env['HIP_VISIBLE_DEVICES'] == '0' and env['LOCAL_RANK'] == '0'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--workload', 'c4'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['scaling'] == 'strong' and d['config']['pockets_this_rank'] == 100 and d['value'] > 0
+    assert abs(d['load_balance']['max_over_mean'] - 1.0) < 1e-9
+    out = tmp_path / 'res'
+    env = launch.rank_env(0, 1, launch.free_port(), pin_devices=True)
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'batch_sample.py'), '--pockets', 'synthetic:4', '--result_path',
+                        str(out), '--num_samples', '6', '--num_steps', '5', '--batch_size', '4', '--ligand_atoms', '20', '--balance'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    s = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert s['world_size'] == 1 and s['pockets_sampled'] == 4 and s['ligands'] == 24
+    for i in range(4):
+        r = torch.load(results.result_file(str(out), i), weights_only=False)
+        assert len(r['pred_ligand_pos']) == 6 and r['pred_ligand_pos'][0].shape == (20, 3) and np.isfinite(r['pred_ligand_pos'][0]).all()
+        assert r['pred_ligand_pos_traj'][0].shape == (5, 20, 3)
+
+
+def test_native_options_survive_a_rebuild_of_the_handle(state_dict):
+    """switches set through the module are re-applied when load_state_dict / .to() rebuild the native handle."""
+    from oracle import weights
+    from targetdiff_amd.models import ScorePosNet3D
+    dev = _dev()
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    m.load_state_dict(state_dict, strict=False)
+    m = m.to(dev).eval()
+    m.set_native_option('edge_key_split', 0)
+    h1 = m._native(dev)
+    assert h1.get_option('edge_key_split') == 0
+    m.load_state_dict(state_dict, strict=False)              # new parameter versions -> a new handle
+    h2 = m._native(dev)
+    assert h2 is not h1 and h2.get_option('edge_key_split') == 0 and h2.get_option('node_proj_split') == 1

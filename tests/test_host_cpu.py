@@ -141,3 +141,49 @@ def test_egnn_mirror_state_dict_and_loud_failure():
         get_refine_net('gcn', dict(weights.DEFAULT_MODEL_CONFIG))
     with pytest.raises(RuntimeError):
         net(torch.zeros(4, 128), torch.zeros(4, 3), torch.zeros(4, dtype=torch.bool), torch.zeros(4, dtype=torch.long))
+
+
+def test_size_balanced_assignment_is_opt_in_and_deterministic():
+    """The reference's i % N round-robin stays the default; LPT on node counts is the opt-in."""
+    costs = [300, 600, 250, 500, 400, 450, 350, 550, 275, 575]
+    assert workloads.partition_pockets(10, 4, 1) == [1, 5, 9]
+    parts = workloads.lpt_assignment(costs, 4)
+    assert sorted(i for p in parts for i in p) == list(range(10))                       # a partition
+    assert parts == workloads.lpt_assignment(costs, 4)                                  # every rank computes the same table
+    assert [workloads.partition_pockets(10, 4, r, costs=costs) for r in range(4)] == parts
+    assert workloads.predicted_imbalance(costs, 4, balanced=True) <= workloads.predicted_imbalance(costs, 4) + 1e-12
+    assert workloads.predicted_imbalance(costs, 4, balanced=True) < 1.12 < workloads.predicted_imbalance(costs, 4)
+    # start_idx: the pockets before it are nobody's
+    assert all(i >= 3 for p in workloads.lpt_assignment(costs, 4, start_idx=3) for i in p)
+
+
+def test_native_options_live_on_the_module(state_dict):
+    """set_native_option values survive a rebuild of the native handle and copy / pickle with the module."""
+    import copy
+    import pickle
+    from targetdiff_amd.models import ScorePosNet3D
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    m.set_native_option('edge_key_split', 0)
+    m.set_native_option('session_hop_levels', 2)
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert clone._native_options == {'edge_key_split': 0, 'session_hop_levels': 2}
+        assert clone._native_model is None
+
+
+def test_unsorted_batch_is_refused_before_any_device_work():
+    from targetdiff_amd.models import _check_graph_inputs, _check_sorted
+    ok = torch.tensor([0, 0, 1, 1, 2])
+    _check_graph_inputs(ok, ok, torch.tensor([0, 12, 3, 4, 5]), 13)
+    _check_sorted(ok)
+    with pytest.raises(ValueError, match='sorted'):
+        _check_graph_inputs(torch.tensor([0, 1, 0]), ok, torch.tensor([0, 1, 2, 3, 4]), 13)
+    with pytest.raises(ValueError, match='sorted'):
+        _check_sorted(torch.tensor([1, 0]))
+    with pytest.raises(ValueError, match=r'ligand_v must be in \[0, 13\)'):
+        _check_graph_inputs(ok, ok, torch.tensor([0, 13, 2, 3, 4]), 13)
+
+
+def test_radius_mode_warns_that_it_is_the_projects_rule():
+    from targetdiff_amd.models import ScorePosNet3D
+    with pytest.warns(UserWarning, match="no counterpart in the reference"):
+        ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, cutoff_mode='radius', r=5.0), 27, 13)

@@ -77,3 +77,36 @@ def test_self_spawn_refuses_more_ranks_than_devices(monkeypatch):
     assert launch.self_spawn_if_needed(1) is False
     with pytest.raises(SystemExit, match='visible'):
         launch.self_spawn_if_needed(torch.cuda.device_count() + 2)
+
+
+def test_pinned_rank_environment():
+    """pin_devices: the reference's CUDA_VISIBLE_DEVICES recipe (README.md:96-102) -- one visible GPU per rank, as device 0."""
+    from targetdiff_amd import launch
+    env = launch.rank_env(3, 8, 29501, base={}, pin_devices=True)
+    assert env['HIP_VISIBLE_DEVICES'] == '3' and env['LOCAL_RANK'] == '0' and env['RANK'] == '3' and env['WORLD_SIZE'] == '8'
+    env = launch.rank_env(1, 2, 29501, base={'HIP_VISIBLE_DEVICES': '4,6'}, pin_devices=True)
+    assert env['HIP_VISIBLE_DEVICES'] == '6'
+    assert launch.rank_env(3, 8, 29501, base={})['LOCAL_RANK'] == '3'
+
+
+def test_timeout_and_interrupt_leave_no_rank_behind(tmp_path):
+    """A hung job: spawn_ranks returns 124 and every rank (and its child) is gone; the same clean-up runs when the
+    supervising loop is interrupted."""
+    import subprocess
+    import sys
+    import time
+    from targetdiff_amd import launch
+    script = tmp_path / 'hang.py'
+    script.write_text('import os, subprocess, sys, time\n'
+                      'open(os.path.join(sys.argv[1], "pid_%s" % os.environ["RANK"]), "w").write(str(os.getpid()))\n'
+                      'c = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])\n'
+                      'open(os.path.join(sys.argv[1], "child_%s" % os.environ["RANK"]), "w").write(str(c.pid))\n'
+                      'time.sleep(600)\n')
+    t0 = time.time()
+    rc = launch.spawn_ranks([sys.executable, str(script), str(tmp_path)], 2, timeout=3.0)
+    assert rc == 124 and time.time() - t0 < 30
+    pids = [int((tmp_path / f).read_text()) for f in ('pid_0', 'pid_1', 'child_0', 'child_1')]
+    time.sleep(0.5)
+    for pid in pids:
+        alive = subprocess.run(['ps', '-p', str(pid), '-o', 'stat='], capture_output=True, text=True).stdout.strip()
+        assert alive == '' or alive.startswith('Z'), (pid, alive)

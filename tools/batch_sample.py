@@ -72,9 +72,15 @@ def main(argv=None, model_factory=build_model):
     ap.add_argument('--checkpoint', default=None)
     ap.add_argument('--seed', type=int, default=2021)                # configs/sampling.yml:6
     ap.add_argument('--ligand_atoms', type=int, default=0, help='fixed ligand size (0: the reference prior)')
+    ap.add_argument('--balance', action='store_true', help='size-balanced pocket -> rank assignment (LPT on protein atom count) '
+                    'instead of the reference\'s i %% N round-robin')
+    ap.add_argument('--pin-devices', action='store_true', help='self-spawned ranks see one GPU each (HIP_VISIBLE_DEVICES=r), the '
+                    'reference\'s CUDA_VISIBLE_DEVICES recipe, instead of all GPUs + set_device(LOCAL_RANK)')
     ap.add_argument('--device', default='cuda', help="'cuda' (rank r uses GPU LOCAL_RANK) or 'cpu' (tests: gloo + stub model)")
     args = ap.parse_args(argv)
     if argv is None:
+        if args.pin_devices:
+            os.environ['TD_PIN_DEVICES'] = '1'
         launch.self_spawn_if_needed(args.gpus)
 
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
@@ -105,7 +111,7 @@ def main(argv=None, model_factory=build_model):
         print(f'[rank {rank}] pocket {idx}: ' + ('exists, skipped' if skipped else f'{seconds:.2f} s'), file=sys.stderr, flush=True)
     t0 = time.time()
     sampling.run_sharded(model, pockets, args.num_samples, rank=rank, world_size=world, start_idx=args.start_idx,
-                         result_path=args.result_path, keep_results=False, on_pocket=on_pocket,
+                         result_path=args.result_path, keep_results=False, on_pocket=on_pocket, balance=args.balance,
                          batch_size=args.batch_size, device=dev, num_steps=args.num_steps, ligand_num_atoms=sizes)
     if on_gpu:
         torch.cuda.synchronize()
