@@ -162,6 +162,18 @@ def cpu_baseline(pocket, sizes, samples=4, steps=8, extrapolate=True):
                          f'samples x {steps} steps run to completion in {sec_per_step * steps:.1f} s ({sec_per_step:.2f} s/step); value = '
                          f'the same rate expressed per 1000-step ligand')
         res['config1_wall_s'] = sec_per_step * steps
+    # the REAL reference cannot run on the GPU box (/root/reference is not there): its own timing, taken in the build container
+    # by tools/cpu_reference.py on BASELINE config 1 in full, is quoted beside the port's figure
+    ref_path = os.path.join(ROOT, 'profiles', 'r03_cpu_reference_c1.json')
+    if os.path.exists(ref_path):
+        with open(ref_path) as f:
+            rj = json.load(f)
+        res['reference_cpu'] = {'source': 'profiles/r03_cpu_reference_c1.json (tools/cpu_reference.py, build container)',
+                                'config': rj['config'], 'host': rj['host'], 'threads': rj['threads'], 'wall_s': rj['wall_s'],
+                                's_per_step': rj['s_per_step'], 'ligands_per_s': rj['ligands_per_s_per_1000_step_ligand'],
+                                'reference_over_port_same_host': rj.get('port_same_inputs', {}).get('reference_over_port')}
+        res['sample'] += (f"; the REAL reference on the build container's {rj['threads']} threads: config 1 in full in "
+                          f"{rj['wall_s']:.0f} s ({rj['s_per_step']:.2f} s/step)")
     return res
 
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
+    'td_debug_wg_trace': (c_int32, [_P, c_int32]),
     'td_profile_begin': (c_int32, [ctypes.c_uint32]),
     'td_profile_end': (c_int32, [POINTER(c_float), POINTER(c_int32), c_int32]),
 }

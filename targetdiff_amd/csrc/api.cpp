@@ -492,7 +492,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0};
+                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing != 0};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
@@ -524,6 +524,10 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     else if (strcmp(name, "node_proj_split") == 0) {
         m->opt.node_proj_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+    } else if (strcmp(name, "edge_row_dealing") == 0) {
+        m->opt.edge_row_dealing = value != 0;
+        for (int l = 0; l < m->cfg.num_layers; ++l)
+            m->layers[l].hk.deal_rows = m->layers[l].hv.deal_rows = m->layers[l].xk.deal_rows = m->layers[l].xv.deal_rows = value != 0;
     } else if (strcmp(name, "node_proj_bpipe") == 0) {
         m->opt.node_proj_bpipe = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.bpipe = m->layers[l].nodeH2x.bpipe = value != 0;
@@ -554,6 +558,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     else if (strcmp(name, "node_proj_split") == 0) *value = m->opt.node_proj_split;
     else if (strcmp(name, "node_proj_async") == 0) *value = m->opt.node_proj_async;
     else if (strcmp(name, "node_proj_bpipe") == 0) *value = m->opt.node_proj_bpipe;
+    else if (strcmp(name, "edge_row_dealing") == 0) *value = m->opt.edge_row_dealing;
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
@@ -1308,6 +1313,10 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
     }
     const TdLayer &L = m->layers[layer];
     return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, nullptr, 0x1f, d_P, d_q, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int td_debug_wg_trace(uint64_t *d_buf, int32_t slots) {
+    return td_set_wg_trace(reinterpret_cast<unsigned long long *>(d_buf), d_buf ? slots : 0);
 }
 
 extern "C" int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream) {

@@ -52,6 +52,8 @@ struct Args16 {
     // from the chunk counts: a hybrid ligand row has several times the chunks of a protein row)
     int cpn_p;
     int64_t lig_chunks;
+    int deal;                      // rows dealt round-robin inside an XCD's range (td_deal16; model option edge_row_dealing)
+    unsigned long long *trace;     // td_debug_wg_trace: (start, end) per workgroup of this launch, or nullptr
 };
 
 // contiguous share of `count` rows for block b of a (sub-)grid of G blocks
@@ -64,6 +66,23 @@ __device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *co
     const int64_t per = (count + G - 1) / G;
     begin = (int64_t)chunk * per;
     end = begin + per < count ? begin + per : count;
+}
+
+// Rows of a launch "dealt" to its workgroups: XCD x (workgroups b = x mod 8) still owns a contiguous range of the row list (its
+// L2 keeps that range's neighbourhood), but inside the range units of U consecutive rows (one per wave) go round-robin to the
+// XCD's workgroups instead of one contiguous share each.  A contiguous share is a third of one graph at C2, and shares differ
+// in how many of their rows see both source classes (twice the first-layer products): workgroup busy times spread by +-15 %
+// and the launch waits for the slowest (profiles/r03_wg_balance_c2.txt); dealt, every workgroup samples the whole range.
+// The wave's rows are first + wid + k * stride (k = 0, 1, ..) below end.
+__device__ __forceinline__ void td_deal16(int64_t count, int U, int64_t &first, int64_t &end, int64_t &stride, int G = gridDim.x,
+                                          int b = blockIdx.x) {
+    const int x = b & 7, r = G & 7, w = b >> 3;
+    const int c0 = x * (G >> 3) + (x < r ? x : r), nx = (G >> 3) + (x < r ? 1 : 0);
+    const int64_t per = (count + G - 1) / G;
+    const int64_t xb = (int64_t)c0 * per;
+    end = xb + (int64_t)nx * per < count ? xb + (int64_t)nx * per : count;
+    first = xb + (int64_t)w * U;
+    stride = (int64_t)nx * U;
 }
 
 // sum / max over the 4 lane groups g (lanes lo, lo+16, lo+32, lo+48), result in all four
@@ -406,8 +425,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
-    int64_t begin, end;
-    td_node_range16(a.count, a.count_ptr, begin, end);
+    if (a.trace && tid == 0) a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    int64_t begin, end, stride = WAVES;
+    if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, WAVES, begin, end, stride);
+    else td_node_range16(a.count, a.count_ptr, begin, end);
 
     // first layer of chunk c of dst node i: z^T in acc
     auto first_layer = [&](int64_t i, int64_t c, floatx4_t (&acc)[2][8], Edge2 &ed) {
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
 
-    for (int64_t it = begin + wid; it < end; it += WAVES) {
+    for (int64_t it = begin + wid; it < end; it += stride) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;           // dst node
         int64_t c0 = i;
         int nch = 1;
@@ -557,6 +578,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                 dst[16] = __expf(x1 - mrun[r]) * inv[r] * ew1;
             }
         }
+    }
+    if (a.trace) {
+        __syncthreads();
+        if (tid == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -770,16 +795,27 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    auto trace_end = [&]() {
+        if (a.trace) {
+            __syncthreads();
+            if (tid == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
 
     // Software pipeline over the wave's rows: the neighbour indices of row n + 1 are fetched at the top of row n, and its
     // gathers (32 neighbour projections straight into the accumulator registers, which are free once Zbar is done) are
     // issued before row n's output GEMV, so that they land while it runs.
     // The wave's candidates: entries scan + 8 t (t = 0, 1, ..) of `list` (nullptr: the identity), below `end`.
     const int32_t *list = a.rows;
-    int64_t scan, end;
-    if (!SPLIT) td_node_range16(a.count, a.count_ptr, scan, end);
-    else if (my_cls) td_node_range16(n_rows, nullptr, scan, end, GP, (int)blockIdx.x);
-    else {
+    int64_t scan, end, stride = V16_WAVES;
+    if (!SPLIT) {
+        if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, V16_WAVES, scan, end, stride);
+        else td_node_range16(a.count, a.count_ptr, scan, end);
+    } else if (my_cls) {
+        if (a.deal) td_deal16(n_rows, V16_WAVES, scan, end, stride, GP, (int)blockIdx.x);
+        else td_node_range16(n_rows, nullptr, scan, end, GP, (int)blockIdx.x);
+    } else {
         list = a.lig_rows;
         const int64_t per = (a.lig_count + GL - 1) / GL;
         scan = ((int)blockIdx.x - GP) * per;
@@ -793,7 +829,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         if (!SPLIT) {
             if (scan >= end) return -1;
             const int64_t r = row_id(scan);
-            scan += V16_WAVES;
+            scan += stride;
             return r;
         }
         while (true) {
@@ -803,8 +839,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 return (int64_t)__builtin_amdgcn_readlane(cand, t);
             }
             if (scan >= end) return -1;
-            const int64_t idx = scan + (int64_t)V16_WAVES * lane;
-            scan += V16_WAVES * 64;
+            const int64_t idx = scan + stride * lane;
+            scan += stride * 64;
             bool mine = false;
             cand = 0;
             if (idx < end) {
@@ -889,6 +925,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
             }
         }
+        trace_end();
         return;
     }
     int64_t i = next_row();
@@ -972,6 +1009,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
     }
+    trace_end();
 }
 
 // ================================================================================================ edge gate
@@ -1084,6 +1122,21 @@ static int grid16(int64_t count, int waves) {
     return (int)(g < 1 ? 1 : g);
 }
 
+// td_debug_wg_trace: per-workgroup (start, end) stamps of the x2h key / value launches
+static unsigned long long *g_wg_trace = nullptr;
+static int g_wg_trace_slots = 0, g_wg_trace_launch[2] = {0, 0};
+int td_set_wg_trace(unsigned long long *buf, int slots) {
+    g_wg_trace = slots > 0 ? buf : nullptr;
+    g_wg_trace_slots = slots;
+    g_wg_trace_launch[0] = g_wg_trace_launch[1] = 0;
+    return TD_OK;
+}
+static unsigned long long *wg_trace_slot(int pass) {
+    if (!g_wg_trace) return nullptr;
+    const int n = g_wg_trace_launch[pass]++ % g_wg_trace_slots;
+    return g_wg_trace + ((size_t)n * 2 + pass) * 256 * 2;
+}
+
 // cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
@@ -1094,6 +1147,8 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     a.cptr = cptr;
     const bool h2x = rows && !count_ptr;      // h2x key pass (ligand row list of known length): STAGE tag 1
+    if (!h2x) a.trace = wg_trace_slot(0);
+    a.deal = mlp.deal_rows && !h2x;
 #define TD_KEY_LAUNCH(WAVES, STAGE, CH, SP, BYTES)                                                            \
     do {                                                                                                      \
         TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
@@ -1147,6 +1202,8 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr; a.cpn_p = cpn_p > 0 ? cpn_p : 1; a.lig_chunks = lig_chunks;
     int G = grid16(count, V16_WAVES);
     const dim3 block(V16_WAVES * 64);
+    a.trace = wg_trace_slot(1);
+    a.deal = mlp.deal_rows;
     if (mlp.use_split) {
         a.lig_rows = lig_rows; a.lig_count = lig_rows ? lig_count : 0;
         if (G < 2 && a.lig_count > 0) G = 2;       // a workgroup for each destination class
