@@ -23,7 +23,6 @@ pytestmark = pytest.mark.gpu
 TOL_TRAJ = 5e-5
 TOL_STEP = 2e-5
 TOL_LOGP = 2e-4
-TOL_DRIFT = 2e-2     # free-running 1000 steps on the real pocket (see test_real_pocket_1000_steps_vs_reference)
 
 
 def _dev():
@@ -87,7 +86,7 @@ def _one_step(model, batch, pos_in, v_in, t, step, base, dev):
     return pos_next + off[b.ligand_element_batch], v_next, log_v0, log_post
 
 
-def _check_trajectory(r, g, steps, what, tol_traj=TOL_TRAJ):
+def _check_trajectory(r, g, steps, what):
     pos = torch.stack(r['pos_traj']).numpy()
     v = torch.stack(r['v_traj']).numpy()
     same_v = (v == g['v_traj'].astype(np.int64)).all(axis=1)
@@ -96,11 +95,9 @@ def _check_trajectory(r, g, steps, what, tol_traj=TOL_TRAJ):
     print(f'{what}: max |dx| over {steps} steps = {dx.max():.3e} (step {int(dx.argmax())}), last step {dx[-1]:.3e}, '
           f'first type flip: {first_flip}')
     assert first_flip is None, f'{what}: atom types differ from the reference at step {first_flip}'
-    assert dx.max() <= tol_traj, f'{what}: |dx| = {dx.max():.3e} at step {int(dx.argmax())}'
+    assert dx.max() <= TOL_TRAJ, f'{what}: |dx| = {dx.max():.3e} at step {int(dx.argmax())}'
     assert np.array_equal(r['v'].cpu().numpy(), g['v'].astype(np.int64))
-    assert _maxdiff(r['pos'], g['pos']) <= tol_traj
-    if tol_traj > TOL_TRAJ:
-        return          # a drifting free run: the per-step log-probabilities are held by the teacher-forced test
+    assert _maxdiff(r['pos'], g['pos']) <= TOL_TRAJ
     for j, s in enumerate(g['kept_steps']):
         assert _maxdiff(r['v0_traj'][int(s)], g['v0_traj'][j]) <= TOL_LOGP, (what, 'v0', int(s))
         # log-posteriors of impossible classes sit near log(1e-30): compare in probability space there
@@ -195,20 +192,22 @@ def test_real_pocket_1000_steps_vs_reference(model):
     batch = workloads.pack_samples(pocket, 2, g['sizes'])
     init = torch.from_numpy(g['init_ligand_pos']), torch.from_numpy(g['init_ligand_v'].astype(np.int64))
     r = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev)
-    # All 70,000 sampled atom types must equal the reference's.  Positions: a free run at real-pocket density amplifies fp32
-    # round-off along the way (the restatement on the CPU, same arithmetic in another summation order, drifts from the
-    # reference by the same order of magnitude: tests/golden/README "drift"); first 100 steps within the usual tolerance, the
-    # whole run within TOL_DRIFT.  The per-step arithmetic of the late steps is held tight by the teacher-forced test below.
-    pos = torch.stack(r['pos_traj']).numpy()
-    assert np.abs(pos[:100].astype(np.float64) - g['pos_traj'][:100]).max() <= TOL_TRAJ
-    _check_trajectory(r, g, 1000, '1h36 x 2, 1000 steps (session)', tol_traj=TOL_DRIFT)
+    # all 70,000 sampled atom types equal and |dx| <= 5e-5 A over the whole run (measured 2.7e-5 at the last step; the CPU
+    # restatement's own free run ends 1.9e-5 from the reference).  This needs the protein centroid bit-identical to the
+    # reference's CPU path (center_kernel sums in index order): with a tree-reduced centroid the centred coordinates differ in
+    # the last bit, one near-tie of the k-NN search at step 424 falls the other way (a 2.5e-4 A jump for one atom) and the run
+    # ends 5.5e-3 A away -- the k-NN graph is discontinuous in the coordinates, so nothing larger than rounding may enter them.
+    _check_trajectory(r, g, 1000, '1h36 x 2, 1000 steps (session)')
     r2 = _free_run(model, batch, *init, 1000, int(g['draws_base']), dev, use_session=False)
     assert torch.equal(torch.stack(r['pos_traj']), torch.stack(r2['pos_traj']))
     assert torch.equal(torch.stack(r['v_traj']), torch.stack(r2['v_traj']))
 
 
 def test_real_pocket_teacher_forced_steps_vs_reference(model):
-    """Every 50th step and the last 12 (t = 11 .. 0) of that run, each started from the reference's own recorded state."""
+    """Every 50th step and the last 12 (t = 11 .. 0) of that run, each started from the reference's own recorded state.
+    (The recorded states are de-centred fp32 positions: re-centring them perturbs the coordinates by up to an ulp of the 30 A
+    offset, 3.8e-6 A, which is why single steps are compared at 2e-5 and not at the free run's internal precision; of all
+    999 steps exactly one -- step 424, not in the kept set -- sits on a k-NN near-tie that this perturbation flips.)"""
     from targetdiff_amd import workloads
     dev = _dev()
     g = _golden_or_skip('sample_1h36x2_1000.npz')
