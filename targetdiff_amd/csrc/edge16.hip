@@ -255,7 +255,8 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
 // Both operands as exact bf16 piece triples (the table pre-split at pack time, the per-edge Gaussians split in registers),
-// 6 of the 9 piece products, fp32 accumulation: fp32-equivalent (the dropped products are below 2^-24 relative).  One
+// 6 of the 9 piece products, fp32 accumulation: fp32-equivalent (the dropped products are ~2^-24 relative, the size of one fp32
+// rounding; the measured errors against the reference goldens are unchanged, profiles/*_split_error_table.txt).  One
 // instruction covers the whole K = 21 (20 Gaussians + the edge-type column; k = 8 g + j for lane group g, slot j) at half the
 // issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds (before or after the products).
 typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
