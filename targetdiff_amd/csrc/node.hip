@@ -315,9 +315,16 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
         for (int u = tid; u < NPS_BIAS_FLOATS; u += blockDim.x) sbias[u] = u < 5 * TD_H ? st.projBias[u] : st.q3Bias[u - 5 * TD_H];
     }
     uint4 ap[3][8];
+    // Node ids of the rows a lane stores, taken once from the A-tile lanes (lane c holds the id of tile row c; -1 beyond the
+    // segment's rows) by lane exchange.  Fetched from the row list at store time (rounds 1-2), every one of the 16 loads sat in
+    // front of the two stores whose addresses it produces, and its s_waitcnt vmcnt(0) also waited for the previous pair of
+    // stores to be acknowledged: 7-10 k cycles per half-matrix epilogue on a row-list launch (in-kernel stamps, round 3).
+    int orow4[4];              // node id of tile row (lane >> 3) + 8 k: the rows this lane stores in every epilogue
     {
         const int64_t aslot = row0 + c;
         const int64_t arow = aslot < N ? (rows ? (int64_t)rows[aslot] : aslot) : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) orow4[k] = __shfl((int)arow, (lane >> 3) + 8 * k);
         float4 a[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m)
@@ -399,15 +406,19 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
             }
             // ---- epilogue of this half: columns 64 * half .. + 63
             if (mat != 4) {
-                float *out = mat < 4 ? P + mat * TD_H + 64 * half + c : q + 64 * half + c;
+                // 32 x 32 tile at a time through the wave-private LDS tile: C layout in (a register row per store would be 32
+                // dword stores of 2 x 128 B per half-matrix), rows out -- each lane stores 16 contiguous bytes, a wave
+                // instruction 8 full 128-byte row segments: 8 stores per half-matrix
+                float *out = mat < 4 ? P + mat * TD_H + 64 * half : q + 64 * half;
                 const size_t ld = mat < 4 ? (size_t)(4 * TD_H) : (size_t)TD_H;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int slot = (int)row0 + td_erow(r, hi);
-                    const int orow = slot < N ? (rows ? rows[slot] : slot) : -1;
-                    if (orow >= 0) {
-                        out[(size_t)orow * ld] = acc[0][r];
-                        out[(size_t)orow * ld + 32] = acc[1][r];
+                for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tb[td_erow(r, hi) * NP_TSTRIDE + c] = acc[t][r];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 v = *reinterpret_cast<const float4 *>(tb + ((lane >> 3) + 8 * k) * NP_TSTRIDE + 4 * (lane & 7));
+                        if (orow4[k] >= 0) *reinterpret_cast<float4 *>(out + (size_t)orow4[k] * ld + 32 * t + 4 * (lane & 7)) = v;
                     }
                 }
             } else if (half == 0) {
