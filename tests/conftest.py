@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle's small torch-CPU ops do not scale past a few threads, and on an 8-vCPU container 8 OpenMP threads next to
+    # the launcher tests' child processes degrade into spinning (the CPU suite then takes 6 min instead of 1.5): cap at 4.
+    torch.set_num_threads(max(1, min(4, os.cpu_count() or 1)))
 
 
 def load_golden(name):

@@ -21,7 +21,6 @@ def _maxdiff(a, b):
 def ref_model():
     from oracle import make_golden
     ref = reference_loader.load()
-    torch.set_num_threads(8)
     model, sd = make_golden.build_reference_model(ref, seed=77)
     return ref, model, sd
 
