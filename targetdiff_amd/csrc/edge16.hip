@@ -851,15 +851,19 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             todo = __ballot(mine);
         }
     };
-    auto load_side = [&](int64_t ix, float (&alx)[8], float &h0, float &h1) {
+    // chunk of a single-chunk row (the pipelined loop below): the node itself on the default graph, cptr[i] on a general one
+    auto chunk_of = [&](int64_t ix) -> int64_t { return CHUNKED ? (int64_t)a.cptr[ix] : ix; };
+    auto load_side = [&](int64_t ix, int64_t cx, float (&alx)[8], float &h0, float &h1) {
         // A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads); residual row
-        const float *ap = a.alpha + ((size_t)ix * TD_HEADS + lo) * TD_K + 8 * g;
+        const float *ap = a.alpha + ((size_t)cx * TD_HEADS + lo) * TD_K + 8 * g;
         const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
         alx[0] = v0.x; alx[1] = v0.y; alx[2] = v0.z; alx[3] = v0.w; alx[4] = v1.x; alx[5] = v1.y; alx[6] = v1.z; alx[7] = v1.w;
         h0 = a.h[(size_t)ix * TD_H + lane];
         h1 = a.h[(size_t)ix * TD_H + 64 + lane];
     };
-    if constexpr (CHUNKED) {
+    // General graphs: the protein workgroups of a graph whose protein rows are one chunk wide (`hybrid`: plain k-NN rows, k <= 32)
+    // take the software-pipelined single-chunk loop below (chunk index through cptr); everything else walks chunks here.
+    if (CHUNKED && !(SPLIT && my_cls == 1 && a.cpn_p == 1)) {
         for (int64_t i = next_row(); i >= 0; i = next_row()) {
             const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
             const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
@@ -934,15 +938,17 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     floatx4_t acc[2][8];
     float al[8], hres0 = 0.f, hres1 = 0.f;
     if (i >= 0) {
-        td_row_index16(a, i, i, lane, rin);
-        td_row_gather16<false>(a, i, i, lane, rin, acc);
-        load_side(i, al, hres0, hres1);
+        const int64_t ci = chunk_of(i);
+        td_row_index16(a, i, ci, lane, rin);
+        td_row_gather16<false>(a, i, ci, lane, rin, acc);
+        load_side(i, ci, al, hres0, hres1);
     }
     while (i >= 0) {
         const int64_t inext = next_row();
         const bool more = inext >= 0;
         RowIn16 rnext;
-        if (more) td_row_index16(a, inext, inext, lane, rnext);
+        const int64_t cnext = more ? chunk_of(inext) : 0;
+        if (more) td_row_index16(a, inext, cnext, lane, rnext);
         Edge2 ed;
         if constexpr (SPLIT)
             td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
@@ -981,8 +987,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         const int64_t icur = i;
         const float hcur0 = hres0, hcur1 = hres1;
         if (more) {
-            td_row_gather16<false>(a, inext, inext, lane, rnext, acc);
-            load_side(inext, al, hres0, hres1);
+            td_row_gather16<false>(a, inext, cnext, lane, rnext, acc);
+            load_side(inext, cnext, al, hres0, hres1);
             rin = rnext;
         }
         i = inext;
