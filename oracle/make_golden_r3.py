@@ -15,6 +15,8 @@ The C5 sweep at C5 size and late-t geometry on the real pocket:
   sample_1h36x2_hybrid_20
                       20 reverse steps (t = 999 .. 980) of the reference's own loop on 1h36 x 2 with cutoff_mode = 'hybrid'
                       and the counter draws: sampling on a general graph against the reference, not the restatement.
+  forward_other_weights
+                      forward_small_seed7 / seed11: the small batch under two other seeded weight sets (gain 1.8 / 0.5).
   sample_1h36x2_1000  a complete 1000-step run of the reference on the real pocket (1h36 x 2, prior sizes, k = 32) with the
                       counter draws: late-t arithmetic at real-pocket density against the session caching.  Every step's
                       positions / types, the log-probabilities of every 50th step and of the last 12.
@@ -149,9 +151,31 @@ def gen_sample_1h36x2_1000(ref, model):
     print(f'sample_1h36x2_1000: N_l = {lpos.shape[0]}, 1000 steps in {time.time() - t0:.0f} s')
 
 
+OTHER_WEIGHTS = [(7, 1.8), (11, 0.5)]
+
+
+def gen_forward_other_weights(ref, model):
+    """The small 3-graph batch under other seeded weight sets of the REAL reference (another seed with a stronger
+    non-linearity / larger coordinate updates, another with a weaker one): parity must not hang on the one weight set."""
+    from .make_golden import small_batch
+    b, lpos, lv = small_batch()
+    for seed, gain in OTHER_WEIGHTS:
+        m = ref.ScorePosNet3D(shims.EasyDict(dict(weights.DEFAULT_MODEL_CONFIG)), weights.PROTEIN_FEATURE_DIM, weights.LIGAND_FEATURE_DIM)
+        res = m.load_state_dict(weights.make_state_dict(seed, gain=gain), strict=False)
+        assert not res.unexpected_keys
+        m.eval()
+        ppos, lpos_c, preds, inter = ref_forward_with_intermediates(ref, m, b, lpos, lv)
+        _save(os.path.join(GOLDEN_DIR, f'forward_small_seed{seed}.npz'), seed=np.int64(seed), gain=np.float64(gain),
+              protein_pos_centred=ppos.numpy(), ligand_pos=lpos_c.numpy(), ligand_v=lv.numpy().astype(np.int8),
+              pred_ligand_pos=preds['pred_ligand_pos'].numpy(), pred_ligand_v=preds['pred_ligand_v'].numpy(),
+              final_h=preds['final_h'].numpy())
+        print(f'forward_small_seed{seed}: gain {gain}, max |h| {float(preds["final_h"].abs().max()):.2f}')
+
+
 GENERATORS = {'forward_c5_k48': gen_forward_c5_k48, 'forward_c5_k64': gen_forward_c5_k64,
               'forward_c5_hybrid': gen_forward_c5_hybrid, 'forward_c5_radius': gen_forward_c5_radius,
-              'sample_1h36x2_hybrid_20': gen_sample_1h36x2_hybrid_20, 'sample_1h36x2_1000': gen_sample_1h36x2_1000}
+              'sample_1h36x2_hybrid_20': gen_sample_1h36x2_hybrid_20, 'sample_1h36x2_1000': gen_sample_1h36x2_1000,
+              'forward_other_weights': gen_forward_other_weights}
 
 
 def main():

@@ -356,26 +356,30 @@ def test_sampling_with_fp32_edge_first_layer(state_dict):
 
 
 @pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
-def test_forward_other_weight_scales_vs_oracle(seed, gain):
+def test_forward_other_weight_scales_vs_reference(seed, gain):
     """Parity must not depend on the one seeded weight set the fixtures use: other seeds and weight scales (stronger /
-    weaker non-linearity, larger coordinate updates) against the oracle restatement."""
+    weaker non-linearity, larger coordinate updates) against the REAL reference's outputs (forward_small_seed*.npz,
+    oracle/make_golden_r3.py) and, beside it, the oracle restatement."""
     from oracle import restatement as R
     from oracle import weights
     from oracle.make_golden import small_batch
     dev = _dev()
+    g = load_golden(f'forward_small_seed{seed}.npz')
+    assert float(g['gain']) == gain
     sd = weights.make_state_dict(seed, gain=gain)
     model = _model(sd)
     b, lpos, lv = small_batch()
-    ppos, lpos_c, _ = R.center_positions(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch)
-    want = R.model_forward(sd, None, ppos, b.protein_atom_feature.float(), b.protein_element_batch, lpos_c, lv, b.ligand_element_batch)
+    ppos, lpos_c = torch.from_numpy(g['protein_pos_centred']), torch.from_numpy(g['ligand_pos'])
     got = model(ppos.to(dev), b.protein_atom_feature.float().to(dev), b.protein_element_batch.to(dev), lpos_c.to(dev), lv.to(dev),
                 b.ligand_element_batch.to(dev))
-    scale = max(1.0, float(want['final_h'].abs().max()))
-    print(f'seed {seed} gain {gain}: |dx| {_maxdiff(got["pred_ligand_pos"], want["pred_ligand_pos"]):.2e}  '
-          f'|dh| {_maxdiff(got["final_h"], want["final_h"]):.2e} (max |h| {scale:.1f})')
-    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= TOL_X * scale
+    scale = max(1.0, float(np.abs(g['final_h']).max()))
+    print(f'seed {seed} gain {gain}: vs reference |dx| {_maxdiff(got["pred_ligand_pos"], g["pred_ligand_pos"]):.2e}  '
+          f'|dh| {_maxdiff(got["final_h"], g["final_h"]):.2e} (max |h| {scale:.1f})')
+    assert _maxdiff(got['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X * scale
+    assert _maxdiff(got['final_h'], g['final_h']) <= TOL_H * scale
+    assert _maxdiff(got['pred_ligand_v'], g['pred_ligand_v']) <= TOL_H * scale
+    want = R.model_forward(sd, None, ppos, b.protein_atom_feature.float(), b.protein_element_batch, lpos_c, lv, b.ligand_element_batch)
     assert _maxdiff(got['final_h'], want['final_h']) <= TOL_H * scale
-    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= TOL_H * scale
 
 
 @pytest.mark.parametrize('sizes', [[(1, 1)], [(3, 2)], [(1, 1), (40, 1), (2, 9)], [(33, 1), (1, 30)], [(200, 24)] * 3])

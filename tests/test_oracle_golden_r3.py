@@ -85,3 +85,17 @@ def test_restatement_real_pocket_late_steps_vs_reference(state_dict):
         assert np.array_equal(v.numpy(), g['v_traj'][s].astype(np.int64)), s
         assert np.max(np.abs(pos.numpy() - g['pos_traj'][s])) < 2e-5, s
         assert np.max(np.abs(log_v0.numpy() - g['v0_traj'][kept[s]])) < 2e-4
+
+
+@pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
+def test_restatement_other_weight_sets_vs_reference(seed, gain):
+    """The small batch under two other seeded weight sets of the real reference (stronger / weaker non-linearity)."""
+    from oracle import weights
+    from oracle.make_golden import small_batch
+    g = load_golden(f'forward_small_seed{seed}.npz')
+    b, _, lv = small_batch()
+    sd = weights.make_state_dict(seed, gain=gain)
+    preds = R.model_forward(sd, None, torch.from_numpy(g['protein_pos_centred']), b.protein_atom_feature.float(), b.protein_element_batch,
+                            torch.from_numpy(g['ligand_pos']), lv, b.ligand_element_batch)
+    assert np.max(np.abs(preds['pred_ligand_pos'].numpy() - g['pred_ligand_pos'])) < 2e-5
+    assert np.max(np.abs(preds['final_h'].numpy() - g['final_h'])) < 2e-4
