@@ -492,7 +492,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing != 0};
+                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
@@ -525,9 +525,9 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         m->opt.node_proj_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
     } else if (strcmp(name, "edge_row_dealing") == 0) {
-        m->opt.edge_row_dealing = value != 0;
+        m->opt.edge_row_dealing = value < 0 ? 0 : (value > 2 ? 2 : value);
         for (int l = 0; l < m->cfg.num_layers; ++l)
-            m->layers[l].hk.deal_rows = m->layers[l].hv.deal_rows = m->layers[l].xk.deal_rows = m->layers[l].xv.deal_rows = value != 0;
+            m->layers[l].hk.deal_rows = m->layers[l].hv.deal_rows = m->layers[l].xk.deal_rows = m->layers[l].xv.deal_rows = m->opt.edge_row_dealing;
     } else if (strcmp(name, "node_proj_bpipe") == 0) {
         m->opt.node_proj_bpipe = value != 0;
         for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.bpipe = m->layers[l].nodeH2x.bpipe = value != 0;
@@ -607,8 +607,9 @@ struct GraphTab {
     float *ew, *alpha;
     int cpn_p;               // chunks per protein row
     int64_t NCl;             // chunks of all ligand rows together
+    const int32_t *mixed;    // device count of the rows that see both source classes (a session's dirty rows), or nullptr
 };
-GraphTab default_tab(Workspace &w) { return GraphTab{nullptr, w.nbr, w.ew, w.alpha, 1, 0}; }
+GraphTab default_tab(Workspace &w) { return GraphTab{nullptr, w.nbr, w.ew, w.alpha, 1, 0, nullptr}; }
 
 int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const float *ew, const int32_t *nbr,
              const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
@@ -619,7 +620,7 @@ int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const G
                const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig,
                int64_t Nl, hipStream_t s) {
     return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s, gt.cptr, gt.cpn_p,
-                                  lig ? gt.NCl : 0);
+                                  lig ? gt.NCl : 0, gt.mixed);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
@@ -801,7 +802,7 @@ int plan_layout(GraphPlan &p, const int32_t *node_ptr, const int32_t *gid, hipSt
                             p.chunk_node, p.lig_chunks, (int32_t)p.NC, s);
 }
 
-GraphTab plan_tab(const GraphPlan &p) { return GraphTab{p.cptr, p.cnbr, p.ew, p.alpha, p.cpn_p, p.NCl}; }
+GraphTab plan_tab(const GraphPlan &p) { return GraphTab{p.cptr, p.cnbr, p.ew, p.alpha, p.cpn_p, p.NCl, nullptr}; }
 
 // graph + edge gate of a composed batch on a general graph (chunked table of the plan)
 int build_general_graph(const td_model *m, GraphPlan &p, Workspace &w, int64_t N, int64_t Nl, int max_graph_nodes, hipStream_t s) {
@@ -1360,7 +1361,11 @@ struct td_session {
 namespace {
 constexpr int TD_STEP_LISTS_MAX_NODES = 12288;       // LDS flags of step_lists_kernel: 4 bytes per node of a graph, 48 KiB
 
-GraphTab session_tab(td_session *S) { return S->chunked ? plan_tab(S->plan) : default_tab(S->w); }
+GraphTab session_tab(td_session *S) {
+    GraphTab gt = S->chunked ? plan_tab(S->plan) : default_tab(S->w);
+    if (S->caching) gt.mixed = S->dirty_count;
+    return gt;
+}
 
 void session_free(td_session *S, hipStream_t s) {
     if (!S) return;

@@ -52,9 +52,22 @@ struct Args16 {
     // from the chunk counts: a hybrid ligand row has several times the chunks of a protein row)
     int cpn_p;
     int64_t lig_chunks;
+    // value pass: device count of the rows that see both source classes (a session's dirty rows: the protein rows with a ligand atom
+    // among their neighbours + the ligand rows), or nullptr (a typical share is assumed)
+    const int32_t *mixed_count;
     int deal;                      // rows dealt round-robin inside an XCD's range (td_deal16; model option edge_row_dealing)
-    unsigned long long *trace;     // td_debug_wg_trace: (start, end) per workgroup of this launch, or nullptr
+    unsigned long long *trace;     // td_debug_wg_trace: (start, end, first wave's end, sum of the waves' ends) per workgroup, or nullptr
 };
+
+// td_debug_wg_trace: a wave that has run out of rows leaves its end time (the earliest of the workgroup in slot 2, their sum in slot 3;
+// both slots zeroed by the host before the step)
+__device__ __forceinline__ void td_trace_wave_end(unsigned long long *trace, int lane) {
+    if (lane == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMin(trace + 4 * blockIdx.x + 2, t);
+        atomicAdd(trace + 4 * blockIdx.x + 3, t);
+    }
+}
 
 // contiguous share of `count` rows for block b of a (sub-)grid of G blocks
 __device__ __forceinline__ void td_node_range16(int64_t count, const int32_t *count_ptr, int64_t &begin, int64_t &end, int G = gridDim.x,
@@ -385,9 +398,9 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 // ================================================================================================ key pass
 constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, one LDS copy of the weights per CU
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
-constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
+constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H + 4) * sizeof(float);       // + the row counter
 constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
-constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H) * sizeof(float);
+constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H + 4) * sizeof(float);
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                        WAVES * 64);
         if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
+        else if (tid == 2 * TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H) = 0;
     }
     float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
 #pragma unroll
@@ -426,10 +440,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
-    if (a.trace && tid == 0) a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     int64_t begin, end, stride = WAVES;
-    if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, WAVES, begin, end, stride);
+    if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, a.deal == 2 ? 1 : WAVES, begin, end, stride);
     else td_node_range16(a.count, a.count_ptr, begin, end);
+    // a.deal == 2: single rows are dealt to the XCD's workgroups (row counts differ by at most one; with units of one row per wave
+    // a workgroup had 15 or 16 units of 12 rows) and handed to the workgroup's waves one at a time through an LDS counter -- the
+    // waves that share a SIMD do not progress at the same rate (the first of a workgroup's 12 is done a third of the launch before
+    // the last, tools/wg_balance.py), and a SIMD left with one wave no longer hides its gathers
+    int *row_ctr = reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H);
+    const bool dyn = a.deal == 2;
+    auto grab = [&]() -> int {
+        int n = 0;
+        if (lane == 0) n = __hip_atomic_fetch_add(row_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return n;
+    };
+    auto row_of = [&](int n) -> int64_t {       // n-th row of the workgroup
+        return begin + (int64_t)__builtin_amdgcn_readfirstlane(n) * stride;
+    };
 
     // first layer of chunk c of dst node i: z^T in acc
     auto first_layer = [&](int64_t i, int64_t c, floatx4_t (&acc)[2][8], Edge2 &ed) {
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
 
-    for (int64_t it = begin + wid; it < end; it += stride) {
+    for (int64_t it = dyn ? row_of(grab()) : begin + wid; it < end; it = dyn ? row_of(grab()) : it + stride) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;           // dst node
         int64_t c0 = i;
         int nch = 1;
@@ -581,8 +609,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         }
     }
     if (a.trace) {
+        td_trace_wave_end(a.trace, lane);
         __syncthreads();
-        if (tid == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) a.trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -737,9 +766,9 @@ constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidde
 constexpr int V16_ZB_STRIDE = 132;
 constexpr int V16_WAVE_FLOATS = 2 * 32 * V16_TB_STRIDE;   // 1280 >= 8 * 132: two transpose tiles, later the Zbar half
 constexpr size_t V16_LDS_BYTES =
-    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
+    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
-    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H) * sizeof(float);
+    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
 // (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
@@ -749,7 +778,11 @@ constexpr size_t V16S_LDS_BYTES =
 // the ligand count so that both kinds finish together: a ligand row costs about 1.25 protein rows (both source classes in
 // its first layer).
 // A wave looks at 64 candidate rows at a time (lane t reads the class of candidate t) and walks the ones of its class.
-constexpr int TD_LIG_ROW_COST_X4 = 5;      // 1.25, in quarters (measured: 8.7 us against 7.0 us per row and wave at C2)
+// Row costs (relative): a row whose neighbours are of one source class, and a row that sees both (every ligand row; the protein rows
+// with a ligand atom among their neighbours).  Measured on the workgroup traces (tools/wg_balance.py --detail): with every row priced
+// alike the ligand workgroups took 1.15 x the protein ones on the full-size lists (28 % mixed protein rows) and 1.0 x on the dirty-row
+// list of layer 0 and the level-1 list of the last layer (all mixed).
+constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // CHUNKED = true (general graphs): a dst node's in-edges are the chunks cptr[i] .. cptr[i+1]-1; alpha (already normalised over
 // the whole node and gated by the key pass) is indexed by chunk; Zbar accumulates over the chunks, then one output product.
 template <bool SPLIT, bool CHUNKED = false>
@@ -772,7 +805,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         n_rows = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
         const int64_t G = gridDim.x, nl = a.lig_count, np = n_rows > nl ? n_rows - nl : 0;
         if (nl > 0) {
-            const int64_t wl = TD_LIG_ROW_COST_X4 * (CHUNKED ? a.lig_chunks : nl), wp = 4 * (CHUNKED ? np * a.cpn_p : np);
+            // protein rows with a ligand neighbour (at most those in the list) run the first layer for both source classes, as a
+            // ligand row does
+            int64_t nm = a.mixed_count ? (int64_t)*a.mixed_count - nl : (np * 3) / 10;
+            nm = nm < 0 ? 0 : (nm > np ? np : nm);
+            const int64_t cp = CHUNKED ? a.cpn_p : 1;
+            const int64_t wl = TD_ROW_COST_MIXED * (CHUNKED ? a.lig_chunks : nl), wp = cp * (TD_ROW_COST_PURE * (np - nm) + TD_ROW_COST_MIXED * nm);
             GL = (int)((wl * G + (wl + wp) / 2) / (wl + wp));
             const int cap = (int)G - (np > 0 ? 1 : 0);
             GL = GL < 1 ? 1 : (GL > cap ? cap : GL);
@@ -788,6 +826,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
         else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
         else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
+        else if (tid == 3 * TD_H) *reinterpret_cast<int *>(B2 + 3 * TD_H) = 0;
     }
     float offk[NOFF];
 #pragma unroll
@@ -796,11 +835,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
-    if (a.trace && tid == 0) a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     auto trace_end = [&]() {
         if (a.trace) {
+            td_trace_wave_end(a.trace, lane);
             __syncthreads();
-            if (tid == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) a.trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         }
     };
 
@@ -811,10 +851,10 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     const int32_t *list = a.rows;
     int64_t scan, end, stride = V16_WAVES;
     if (!SPLIT) {
-        if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, V16_WAVES, scan, end, stride);
+        if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, a.deal == 2 ? 1 : V16_WAVES, scan, end, stride);
         else td_node_range16(a.count, a.count_ptr, scan, end);
     } else if (my_cls) {
-        if (a.deal) td_deal16(n_rows, V16_WAVES, scan, end, stride, GP, (int)blockIdx.x);
+        if (a.deal) td_deal16(n_rows, a.deal == 2 ? 1 : V16_WAVES, scan, end, stride, GP, (int)blockIdx.x);
         else td_node_range16(n_rows, nullptr, scan, end, GP, (int)blockIdx.x);
     } else {
         list = a.lig_rows;
@@ -822,11 +862,24 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         scan = ((int)blockIdx.x - GP) * per;
         end = scan + per < a.lig_count ? scan + per : a.lig_count;
     }
-    scan += wid;
+    // a.deal == 2 (not the ligand workgroups, whose 8-row shares are static): single rows dealt to the XCD's workgroups, and the
+    // workgroup's rows go to its waves one at a time through an LDS counter (see edge_key16_kernel).  A protein workgroup then meets the ligand rows of its share as candidates:
+    // `of_class` below drops them once the candidate's x4 entry -- loaded anyway -- has arrived.
+    const bool dyn = a.deal == 2 && (!SPLIT || my_cls == 1);
+    const int64_t first = scan;
+    if (!dyn) scan += wid;
+    int *row_ctr = reinterpret_cast<int *>(B2 + 3 * TD_H);
     auto row_id = [&](int64_t itx) -> int64_t { return list ? (int64_t)list[itx] : itx; };
     int cand = 0;                      // SPLIT: lane t = row id of candidate t of the current window
     unsigned long long todo = 0ull;    // SPLIT: candidates of the window still to do
     auto next_row = [&]() -> int64_t {
+        if (dyn) {
+            int n = 0;
+            if (lane == 0) n = __hip_atomic_fetch_add(row_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            n = __builtin_amdgcn_readfirstlane(n);
+            const int64_t itx = first + (int64_t)n * stride;
+            return itx < end ? row_id(itx) : -1;
+        }
         if (!SPLIT) {
             if (scan >= end) return -1;
             const int64_t r = row_id(scan);
@@ -851,6 +904,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             todo = __ballot(mine);
         }
     };
+    auto of_class = [&](const float4 &xi) -> bool {        // wave-uniform: the row's x4 entry is the same in every lane
+        return (__builtin_amdgcn_readfirstlane(__float_as_int(xi.w)) > __float_as_int(0.5f) ? 0 : 1) == my_cls;
+    };
     // chunk of a single-chunk row (the pipelined loop below): the node itself on the default graph, cptr[i] on a general one
     auto chunk_of = [&](int64_t ix) -> int64_t { return CHUNKED ? (int64_t)a.cptr[ix] : ix; };
     auto load_side = [&](int64_t ix, int64_t cx, float (&alx)[8], float &h0, float &h1) {
@@ -865,6 +921,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     // take the software-pipelined single-chunk loop below (chunk index through cptr); everything else walks chunks here.
     if (CHUNKED && !(SPLIT && my_cls == 1 && a.cpn_p == 1)) {
         for (int64_t i = next_row(); i >= 0; i = next_row()) {
+            if (SPLIT && dyn && !of_class(a.x4[i])) continue;
             const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
             const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
             floatx4_t zb[8];
@@ -933,22 +990,32 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         trace_end();
         return;
     }
-    int64_t i = next_row();
+    // next row of this workgroup's class with its index loads issued (dyn + SPLIT: candidates of the other class -- the ligand
+    // rows inside a protein workgroup's share, one in 25 -- are dropped here, at the price of one exposed load each)
+    auto next_indexed = [&](RowIn16 &r, int64_t &cx) -> int64_t {
+        int64_t ix = next_row();
+        if (ix >= 0) { cx = chunk_of(ix); td_row_index16(a, ix, cx, lane, r); }
+        return ix;
+    };
+    auto settle = [&](int64_t ix, RowIn16 &r, int64_t &cx) -> int64_t {
+        if (SPLIT && dyn)
+            while (ix >= 0 && !of_class(r.xi)) ix = next_indexed(r, cx);
+        return ix;
+    };
     RowIn16 rin;
+    int64_t ci = 0;
+    int64_t i = settle(next_indexed(rin, ci), rin, ci);
     floatx4_t acc[2][8];
     float al[8], hres0 = 0.f, hres1 = 0.f;
     if (i >= 0) {
-        const int64_t ci = chunk_of(i);
-        td_row_index16(a, i, ci, lane, rin);
         td_row_gather16<false>(a, i, ci, lane, rin, acc);
         load_side(i, ci, al, hres0, hres1);
     }
     while (i >= 0) {
-        const int64_t inext = next_row();
-        const bool more = inext >= 0;
         RowIn16 rnext;
-        const int64_t cnext = more ? chunk_of(inext) : 0;
-        if (more) td_row_index16(a, inext, cnext, lane, rnext);
+        int64_t cnext = 0;
+        int64_t inext = next_indexed(rnext, cnext);
+        bool more = inext >= 0;
         Edge2 ed;
         if constexpr (SPLIT)
             td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
@@ -986,6 +1053,10 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         // ---- next row: gathers into the (now free) accumulators, its alpha fragment and residual ---------------------
         const int64_t icur = i;
         const float hcur0 = hres0, hcur1 = hres1;
+        if (SPLIT && dyn && more) {
+            inext = settle(inext, rnext, cnext);
+            more = inext >= 0;
+        }
         if (more) {
             td_row_gather16<false>(a, inext, cnext, lane, rnext, acc);
             load_side(inext, cnext, al, hres0, hres1);
@@ -1129,7 +1200,7 @@ static int grid16(int64_t count, int waves) {
     return (int)(g < 1 ? 1 : g);
 }
 
-// td_debug_wg_trace: per-workgroup (start, end) stamps of the x2h key / value launches
+// td_debug_wg_trace: per-workgroup (start, end, first wave end, sum of wave ends) stamps of the x2h key / value launches
 static unsigned long long *g_wg_trace = nullptr;
 static int g_wg_trace_slots = 0, g_wg_trace_launch[2] = {0, 0};
 int td_set_wg_trace(unsigned long long *buf, int slots) {
@@ -1141,7 +1212,7 @@ int td_set_wg_trace(unsigned long long *buf, int slots) {
 static unsigned long long *wg_trace_slot(int pass) {
     if (!g_wg_trace) return nullptr;
     const int n = g_wg_trace_launch[pass]++ % g_wg_trace_slots;
-    return g_wg_trace + ((size_t)n * 2 + pass) * 256 * 2;
+    return g_wg_trace + ((size_t)n * 2 + pass) * 256 * 4;
 }
 
 // cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node
@@ -1155,7 +1226,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
     a.cptr = cptr;
     const bool h2x = rows && !count_ptr;      // h2x key pass (ligand row list of known length): STAGE tag 1
     if (!h2x) a.trace = wg_trace_slot(0);
-    a.deal = mlp.deal_rows && !h2x;
+    a.deal = h2x ? 0 : mlp.deal_rows;
 #define TD_KEY_LAUNCH(WAVES, STAGE, CH, SP, BYTES)                                                            \
     do {                                                                                                      \
         TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
@@ -1201,12 +1272,13 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            const int32_t *lig_rows, int64_t lig_count, hipStream_t s, const int32_t *cptr, int cpn_p,
-                           int64_t lig_chunks) {
+                           int64_t lig_chunks, const int32_t *mixed_count) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr; a.cpn_p = cpn_p > 0 ? cpn_p : 1; a.lig_chunks = lig_chunks;
+    a.mixed_count = mixed_count;
     int G = grid16(count, V16_WAVES);
     const dim3 block(V16_WAVES * 64);
     a.trace = wg_trace_slot(1);

@@ -62,7 +62,8 @@ struct TdEdgeMlp {
     const float *R16p;     // the radial/type table as bf16 piece triples for v_mfma_f32_16x16x32_bf16:
                            // [2 dst class][2 slot][3 piece][8 hidden block][48 lanes (k group g < 3)] x 8 bf16 (k = 8g + j)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
-    bool deal_rows;        // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing", default)
+    int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
+                           // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
 };
 
 // Node-side weights of one stage (x2h or h2x): 4 projections (k_i,k_j,v_i,v_j) + the query MLP.
@@ -133,8 +134,9 @@ struct TdOptions {
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
-    int edge_row_dealing = 1;      // x2h key / value passes: units of rows dealt round-robin to an XCD's workgroups (0: one
-                                   // contiguous share per workgroup)
+    int edge_row_dealing = 2;      // x2h key / value passes: units of rows dealt round-robin to an XCD's workgroups (0: one
+                                   // contiguous share per workgroup; 1: a fixed row sequence per wave; 2: the workgroup's rows
+                                   // handed to its waves one at a time through an LDS counter)
     int node_proj_bpipe = 0;       // split node GEMMs: register double-buffering of the B fragments (LDS reads ahead of the MFMAs; measured
                                    // slower at C2: 0.848 vs 0.817 ms per step, profiles/r03b_*; kept as a switch)
     int node_proj_async = 1;    // split node GEMMs: B chunks by inline-asm global_load_lds + an explicit wait per round (0: the builtin, which the compiler serialises)
@@ -233,7 +235,8 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
                         const int32_t *cptr = nullptr);
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig_rows, int64_t lig_count,
-                           hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0);
+                           hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0,
+                           const int32_t *mixed_count = nullptr);
 int td_set_wg_trace(unsigned long long *buf, int slots);
 // graph.hip, general graphs
 int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *g_cbase,

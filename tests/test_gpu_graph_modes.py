@@ -332,6 +332,34 @@ def test_model_options_live_in_the_handle(state_dict):
         assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
 
 
+def test_row_distribution_settings_are_bit_identical(state_dict):
+    """edge_row_dealing = 0 (contiguous shares) / 1 (dealt, fixed sequence per wave) / 2 (dealt, rows handed to the workgroup's waves
+    through an LDS counter; default): which wave runs a row changes nothing in its arithmetic.  32 pockets x 8 samples (83 k nodes:
+    every wave draws several rows), k-NN and hybrid graphs (32-slot and chunk-walking kernels), the stateless forward and two
+    session steps, bit for bit."""
+    from oracle.make_golden_r2 import c3_pockets
+    from targetdiff_amd import workloads
+    dev = _dev()
+    b = workloads.pack_samples(c3_pockets(), 8, [25] * 256)
+    lpos, lv = workloads.init_ligand(b, generator=torch.Generator().manual_seed(5), spread=2.0)
+    b = b.to(dev)
+    for cfg in ({}, {'cutoff_mode': 'hybrid'}):
+        outs = []
+        for deal in (2, 1, 0):
+            model = _model(state_dict, **cfg)
+            nat = model._native(dev)
+            assert nat.get_option('edge_row_dealing') == 2            # shipped default
+            nat.set_option('edge_row_dealing', deal)
+            o = model(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev), b.ligand_element_batch)
+            smp = model.begin_sampling(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev),
+                                       b.ligand_element_batch, num_steps=2, center_pos_mode='protein',
+                                       noise_source=lambda s, name, like: torch.full_like(like, 0.25))
+            smp.step(); smp.step()
+            outs.append((o['final_h'].clone(), o['pred_ligand_pos'].clone(), smp.lpos.clone(), smp.lv.clone()))
+        for o in outs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(o, outs[0])), cfg
+
+
 def test_sampling_with_fp32_edge_first_layer(state_dict):
     """edge_key_split = 0 (radial/type first layer on fp32 MFMA) stays a tested path: 5 reverse steps through the session and
     the stateless forward against the default (bf16 piece triples): same types, positions within the sampling tolerance, and

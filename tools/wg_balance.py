@@ -38,7 +38,8 @@ def main():
         sampler.step()
     torch.cuda.synchronize()
     slots = 9
-    buf = torch.zeros(slots, 2, 256, 2, dtype=torch.int64, device=dev)
+    buf = torch.zeros(slots, 2, 256, 4, dtype=torch.int64, device=dev)
+    buf[..., 2] = torch.iinfo(torch.int64).max           # atomic min of the waves' end times (unsigned compare: below 2^63)
     lib = capi.load_library()
     assert lib.td_debug_wg_trace(ctypes.c_void_p(buf.data_ptr()), slots) == 0
     sampler.step()
@@ -46,7 +47,8 @@ def main():
     lib.td_debug_wg_trace(None, 0)
     t = buf.cpu().numpy().astype(np.float64) / 100.0          # microseconds (100 MHz)
     print(f'# {desc}; one step, launches in order (layer 0 .. 8); times in us from the first workgroup start of the launch')
-    print('# pass layer  active_wgs   mean_busy   max_busy  launch_span  max/mean  (span - mean)/span')
+    print('# pass layer  active_wgs   mean_busy   max_busy  launch_span  max/mean  (span - mean)/span   waves: (wg end - mean wave end) / busy, '
+          '(wg end - first wave end) / busy, both averaged over the workgroups')
     for p, name in enumerate(('key', 'value')):
         for l in range(slots):
             st, en = t[l, p, :, 0], t[l, p, :, 1]
@@ -56,13 +58,18 @@ def main():
             t0 = st[on].min()
             busy = (en - st)[on]
             span = en[on].max() - t0
+            nw = 12 if p == 0 else 8
+            wmean = (en - t[l, p, :, 3] / nw)[on] / busy
+            wfirst = (en - t[l, p, :, 2])[on] / busy
             print(f'  {name:5s} {l:3d} {int(on.sum()):10d} {busy.mean():11.1f} {busy.max():10.1f} {span:12.1f} {busy.max() / busy.mean():9.3f} '
-                  f'{(span - busy.mean()) / span:10.3f}')
+                  f'{(span - busy.mean()) / span:10.3f}   {wmean.mean():8.3f} {wfirst.mean():8.3f}')
             if args.detail:
                 b = (en - st)
                 q = lambda v: ' '.join(f'{x:6.0f}' for x in np.percentile(v, [0, 10, 50, 90, 100]))
                 print(f'        busy percentiles 0/10/50/90/100, workgroups 0..199: {q(b[:200])} | 200..239: {q(b[200:240])} | 240..255: {q(b[240:])}')
                 print('        last 24 workgroups: ' + ' '.join(f'{x:.0f}' for x in b[232:]))
+                print('        per XCD (workgroups b % 8 == x, b < 232) mean / max: ' +
+                      '  '.join(f'{b[x:232:8].mean():.0f}/{b[x:232:8].max():.0f}' for x in range(8)))
 
 
 if __name__ == '__main__':
