@@ -252,11 +252,12 @@ int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const f
  *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */
 int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream);
 
-/* ---- profiling hook: wall clock of every workgroup of the x2h key / value launches.  d_buf [slots][2 passes][256 workgroups]
- *      [4] uint64 = (start, end, end of the workgroup's first finished wave, sum of its waves' ends) in s_memrealtime ticks (the
- *      100 MHz reference clock: comparable across CUs); launch n of a pass writes slot n % slots (pass 0 = key, 1 = value).  The
- *      caller fills entries 2 with all-ones and 3 with zero before the step (atomic min / add).  d_buf == NULL switches it off
- *      (the default; one scalar test per kernel). */
+/* ---- profiling hook: wall clock of every workgroup of the x2h key / x2h value / fused h2x launches.  d_buf [slots][3 passes]
+ *      [256 workgroups][8] uint64 in s_memrealtime ticks (the 100 MHz reference clock: comparable across CUs): 0 = the row loop
+ *      starts (tables staged), 1 = end, 2 = end of the workgroup's first finished wave, 3 = sum of its waves' ends, 4 = kernel entry;
+ *      launch n of a pass writes slot n % slots (pass 0 = key, 1 = value, 2 = h2x).  The caller fills entries 2 with all-ones and
+ *      the rest with zero before the step (atomic min / add).  d_buf == NULL switches it off (the default; one scalar test per
+ *      kernel). */
 int td_debug_wg_trace(uint64_t *d_buf, int32_t slots);
 
 #if defined(__GNUC__)

@@ -64,8 +64,8 @@ struct Args16 {
 __device__ __forceinline__ void td_trace_wave_end(unsigned long long *trace, int lane) {
     if (lane == 0) {
         const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        atomicMin(trace + 4 * blockIdx.x + 2, t);
-        atomicAdd(trace + 4 * blockIdx.x + 3, t);
+        atomicMin(trace + 8 * blockIdx.x + 2, t);
+        atomicAdd(trace + 8 * blockIdx.x + 3, t);
     }
 }
 
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     const float *GAM = lds + RF + E16_WQ_FLOATS, *BET = GAM + TD_H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
+    if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, WAVES * 64);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
-    if (a.trace && tid == 0) a.trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     int64_t begin, end, stride = WAVES;
     if (a.deal) td_deal16(a.count_ptr ? (int64_t)*a.count_ptr : a.count, a.deal == 2 ? 1 : WAVES, begin, end, stride);
     else td_node_range16(a.count, a.count_ptr, begin, end);
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     if (a.trace) {
         td_trace_wave_end(a.trace, lane);
         __syncthreads();
-        if (tid == 0) a.trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) a.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     const float *GAMk = GB, *BETk = GB + TD_H, *GAMv = GB + 2 * TD_H, *BETv = GB + 3 * TD_H;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
+    if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         // destination class 0 (ligand) is the first half of either table
         td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     av.p_off = 2 * TD_H;
     const float b2 = ar.mlp_v.b2[lo];
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
     for (int64_t it = begin + wid; it < end; it += WAVES) {
         const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
@@ -757,6 +760,11 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         sz = td_sum64(sz) * (1.0f / TD_HEADS);
         if (lane == 0) a.x4_out[i] = make_float4(ev.xi.x + sx, ev.xi.y + sy, ev.xi.z + sz, ev.xi.w);
     }
+    if (a.trace) {
+        td_trace_wave_end(a.trace, lane);
+        __syncthreads();
+        if (tid == 0) a.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ================================================================================================ value pass (x2h)
@@ -818,6 +826,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         my_cls = (int)blockIdx.x >= (int)G - GL ? 0 : 1;
     }
     const int GP = gridDim.x - GL;
+    if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         td_stage_lds16(SPLIT ? reinterpret_cast<const float4 *>(a.mlp.R16p) + my_cls * E16P_HALF_U4 : reinterpret_cast<const float4 *>(a.mlp.R16),
                        reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
@@ -835,12 +844,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
     }
     __syncthreads();
-    if (a.trace && tid == 0) a.trace[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     auto trace_end = [&]() {
         if (a.trace) {
             td_trace_wave_end(a.trace, lane);
             __syncthreads();
-            if (tid == 0) a.trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0) a.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         }
     };
 
@@ -1202,17 +1211,17 @@ static int grid16(int64_t count, int waves) {
 
 // td_debug_wg_trace: per-workgroup (start, end, first wave end, sum of wave ends) stamps of the x2h key / value launches
 static unsigned long long *g_wg_trace = nullptr;
-static int g_wg_trace_slots = 0, g_wg_trace_launch[2] = {0, 0};
+static int g_wg_trace_slots = 0, g_wg_trace_launch[3] = {0, 0, 0};
 int td_set_wg_trace(unsigned long long *buf, int slots) {
     g_wg_trace = slots > 0 ? buf : nullptr;
     g_wg_trace_slots = slots;
-    g_wg_trace_launch[0] = g_wg_trace_launch[1] = 0;
+    g_wg_trace_launch[0] = g_wg_trace_launch[1] = g_wg_trace_launch[2] = 0;
     return TD_OK;
 }
 static unsigned long long *wg_trace_slot(int pass) {
     if (!g_wg_trace) return nullptr;
     const int n = g_wg_trace_launch[pass]++ % g_wg_trace_slots;
-    return g_wg_trace + ((size_t)n * 2 + pass) * 256 * 4;
+    return g_wg_trace + ((size_t)n * 3 + pass) * 256 * 8;
 }
 
 // cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node
@@ -1314,6 +1323,7 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
     a.x4 = x4_in; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
     a.alpha = nullptr; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     ar.mlp_v = mlp_v;
+    a.trace = wg_trace_slot(2);
     const dim3 grid(grid16(count, H2X16_WAVES)), block(H2X16_WAVES * 64);
     if (mlp_k.use_split && mlp_v.use_split) {
         TD_LDS_ONCE((edge_h2x16_kernel<true>), h2x16_lds_bytes<true>());

@@ -38,7 +38,7 @@ def main():
         sampler.step()
     torch.cuda.synchronize()
     slots = 9
-    buf = torch.zeros(slots, 2, 256, 4, dtype=torch.int64, device=dev)
+    buf = torch.zeros(slots, 3, 256, 8, dtype=torch.int64, device=dev)
     buf[..., 2] = torch.iinfo(torch.int64).max           # atomic min of the waves' end times (unsigned compare: below 2^63)
     lib = capi.load_library()
     assert lib.td_debug_wg_trace(ctypes.c_void_p(buf.data_ptr()), slots) == 0
@@ -49,7 +49,7 @@ def main():
     print(f'# {desc}; one step, launches in order (layer 0 .. 8); times in us from the first workgroup start of the launch')
     print('# pass layer  active_wgs   mean_busy   max_busy  launch_span  max/mean  (span - mean)/span   waves: (wg end - mean wave end) / busy, '
           '(wg end - first wave end) / busy, both averaged over the workgroups')
-    for p, name in enumerate(('key', 'value')):
+    for p, name in enumerate(('key', 'value', 'h2x')):
         for l in range(slots):
             st, en = t[l, p, :, 0], t[l, p, :, 1]
             on = en > 0
@@ -59,10 +59,11 @@ def main():
             busy = (en - st)[on]
             span = en[on].max() - t0
             nw = 12 if p == 0 else 8
+            stage = (st - t[l, p, :, 4])[on]
             wmean = (en - t[l, p, :, 3] / nw)[on] / busy
             wfirst = (en - t[l, p, :, 2])[on] / busy
             print(f'  {name:5s} {l:3d} {int(on.sum()):10d} {busy.mean():11.1f} {busy.max():10.1f} {span:12.1f} {busy.max() / busy.mean():9.3f} '
-                  f'{(span - busy.mean()) / span:10.3f}   {wmean.mean():8.3f} {wfirst.mean():8.3f}')
+                  f'{(span - busy.mean()) / span:10.3f}   {wmean.mean():8.3f} {wfirst.mean():8.3f}   staging {stage.mean():6.1f} (max {stage.max():.1f})  first entry -> last end {en[on].max() - t[l, p, :, 4][on].min():6.1f}  entries spread {np.ptp(t[l, p, :, 4][on]):5.1f}')
             if args.detail:
                 b = (en - st)
                 q = lambda v: ' '.join(f'{x:6.0f}' for x in np.percentile(v, [0, 10, 50, 90, 100]))
