@@ -360,6 +360,41 @@ def test_row_distribution_settings_are_bit_identical(state_dict):
             assert all(torch.equal(x, y) for x, y in zip(o, outs[0])), cfg
 
 
+def test_workgroup_trace_hook(state_dict):
+    """td_debug_wg_trace (include/targetdiff_hip.h): a traced forward leaves ordered stamps for every workgroup that ran in the x2h
+    key / value and fused h2x launches, changes no result, and switches off again."""
+    import ctypes
+    from conftest import small_inputs
+    from targetdiff_amd import capi
+    dev = _dev()
+    g = load_golden('forward_small.npz')
+    inp = {k: v.to(dev) for k, v in small_inputs(g).items()}
+    model = _model(state_dict)
+    call = lambda: model(inp['protein_pos'], inp['protein_v'], inp['batch_protein'], inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'])
+    want = call()['final_h'].clone()
+    slots = 9
+    buf = torch.zeros(slots, 3, 256, 8, dtype=torch.int64, device=dev)
+    buf[..., 2] = torch.iinfo(torch.int64).max
+    lib = capi.load_library()
+    assert lib.td_debug_wg_trace(ctypes.c_void_p(buf.data_ptr()), slots) == 0
+    try:
+        got = call()['final_h'].clone()
+        torch.cuda.synchronize()
+    finally:
+        lib.td_debug_wg_trace(None, 0)
+    assert torch.equal(got, want)
+    t = buf.cpu()
+    for p in range(3):
+        ran = t[:, p, :, 1] > 0
+        assert ran.any(dim=1).all()                              # every layer's launch of the pass left stamps
+        entry, start, end, first, total = (t[:, p, :, k][ran] for k in (4, 0, 1, 2, 3))
+        assert (entry <= start).all() and (start <= end).all() and (first <= end).all() and (first >= start).all() and (total > 0).all()
+    before = buf.clone()
+    call()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, before)                              # off again: nothing written
+
+
 def test_sampling_with_fp32_edge_first_layer(state_dict):
     """edge_key_split = 0 (radial/type first layer on fp32 MFMA) stays a tested path: 5 reverse steps through the session and
     the stateless forward against the default (bf16 piece triples): same types, positions within the sampling tolerance, and
