@@ -35,7 +35,7 @@ extern "C" {
 #define TD_ENOMEM (-2)      /* workspace too small or allocation failure */
 #define TD_EHIP (-3)        /* HIP runtime error (message in td_last_error) */
 
-#define TD_ABI_VERSION 2
+#define TD_ABI_VERSION 3
 
 typedef struct td_model td_model;
 

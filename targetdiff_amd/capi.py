@@ -31,7 +31,7 @@ class TdConfig(ctypes.Structure):
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
 MAX_FANIN = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 # every symbol include/targetdiff_hip.h declares: (restype, argtypes)
