@@ -520,9 +520,16 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
     NpArgs a;
     a.nseg = 0;
     unsigned total = 0;
+    // After the long workgroups: the ligand rows' single-unit workgroups (their query MLP, two chained GEMMs, is the longest short
+    // one: it takes the slots the long ones leave free from the start), then the neighbourhood rows'.  When the long workgroups fit
+    // the chip's 512 slots in one round (C2: 475), the neighbourhood rows mostly run once the long ones are done, on an empty chip,
+    // where a second workgroup costs nothing and a second GEMM in the same workgroup is 10 us of tail: one unit per workgroup
+    // (projections 0.765 -> 0.729 ms per C2 step).  Over many rounds (C3: 8,140 long workgroups) the second tile load costs
+    // throughput instead (+2.5 %): both units in one workgroup.
+    const bool one_round = (N + 127) / 128 <= 512;
     total += np_fill(a.seg[a.nseg++], nx, rows, rows ? count_ptr : nullptr, N, 0x1f, P, q, N <= TD_SMALL_BATCH_ROWS, 128);
-    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, N <= TD_SMALL_BATCH_ROWS, 128);
     if (Nl > 0) total += np_fill(a.seg[a.nseg++], hx, lig_rows, nullptr, Nl, 0x15, Px, qx, true, 128);
+    total += np_fill(a.seg[a.nseg++], hx, hop_rows, hop_rows ? hop_count : nullptr, N, 0x0a, Px, qx, one_round, 128);
     return np_launch(a, h, total, s);
 }
 
