@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03h
+OUT=$ROOT/gpurun_out/${1:-timeline}
 mkdir -p "$OUT"
 cd "$ROOT"
 timeout 600 python tools/c4_per_pocket.py > "$OUT/c4_per_pocket.json" 2> "$OUT/c4.err"; python -c "
