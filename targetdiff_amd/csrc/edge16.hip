@@ -529,18 +529,24 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            // the weight fragments of k-step s + 1 are read while the eight products of k-step s run (left to itself the compiler
+            // reads them right in front of their use and the wave sits out the LDS latency 32 times per row)
+            float4 w0 = Wq[lane], w1 = Wq[64 + lane];
 #pragma unroll
-            for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
-                    const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
-                    float u = w0.x * q0.x;
-                    u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
-                    u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
-                    lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                    if (!CHUNKED || ed.any[1]) lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);       // an all-pad second block is skipped
+            for (int kk = 0; kk < 32; ++kk) {
+                float4 n0 = w0, n1 = w1;
+                if (kk + 1 < 32) {
+                    n0 = Wq[((kk + 1) * 2 + 0) * 64 + lane];
+                    n1 = Wq[((kk + 1) * 2 + 1) * 64 + lane];
                 }
+                __builtin_amdgcn_sched_barrier(0);         // the reads stay in front of this k-step's arithmetic
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                lg[0] = td_mfma16(u, acc[0][kk >> 2][kk & 3], lg[0]);
+                if (!CHUNKED || ed.any[1]) lg[1] = td_mfma16(u, acc[1][kk >> 2][kk & 3], lg[1]);       // an all-pad second block is skipped
+                w0 = n0; w1 = n1;
+            }
         };
 
         if (!CHUNKED || nch == 1) {
@@ -702,18 +708,24 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         floatx4_t lg[2];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+        {   // weight fragments read a k-step ahead (see edge_key16_kernel)
+            float4 w0 = Wq[lane], w1 = Wq[64 + lane];
 #pragma unroll
-        for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 w0 = Wq[((hb * 4 + r) * 2 + 0) * 64 + lane];
-                const float4 w1 = Wq[((hb * 4 + r) * 2 + 1) * 64 + lane];
+            for (int kk = 0; kk < 32; ++kk) {
+                float4 n0 = w0, n1 = w1;
+                if (kk + 1 < 32) {
+                    n0 = Wq[((kk + 1) * 2 + 0) * 64 + lane];
+                    n1 = Wq[((kk + 1) * 2 + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 float u = w0.x * q0.x;
                 u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
                 u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
-                lg[0] = td_mfma16(u, acc[0][hb][r], lg[0]);
-                lg[1] = td_mfma16(u, acc[1][hb][r], lg[1]);
+                lg[0] = td_mfma16(u, acc[0][kk >> 2][kk & 3], lg[0]);
+                lg[1] = td_mfma16(u, acc[1][kk >> 2][kk & 3], lg[1]);
+                w0 = n0; w1 = n1;
             }
+        }
         floatx4_t al[2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
