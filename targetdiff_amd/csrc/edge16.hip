@@ -747,14 +747,18 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         floatx4_t xv[2];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+        {
+            float u = Wx[lane];
 #pragma unroll
-        for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u = Wx[(hb * 4 + r) * 64 + lane];
-                xv[0] = td_mfma16(u, accv[0][hb][r], xv[0]);
-                xv[1] = td_mfma16(u, accv[1][hb][r], xv[1]);
+            for (int kk = 0; kk < 32; ++kk) {
+                float un = u;
+                if (kk + 1 < 32) un = Wx[(kk + 1) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                xv[0] = td_mfma16(u, accv[0][kk >> 2][kk & 3], xv[0]);
+                xv[1] = td_mfma16(u, accv[1][kk >> 2][kk & 3], xv[1]);
+                u = un;
             }
+        }
         float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
