@@ -977,16 +977,23 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
                             make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
                 };
-                flip_store(0);
-#pragma unroll
-                for (int hb = 0; hb < 8; ++hb) {
-                    if (hb + 1 < 8) flip_store(hb + 1);
+                auto flip_load = [&](int hb, float (&bv)[8]) {
                     const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
-                    float bv[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
+                };
+                float bvb[2][8];
+                flip_store(0);
+                flip_load(0, bvb[0]);
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bv[s], zb[hb]);
+                for (int hb = 0; hb < 8; ++hb) {
+                    if (hb + 1 < 8) {
+                        flip_store(hb + 1);
+                        flip_load(hb + 1, bvb[(hb + 1) & 1]);       // read back a block ahead of its products (see the pipelined loop)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bvb[hb & 1][s], zb[hb]);
                 }
             }
             const float ssum = td_sum_groups(asum);
