@@ -788,7 +788,12 @@ constexpr int V16_WAVES = 8;
 constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
 constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidden + 4]
 constexpr int V16_ZB_STRIDE = 132;
-constexpr int V16_WAVE_FLOATS = 2 * 32 * V16_TB_STRIDE;   // 1280 >= 8 * 132: two transpose tiles, later the Zbar half
+// Rows 8g .. 8g + 7 of a tile are read by lane group g (ds_read_b32, hidden column lo): with any 16-byte-aligned row stride 8 rows
+// are a multiple of 32 banks, i.e. groups 0 and 1 (and 2, 3) of a half-wave collide two-way (PMC: 10 % conflict cycles).  16 floats of
+// padding after every 8 rows put the odd groups on the other 16 banks.
+constexpr int V16_TILE_FLOATS = 32 * V16_TB_STRIDE + 4 * 16;
+__device__ __forceinline__ int td_tile_row16(int e) { return e * V16_TB_STRIDE + (e >> 3) * 16; }
+constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // 1408 >= 8 * 132: two transpose tiles, later the Zbar half
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
@@ -971,16 +976,16 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
                 asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
                 auto flip_store = [&](int hb) {
-                    float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+                    float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
                     for (int eb = 0; eb < 2; ++eb)
-                        *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                        *reinterpret_cast<float4 *>(t + td_tile_row16(16 * eb + lo) + 4 * g) =
                             make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
                 };
                 auto flip_load = [&](int hb, float (&bv)[8]) {
-                    const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+                    const float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
+                    for (int s = 0; s < 8; ++s) bv[s] = t[td_tile_row16(8 * g + s) + lo];
                 };
                 float bvb[2][8];
                 flip_store(0);
@@ -1063,18 +1068,18 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         // Two tiles ping-pong so that the flip of block hb + 1 is in flight while block hb feeds the MFMAs.
         floatx4_t zb[8];
         auto flip_store = [&](int hb) {
-            float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+            float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb)
-                *reinterpret_cast<float4 *>(t + (16 * eb + lo) * V16_TB_STRIDE + 4 * g) =
+                *reinterpret_cast<float4 *>(t + td_tile_row16(16 * eb + lo) + 4 * g) =
                     make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
         };
         // block hb + 1 is flipped AND read back (B[edge 8g + s][hidden 16(hb + 1) + lo]) before block hb's products are issued: the
         // reads' latency runs behind eight MFMAs instead of in front of them
         auto flip_load = [&](int hb, float (&bv)[8]) {
-            const float *t = TB + (hb & 1) * (32 * V16_TB_STRIDE);
+            const float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) bv[s] = t[(8 * g + s) * V16_TB_STRIDE + lo];
+            for (int s = 0; s < 8; ++s) bv[s] = t[td_tile_row16(8 * g + s) + lo];
         };
         float bvb[2][8];
         flip_store(0);
