@@ -400,7 +400,7 @@ constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, o
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H + 4) * sizeof(float);       // + the row counter
 constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
-constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H + 4) * sizeof(float);
+constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -433,6 +433,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
         else if (tid < 2 * TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
         else if (tid == 2 * TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H) = 0;
+        else if (SPLIT && tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {
+            const int k = tid - (2 * TD_H + 32);
+            lds[RF + E16_WQ_FLOATS + 2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : 0.f;
+        }
     }
     float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
 #pragma unroll
@@ -467,7 +471,18 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             RowIn16 rin;
             td_row_index16(a, i, c, lane, rin);
             td_row_gather16<EW>(a, i, c, lane, rin, acc);
-            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+            // the lane group's eight Gaussian centres come from LDS for every row: as loop-invariant registers they were what the
+            // allocator pushed to scratch at this kernel's 168-register budget, and a scratch reload is a vmcnt wait in the middle
+            // of the row's gathers
+            float offr[8];
+            {
+                int dep = 0;
+                asm volatile("" : "+v"(dep));
+                const float4 *op = reinterpret_cast<const float4 *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H + 4 + 8 * g + dep);
+                const float4 o0 = op[0], o1 = op[1];
+                offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
+            }
+            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
