@@ -812,7 +812,7 @@ constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // 1408 >= 8 * 132: tw
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
-    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
+    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4 + 32) * sizeof(float);
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
 // (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
@@ -872,6 +872,10 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
         else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
         else if (tid == 3 * TD_H) *reinterpret_cast<int *>(B2 + 3 * TD_H) = 0;
+        else if (SPLIT && tid >= 3 * TD_H + 32 && tid < 3 * TD_H + 64) {           // Gaussian centres, read per row (see edge_key16_kernel)
+            const int k = tid - (3 * TD_H + 32);
+            B2[3 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : 0.f;
+        }
     }
     float offk[NOFF];
 #pragma unroll
@@ -1069,8 +1073,17 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         int64_t inext = next_indexed(rnext, cnext);
         bool more = inext >= 0;
         Edge2 ed;
-        if constexpr (SPLIT)
-            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+        if constexpr (SPLIT) {
+            float offr[8];
+            {
+                int dep = 0;
+                asm volatile("" : "+v"(dep));
+                const float4 *op = reinterpret_cast<const float4 *>(B2 + 3 * TD_H + 4 + 8 * g + dep);
+                const float4 o0 = op[0], o1 = op[1];
+                offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
+            }
+            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed);
+        }
         else
             td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
 
