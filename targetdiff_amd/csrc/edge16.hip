@@ -714,12 +714,14 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_row_gather16<true>(a, i, i, lane, rin, acc);
         if constexpr (SPLIT) td_first_layer_split16<true, true, false>(a, reinterpret_cast<const uint4 *>(Rk), GAMk, BETk, offk, rin, i, lane, acc, ed);
         else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), GAMk, BETk, offk, rin, lane, acc, ed);
-        // the value half's gathers (its own accumulators) fly while the logits and the softmax run
+        // the value half's gathers (its own accumulators) fly while the logits and the softmax run.  The query is fetched BEFORE they are
+        // issued: vmcnt counts in order, so a load issued after the gathers could only be waited for together with them -- and the
+        // logits, which need the query first, would start when the gathers have landed instead of while they fly
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
         RowIn16 rv = rin;
         floatx4_t accv[2][8];
         td_row_gather16<false>(av, i, i, lane, rv, accv);
-        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
-        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
         floatx4_t lg[2];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
