@@ -1050,9 +1050,15 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     }
     // next row of this workgroup's class with its index loads issued (dyn + SPLIT: candidates of the other class -- the ligand
     // rows inside a protein workgroup's share, one in 25 -- are dropped here, at the price of one exposed load each)
+    // The loads are issued unconditionally (row 0 stands in when the wave has run out of rows): behind a branch they make the
+    // compiler's wait-count bookkeeping pessimistic at the join -- vmcnt counts in order, the path without the loads has fewer
+    // outstanding, and the wait for the CURRENT row's gathers was emitted as if the next row's index loads, issued a moment
+    // earlier, had to land first (s_waitcnt vmcnt(9) / (8) where vmcnt(11) is enough: one exposed round trip per row).
     auto next_indexed = [&](RowIn16 &r, int64_t &cx) -> int64_t {
-        int64_t ix = next_row();
-        if (ix >= 0) { cx = chunk_of(ix); td_row_index16(a, ix, cx, lane, r); }
+        const int64_t ix = next_row();
+        const int64_t safe = ix >= 0 ? ix : 0;
+        cx = chunk_of(safe);
+        td_row_index16(a, safe, cx, lane, r);
         return ix;
     };
     auto settle = [&](int64_t ix, RowIn16 &r, int64_t &cx) -> int64_t {
@@ -1133,9 +1139,10 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             inext = settle(inext, rnext, cnext);
             more = inext >= 0;
         }
-        if (more) {
-            td_row_gather16<false>(a, inext, cnext, lane, rnext, acc);
-            load_side(inext, cnext, al, hres0, hres1);
+        {   // (unconditional for the same reason: after the last row these are loads of row 0 that nobody reads)
+            const int64_t gsafe = more ? inext : 0;
+            td_row_gather16<false>(a, gsafe, more ? cnext : chunk_of(0), lane, rnext, acc);
+            load_side(gsafe, more ? cnext : chunk_of(0), al, hres0, hres1);
             rin = rnext;
         }
         i = inext;
