@@ -298,11 +298,15 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 // offj[j] = Gaussian centre of k = 8g + j.  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
 // PI_LATE: the P_i loads are issued first and consumed after the products (their latency hides behind the MFMAs at the
 // price of 32 registers); otherwise P_i is added up front.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, bool SKIP_EMPTY = false>
+struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
+// before_products: called once the gathered operands have been consumed (Gaussians computed, P_i added) and before the matrix products
+// are issued -- the place to start loads whose data is needed after the first layer (the key pass's query): the live set is at its
+// lowest there and the products give them ~ 1.5 k cycles of cover.
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, bool SKIP_EMPTY = false, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ GAM, const float *__restrict__ BET,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
-                                                       floatx4_t (&acc)[2][8], Edge2 &ed) {
+                                                       floatx4_t (&acc)[2][8], Edge2 &ed, Hook before_products = Hook()) {
     const int lo = lane & 15, g = lane >> 4;
     const int l48 = (g < 3 ? g : 2) * 16 + lo;
     const float4 xi = r.xi;
@@ -346,6 +350,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             gv[eb][j] = !ed.valid[eb] ? 0.f : (k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f));
         }
     }
+    before_products();
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         if (!(has[sl][0] || has[sl][1])) continue;
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         return begin + (int64_t)__builtin_amdgcn_readfirstlane(n) * stride;
     };
 
+    float4 qpre0, qpre1;           // the row's query, fetched from inside the first layer (bf16 path, non-XV)
     // first layer of chunk c of dst node i: z^T in acc
     auto first_layer = [&](int64_t i, int64_t c, floatx4_t (&acc)[2][8], Edge2 &ed) {
         constexpr bool EW = !XV && !CHUNKED;       // the chunked key pass fetches the gate in its second sweep
@@ -482,7 +488,13 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
-            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed);
+            auto fetch_q = [&]() {
+                if constexpr (!XV && !CHUNKED) {        // (the chunk-walking kernel has no register to spare for it: measured slower)
+                    qpre0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+                    qpre1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+                }
+            };
+            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
@@ -539,9 +551,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 
         // ---- logits^T[head][edge] = sum_k U_i[k][head] z[k][edge];  A = U_i built from q_i: lane (head lo, group g) ----
         auto logits = [&](const floatx4_t (&acc)[2][8], floatx4_t (&lg)[2], const Edge2 &ed) {
-            // fetched after the first layer: eight fewer live registers while it runs
-            const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
-            const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+            // bf16 path: fetched by the first layer in front of its products (td_first_layer_split16's hook); fp32 path: here
+            const float4 q0 = (SPLIT && !CHUNKED) ? qpre0 : *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+            const float4 q1 = (SPLIT && !CHUNKED) ? qpre1 : *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
             // the weight fragments of k-step s + 1 are read while the eight products of k-step s run (left to itself the compiler
