@@ -1,6 +1,8 @@
 #!/bin/bash
+# Headline evidence of the current build in one short gpurun call: kernel stats of the default command (rocprofv3), the default bench line,
+# per-class breakdown, workgroup traces, C1 / C3 / C5 / k = 48 lines.   usage: tools/refresh_headline.sh <tag>  -> gpurun_out/<tag>/
 cd "${GRAFT_REPO_ROOT:-.}"
-OUT=gpurun_out/r03u; mkdir -p $OUT
+OUT=gpurun_out/${1:-headline}; mkdir -p $OUT
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/stats_c2" -o c2 -- python "$ROOT/bench.py" --workload c2 --no-cpu-baseline --no-full-run --no-stateless > "$ROOT/$OUT/bench_c2_under_rocprof.json" 2> "$ROOT/$OUT/stats_c2.log"
