@@ -991,12 +991,20 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 #pragma unroll
             for (int hb = 0; hb < 8; ++hb) zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
             float asum = 0.f;
+            // the neighbour indices of chunk c + 1 are fetched while chunk c runs (unconditionally: the row's last chunk stands in
+            // for the one after it), so that a chunk starts with its gathers instead of two dependent round trips
+            RowIn16 rin;
+            td_row_index16(a, i, c0, lane, rin);
             for (int c = c0; c < c1; ++c) {
-                RowIn16 rin;
                 floatx4_t acc[2][8];
                 Edge2 ed;
-                td_row_index16(a, i, c, lane, rin);
                 td_row_gather16<false>(a, i, c, lane, rin, acc);
+                RowIn16 rcur = rin;
+                {
+                    const int cn = c + 1 < c1 ? c + 1 : c;
+                    rin.j[0] = a.nbr[(int64_t)cn * TD_K + lo];
+                    rin.j[1] = a.nbr[(int64_t)cn * TD_K + 16 + lo];
+                }
                 float al[8];
                 {   // A operand of the aggregation product: alpha[edge 8g + s][head lo] of this chunk
                     const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
@@ -1004,9 +1012,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
                 }
                 if constexpr (SPLIT)
-                    td_first_layer_split16<false, true, false, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rin, i, lane, acc, ed);
+                    td_first_layer_split16<false, true, false, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rcur, i, lane, acc, ed);
                 else
-                    td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+                    td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rcur, lane, acc, ed);
                 asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
                 auto flip_store = [&](int hb) {
                     float *t = TB + (hb & 1) * V16_TILE_FLOATS;
