@@ -20,6 +20,10 @@ ARCH = 'gfx950'
 # NB: the kNN distance uses __fmul_rn/__fadd_rn explicitly (td_dist2), so the default fp contraction is safe.
 # -fvisibility=hidden: only the extern "C" entry points of include/targetdiff_hip.h (visibility push(default)) are exported
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-arch={ARCH}', '-x', 'hip', '-Wall', '-Wno-unused-function']
+# per-file additions.  edge16.hip: no SLP vectorisation -- it turns the 64 P_i adds of a row (and other adjacent fp32 adds) into
+# v_pk_add_f32, which costs more than two plain adds next to the co-resident waves' matrix instructions (x2h key pass -2 %, h2x -1.5 %
+# per C2 step, A/B in one gpurun call; MI355X_MICROARCH.md lists packed fp32 as an anti-lever beside MFMAs)
+FILE_FLAGS = {'edge16.hip': ['-fno-slp-vectorize']}
 
 
 def hipcc() -> str:
@@ -46,8 +50,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc()] + FLAGS + ['-c', sp, '-o', obj]
+        if force or _stale(obj, [sp, os.path.abspath(__file__)] + headers):
+            cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

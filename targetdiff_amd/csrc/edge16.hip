@@ -22,6 +22,8 @@ __device__ __forceinline__ floatx4_t td_mfma16(float a, float b, floatx4_t c) {
 }
 
 constexpr float TD_ATT_SCALE_16 = 0.35355339059327373f;   // 1/sqrt(8)
+constexpr float TD_LOG2E = 1.4426950408889634f;
+constexpr float TD_FAR_CENTRE = 1.0e4f;                    // "centre" of the K slots behind the 20 Gaussians: exp2(c (d - 1e4)^2) = 0
 constexpr int E16_STEPS = TD_SLOTK / 4;                    // 6 k-steps of 4 over the 24-wide radial/type slot
 constexpr int E16_R_FLOATS = 2 * 2 * E16_STEPS * 64 * 8;   // [cls][slot][step][lane][hb]   = 12288
 constexpr int E16_WQ_FLOATS = 8 * 4 * 2 * 64 * 4;          // [hb][r][jq][lane][4 j]        = 16384
@@ -115,6 +117,56 @@ __device__ __forceinline__ float td_max16(float v) {
     v = fmaxf(v, td_dpp<DPP_ROW_HALF_MIRROR>(v));
     v = fmaxf(v, td_dpp<DPP_ROW_MIRROR>(v));
     return v;
+}
+
+// Four row-of-16 reductions at once (the four heads 4g .. 4g+3 a lane group owns in the softmax).  Every step is ONE v_max / v_add with
+// the DPP modifier on its first source: through __builtin_amdgcn_update_dpp + fmaxf the compiler emits, per step, v_mov_b32 0 /
+// v_mov_b32_dpp / a canonicalising v_max / v_max (and SLP-packs the sums into v_pk_add_f32 behind two v_mov_b32_dpp) -- ~230 VALU
+// instructions for one row's softmax where ~100 do.  The four independent chains cover each other's "VALU write -> DPP read" hazard
+// (2 wait states); the leading s_nop covers the producers of the inputs.
+#define TD_DPP4(op, ctrl)                                            \
+    op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+    op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+    op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"         \
+    op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void td_max16x4(float (&v)[4]) {
+    asm volatile("s_nop 1\n\t" TD_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") TD_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                 TD_DPP4("v_max_f32_dpp", "row_half_mirror") TD_DPP4("v_max_f32_dpp", "row_mirror")
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+__device__ __forceinline__ void td_sum16x4(float (&v)[4]) {
+    asm volatile("s_nop 1\n\t" TD_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") TD_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+                 TD_DPP4("v_add_f32_dpp", "row_half_mirror") TD_DPP4("v_add_f32_dpp", "row_mirror")
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+#undef TD_DPP4
+
+// softmax over the 32 edges of a row for the four heads 4g + r of the lane group (lg[eb][r] = logit of edge 16eb + lo), times the edge
+// gate: p[eb][r] = exp(x - max) / sum * ew[eb].  A pad's logit is -inf, so its weight is exp(-inf) = 0 without a select; a row without
+// edges gets zeros.  1 / sum is v_rcp_f32 (1 ulp; the correctly rounded __frcp_rn is an 11-instruction sequence per head).
+__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], floatx4_t (&p)[2]) {
+    float x0[4], x1[4], mx[4], sm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x0[r] = valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+        x1[r] = valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+        mx[r] = fmaxf(x0[r], x1[r]);
+    }
+    td_max16x4(mx);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (mx[r] == -INFINITY) mx[r] = 0.f;
+        x0[r] = __expf(x0[r] - mx[r]);
+        x1[r] = __expf(x1[r] - mx[r]);
+        sm[r] = x0[r] + x1[r];
+    }
+    td_sum16x4(sm);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = sm[r] > 0.f ? __builtin_amdgcn_rcpf(sm[r]) : 0.f;
+        p[0][r] = x0[r] * inv * ew[0];
+        p[1][r] = x1[r] * inv * ew[1];
+    }
 }
 
 // ---- first layer + LayerNorm + ReLU of one dst node: z^T in acc[eb][hb] ------------------------------------------------
@@ -295,7 +347,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 }
 
 // Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
-// offj[j] = Gaussian centre of k = 8g + j.  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
+// offj[j] = Gaussian centre of k = 8g + j (TD_FAR_CENTRE for k >= 20).  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
 // PI_LATE: the P_i loads are issued first and consumed after the products (their latency hides behind the MFMAs at the
 // price of 32 registers); otherwise P_i is added up front.
 struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
@@ -331,6 +383,12 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     int slot[2];
     bool has[2][2];
     float gv[2][8];
+    // g_k(d) = exp(coeff (d - mu_k)^2) = exp2(c2 (d - mu_k)^2): four instructions per entry (the compiler cannot fold the two scale
+    // factors of __expf(coeff * u * u) itself).  offj holds TD_FAR_CENTRE behind the 20 Gaussians, so the unused K slots come out as
+    // exp2(-huge) = 0 without a select; slot k = 20 (lane group 2, j = 4) is the edge-type column, constant 1.  A pad (neighbour
+    // index -1, gathered as the row itself) is NOT zeroed: its column of z is finite garbage that the softmax (logit -inf) and the
+    // aggregations (alpha = 0, `valid` selects) never let through.
+    const float c2 = a.coeff * TD_LOG2E;
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
         ed.valid[eb] = r.j[eb] >= 0;
@@ -345,32 +403,26 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         ed.any[eb] = has[0][eb] || has[1][eb];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = 8 * g + j;
             const float u = dist - offj[j];
-            gv[eb][j] = !ed.valid[eb] ? 0.f : (k < TD_NG ? __expf(a.coeff * u * u) : (k == TD_NG ? 1.f : 0.f));
+            gv[eb][j] = __builtin_amdgcn_exp2f(c2 * (u * u));
         }
+        if (g == 2) gv[eb][4] = 1.f;
     }
     before_products();
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        if (!(has[sl][0] || has[sl][1])) continue;
-        // B: the edge inputs of this source class in 3 pieces (edges of the other class contribute nothing)
+    // products of source class sl with the edge inputs m (B operand: the edge inputs in 3 pieces)
+    auto products = [&](int sl, const float (&m)[2][8]) {
         uint4 bm[2][3];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
-            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;
-            float m[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = keep ? gv[eb][j] : 0.f;
-            td_split_pair(m[0], m[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
-            td_split_pair(m[2], m[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
-            td_split_pair(m[4], m[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
-            td_split_pair(m[6], m[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
+            td_split_pair(m[eb][0], m[eb][1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
+            td_split_pair(m[eb][2], m[eb][3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
+            td_split_pair(m[eb][4], m[eb][5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
+            td_split_pair(m[eb][6], m[eb][7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
         }
+        const uint4 *Rs = Rp + (size_t)(((ONE_CLASS ? 0 : cls * 2) + sl) * 3) * 8 * 48 + l48;
 #pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
             uint4 ar[2][3];                 // A: table pieces of hidden blocks 2hp, 2hp + 1
-            const uint4 *Rs = Rp + (size_t)(((ONE_CLASS ? 0 : cls * 2) + sl) * 3) * 8 * 48 + l48;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -383,6 +435,18 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
         }
+    };
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        if (!(has[sl][0] || has[sl][1])) continue;
+        float m[2][8];
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[eb][j] = keep ? gv[eb][j] : 0.f;
+        }
+        products(sl, m);
     }
     if (PI_LATE) add_pi();
     td_ln_relu16<SKIP_EMPTY>(GAM, BET, g, acc, ed.any);
@@ -440,14 +504,14 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         else if (tid == 2 * TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H) = 0;
         else if (SPLIT && tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {
             const int k = tid - (2 * TD_H + 32);
-            lds[RF + E16_WQ_FLOATS + 2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : 0.f;
+            lds[RF + E16_WQ_FLOATS + 2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
         const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
     }
     __syncthreads();
     if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -586,19 +650,13 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                 ed.ew[1] = a.ew[c0 * TD_K + 16 + lo];
             }
             // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate ---------------------
+            floatx4_t pr[2];
+            td_softmax16x4(lg, ed.valid, ed.ew, pr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
-                float mx = td_max16(fmaxf(x0, x1));
-                if (mx == -INFINITY) mx = 0.f;
-                const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
-                const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
-                const float sm = td_sum16(p0 + p1);
-                const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
                 float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
-                dst[0] = p0 * inv * ed.ew[0];
-                dst[16] = p1 * inv * ed.ew[1];
+                dst[0] = pr[0][r];
+                dst[16] = pr[1][r];
             }
             continue;
         }
@@ -610,24 +668,35 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             Edge2 ed;
             first_layer(i, c, acc, ed);
             logits(acc, lg, ed);
+            float x0[4], x1[4], mn[4], ps[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-                const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+                x0[r] = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+                x1[r] = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
                 float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
-                dst[0] = x0;
-                dst[16] = x1;
-                const float mn = fmaxf(mrun[r], td_max16(fmaxf(x0, x1)));
-                if (mn != -INFINITY) {                    // wave-uniform per row of 16 lanes; exp(-inf - mn) = 0 on the first hit
-                    srun[r] = srun[r] * __expf(mrun[r] - mn) + td_sum16(__expf(x0 - mn) + __expf(x1 - mn));
-                    mrun[r] = mn;
-                }
+                dst[0] = x0[r];
+                dst[16] = x1[r];
+                mn[r] = fmaxf(x0[r], x1[r]);
             }
+            td_max16x4(mn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mn[r] = fmaxf(mrun[r], mn[r]);
+                const float ms = mn[r] == -INFINITY ? 0.f : mn[r];       // nothing but pads so far: exp(-inf - 0) = 0
+                ps[r] = __expf(x0[r] - ms) + __expf(x1[r] - ms);
+            }
+            td_sum16x4(ps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mn[r] != -INFINITY) {                 // uniform per row of 16 lanes; exp(-inf - mn) = 0 on the first hit
+                    srun[r] = srun[r] * __expf(mrun[r] - mn[r]) + ps[r];
+                    mrun[r] = mn[r];
+                }
         }
         float inv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            inv[r] = srun[r] > 0.f ? __frcp_rn(srun[r]) : 0.f;
+            inv[r] = srun[r] > 0.f ? __builtin_amdgcn_rcpf(srun[r]) : 0.f;
             if (mrun[r] == -INFINITY) mrun[r] = 0.f;
         }
         // ---- sweep 2: every lane re-reads the entries it wrote (same thread, same addresses) and normalises them -----------
@@ -706,7 +775,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
         const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
     }
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
@@ -756,19 +825,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
             }
         }
         floatx4_t al[2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float x0 = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-            const float x1 = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
-            float mx = td_max16(fmaxf(x0, x1));
-            if (mx == -INFINITY) mx = 0.f;
-            const float p0 = ed.valid[0] ? __expf(x0 - mx) : 0.f;
-            const float p1 = ed.valid[1] ? __expf(x1 - mx) : 0.f;
-            const float sm = td_sum16(p0 + p1);
-            const float inv = sm > 0.f ? __frcp_rn(sm) : 0.f;
-            al[0][r] = p0 * inv * ed.ew[0];
-            al[1][r] = p1 * inv * ed.ew[1];
-        }
+        td_softmax16x4(lg, ed.valid, ed.ew, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
         if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), GAMv, BETv, offk, rv, i, lane, accv, ev);
@@ -888,14 +945,14 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         else if (tid == 3 * TD_H) *reinterpret_cast<int *>(B2 + 3 * TD_H) = 0;
         else if (SPLIT && tid >= 3 * TD_H + 32 && tid < 3 * TD_H + 64) {           // Gaussian centres, read per row (see edge_key16_kernel)
             const int k = tid - (3 * TD_H + 32);
-            B2[3 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : 0.f;
+            B2[3 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
         const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : 0.f;
+        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
     }
     __syncthreads();
     if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -1054,7 +1111,11 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
                 }
                 const int n = 64 * ph + lane;
-                const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
+                // (the wave's tile sits above 64 KiB: as a compile-time constant the offset does not fit the 16-bit field of ds_read and
+            // every one of the 32 reads of a phase got its own v_add_u32 -- opaque, it is one base register + small immediates)
+            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
+            asm volatile("" : "+v"(zoff));
+            const float *zrow = lds + zoff;
                 float o = B2[n] * SB[8 * ph + (lane >> 3)];
 #pragma unroll 8
                 for (int kq = 0; kq < 32; ++kq) {
@@ -1179,7 +1240,11 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
             }
             const int n = 64 * ph + lane;
-            const float *zrow = ZB + (lane >> 3) * V16_ZB_STRIDE;
+            // (the wave's tile sits above 64 KiB: as a compile-time constant the offset does not fit the 16-bit field of ds_read and
+            // every one of the 32 reads of a phase got its own v_add_u32 -- opaque, it is one base register + small immediates)
+            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
+            asm volatile("" : "+v"(zoff));
+            const float *zrow = lds + zoff;
             float o = B2[n] * SB[8 * ph + (lane >> 3)];
 #pragma unroll 8
             for (int kq = 0; kq < 32; ++kq) {

@@ -28,15 +28,29 @@ def under_launcher() -> bool:
     return 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
 
 
+def visible_device_list(env=None):
+    """The outer restriction on the devices this job may use: the entries of HIP_VISIBLE_DEVICES, else of
+    CUDA_VISIBLE_DEVICES (ROCm honours both); None when neither is set."""
+    env = os.environ if env is None else env
+    for name in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if env.get(name, '') != '':
+            return [d for d in env[name].split(',') if d != '']
+    return None
+
+
 def rank_env(rank: int, world: int, port: int, base=None, pin_devices: bool = False) -> dict:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     if pin_devices:
         # the reference's recipe (README.md:96-102, CUDA_VISIBLE_DEVICES=k per shell): rank r sees one GPU, as device 0.
-        # An outer HIP_VISIBLE_DEVICES list is honoured: rank r gets its r-th entry.
-        outer = [d for d in env.get('HIP_VISIBLE_DEVICES', '').split(',') if d != '']
-        env['HIP_VISIBLE_DEVICES'] = outer[rank] if rank < len(outer) else str(rank)
+        # An outer device list is honoured -- HIP_VISIBLE_DEVICES, else CUDA_VISIBLE_DEVICES (a scheduler may hand out devices
+        # through either): rank r gets its r-th entry, and a job with more ranks than entries is refused rather than placed on
+        # GPUs outside the set it was restricted to.
+        outer = visible_device_list(env)
+        if outer is not None and rank >= len(outer):
+            raise RuntimeError(f'pin_devices: rank {rank} of {world} has no device in the outer visible-device list {outer}')
+        env['HIP_VISIBLE_DEVICES'] = outer[rank] if outer is not None else str(rank)
         env.pop('CUDA_VISIBLE_DEVICES', None)
         env['LOCAL_RANK'] = '0'
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this driver
@@ -64,14 +78,31 @@ def _stop(procs, grace: float = 3.0):
                 p.kill()
 
 
+class _Terminated(BaseException):
+    """raised inside spawn_ranks by its SIGTERM / SIGHUP handler, so that the `finally` that stops the ranks runs"""
+
+    def __init__(self, signum):
+        super().__init__(signum)
+        self.signum = signum
+
+
+_ADDR_IN_USE = ('EADDRINUSE', 'Address already in use', 'address already in use', 'errno: 98')
+
+
 def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=None, _retries: int = 1) -> int:
     """Run ``argv`` (a full command line, e.g. ``[sys.executable, 'bench.py', ...]``) as ``nprocs`` ranks.  Rank 0
-    inherits stdout (so its single JSON line is the job's output); every rank inherits stderr.  Returns the first
-    non-zero exit code (0 if all ranks succeeded; 124 on a timeout).  Whatever ends the supervision -- a failing rank, the
-    timeout, KeyboardInterrupt / SIGTERM in this process, an exception while starting rank k > 0 -- every rank still
-    running is terminated (each rank is its own session, so its children go with it): no orphan keeps a GPU or the
-    rendezvous port.  The port is picked free at start; a rank that fails within the first seconds because another job
-    took it in between is retried once on a new port."""
+    inherits stdout (so its single JSON line is the job's output); every rank's stderr is passed through (and its tail kept,
+    see below).  Returns the first non-zero exit code (0 if all ranks succeeded; 124 on a timeout; 128 + signal when this
+    process was told to stop).  Whatever ends the supervision -- a failing rank, the timeout, KeyboardInterrupt, SIGTERM /
+    SIGHUP delivered to this process (handlers are installed for the duration of the call when it runs in the main thread:
+    Python's default action for SIGTERM would end the supervisor without running any clean-up, and the ranks, being their own
+    sessions, are out of reach of a process-group kill aimed at the supervisor), an exception while starting rank k > 0 --
+    every rank still running is terminated (each rank is its own session, so its children go with it): no orphan keeps a GPU
+    or the rendezvous port.  The port is picked free at start; when a rank fails within the first seconds AND its stderr shows
+    the rendezvous could not bind the port (EADDRINUSE: another job took it in between), the job is retried once on a new port."""
+    import collections
+    import signal
+    import threading
     import time
     if pin_devices is None:
         pin_devices = os.environ.get('TD_PIN_DEVICES', '0') not in ('', '0')
@@ -79,14 +110,42 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=Non
     procs = []
     rc = 0
     timed_out = False
+    stopped_by = None
     t_start = time.monotonic()
+    tails = collections.deque(maxlen=400)          # last stderr lines of all ranks (looked at only to classify a failed start)
+    pumps = []
+
+    def _pump(stream):
+        for line in iter(stream.readline, b''):
+            try:
+                sys.stderr.buffer.write(line)
+                sys.stderr.buffer.flush()
+            except Exception:
+                pass
+            tails.append(line.decode('utf-8', 'replace'))
+        stream.close()
+
+    def _on_signal(signum, frame):
+        raise _Terminated(signum)
+
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGHUP):
+            try:
+                old_handlers[sig] = signal.signal(sig, _on_signal)
+            except (ValueError, OSError):
+                pass
     try:
         for r in range(nprocs):
             env = rank_env(r, nprocs, port, pin_devices=pin_devices)
             if extra_env:
                 env.update(extra_env)
-            procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL,
-                                          start_new_session=True))
+            p = subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 start_new_session=True)
+            procs.append(p)
+            t = threading.Thread(target=_pump, args=(p.stderr,), daemon=True)
+            t.start()
+            pumps.append(t)
         deadline = None if timeout is None else t_start + timeout
         live = list(procs)
         while live:                   # poll all ranks: one that dies must not leave the others waiting in a rendezvous
@@ -103,11 +162,22 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=Non
                 _stop(live)
             if live:
                 time.sleep(0.05)
+    except _Terminated as t:
+        stopped_by = t.signum
     finally:
         _stop(procs)
+        for sig, h in old_handlers.items():
+            try:
+                signal.signal(sig, h)
+            except (ValueError, OSError):
+                pass
+        for t in pumps:
+            t.join(timeout=2.0)
+    if stopped_by is not None:
+        return 128 + int(stopped_by)
     if timed_out:
         return 124
-    if rc != 0 and _retries > 0 and time.monotonic() - t_start < 20.0 and _port_in_use(port):
+    if rc != 0 and _retries > 0 and time.monotonic() - t_start < 20.0 and any(k in line for line in tails for k in _ADDR_IN_USE):
         return spawn_ranks(argv, nprocs, timeout, extra_env, pin_devices, _retries - 1)
     return rc
 

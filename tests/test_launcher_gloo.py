@@ -110,3 +110,75 @@ def test_timeout_and_interrupt_leave_no_rank_behind(tmp_path):
     for pid in pids:
         alive = subprocess.run(['ps', '-p', str(pid), '-o', 'stat='], capture_output=True, text=True).stdout.strip()
         assert alive == '' or alive.startswith('Z'), (pid, alive)
+
+
+def test_sigterm_to_the_supervisor_leaves_no_rank_behind(tmp_path):
+    """SIGTERM (what `timeout`, a CI runner or a scheduler sends) to the process that supervises the ranks: Python's default action
+    would end it without any clean-up and the ranks -- their own sessions -- would keep their GPUs and the rendezvous port.
+    spawn_ranks installs a handler for the duration of the call: every rank and its child is gone, exit status 128 + SIGTERM."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    hang = tmp_path / 'hang.py'
+    hang.write_text('import os, subprocess, sys, time\n'
+                    'c = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])\n'
+                    'open(os.path.join(sys.argv[1], "child_%s" % os.environ["RANK"]), "w").write(str(c.pid))\n'
+                    'open(os.path.join(sys.argv[1], "pid_%s" % os.environ["RANK"]), "w").write(str(os.getpid()))\n'
+                    'time.sleep(600)\n')
+    sup = tmp_path / 'sup.py'
+    sup.write_text('import sys\n'
+                   f'sys.path.insert(0, {os.path.dirname(HERE)!r})\n'
+                   'from targetdiff_amd import launch\n'
+                   'sys.exit(launch.spawn_ranks([sys.executable, sys.argv[1], sys.argv[2]], 2, timeout=300))\n')
+    p = subprocess.Popen([sys.executable, str(sup), str(hang), str(tmp_path)])
+    t_end = time.time() + 60
+    names = ('pid_0', 'pid_1', 'child_0', 'child_1')
+    while time.time() < t_end and not all((tmp_path / f).exists() and (tmp_path / f).read_text() for f in names):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f).read_text()) for f in names]
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    assert rc == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:
+        alive = subprocess.run(['ps', '-p', str(pid), '-o', 'stat='], capture_output=True, text=True).stdout.strip()
+        assert alive == '' or alive.startswith('Z'), (pid, alive)
+    # the handlers are gone again in a process that returned from spawn_ranks normally
+    import signal as _s
+    before = _s.getsignal(_s.SIGTERM)
+    ok = tmp_path / 'ok.py'
+    ok.write_text('pass\n')
+    assert launch.spawn_ranks([sys.executable, str(ok)], 2, timeout=60) == 0
+    assert _s.getsignal(_s.SIGTERM) is before
+
+
+def test_pinned_devices_honour_the_outer_restriction():
+    """pin_devices under a scheduler that hands out devices through CUDA_VISIBLE_DEVICES (ROCm honours it too): rank r gets the
+    r-th entry of the outer list, and a job with more ranks than entries is refused instead of spilling onto other GPUs."""
+    import pytest
+    env = launch.rank_env(1, 2, 29501, base={'CUDA_VISIBLE_DEVICES': '5,7'}, pin_devices=True)
+    assert env['HIP_VISIBLE_DEVICES'] == '7' and 'CUDA_VISIBLE_DEVICES' not in env and env['LOCAL_RANK'] == '0'
+    env = launch.rank_env(0, 2, 29501, base={'HIP_VISIBLE_DEVICES': '2,3', 'CUDA_VISIBLE_DEVICES': '5,7'}, pin_devices=True)
+    assert env['HIP_VISIBLE_DEVICES'] == '2'                       # HIP_VISIBLE_DEVICES wins
+    with pytest.raises(RuntimeError, match='no device'):
+        launch.rank_env(2, 3, 29501, base={'HIP_VISIBLE_DEVICES': '4,6'}, pin_devices=True)
+    with pytest.raises(RuntimeError, match='no device'):
+        launch.rank_env(1, 2, 29501, base={'CUDA_VISIBLE_DEVICES': '4'}, pin_devices=True)
+
+
+def test_retry_only_when_the_rendezvous_port_was_taken(tmp_path):
+    """A rank that fails at once is retried on a new port only when its stderr says the port could not be bound; any other
+    early failure is reported as it is (one run), even if something unrelated listens on the port."""
+    import sys
+    count = tmp_path / 'runs'
+    script = tmp_path / 'w.py'
+    script.write_text('import os, sys\n'
+                      f'open({str(count)!r}, "a").write(os.environ["RANK"] + "\\n")\n'
+                      'if os.environ["RANK"] == "0":\n'
+                      '    sys.stderr.write(sys.argv[1] + "\\n"); sys.exit(7)\n')
+    assert launch.spawn_ranks([sys.executable, str(script), 'some other failure'], 2, timeout=60) == 7
+    assert count.read_text().count('0') == 1
+    count.write_text('')
+    assert launch.spawn_ranks([sys.executable, str(script), 'RuntimeError: Address already in use (errno: 98)'], 2, timeout=60) == 7
+    assert count.read_text().count('0') == 2                        # retried once
