@@ -372,6 +372,7 @@ def main():
                          'initial state N(0, I) (see --initial-state)')
     ap.add_argument('--initial-state', action='store_true',
                     help='after the timed region, also time 10 steps from the sampler\'s initial state N(0, I)')
+    ap.add_argument('--no-graph', action='store_true', help='issue the launches of a step one by one instead of replaying the captured hipGraph')
     ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
     ap.add_argument('--no-stateless', action='store_true', help='skip the 10 stateless steps reported as stateless_ms_per_step')
     ap.add_argument('--knn', type=int, default=32, help='fan-in of the k-NN / hybrid graph (C5 sweep: 16, 32, 48, 64)')
@@ -429,7 +430,7 @@ def main():
         raise SystemExit('warmup + steps + the profiled steps must be <= 1000 (one sampling run)')
     sampler = model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
                                    lpos, lv, batch.ligand_element_batch, num_steps=total, center_pos_mode='protein',
-                                   max_graph_nodes=max_nodes, use_session=not args.no_session)
+                                   max_graph_nodes=max_nodes, use_session=not args.no_session, use_graph=False if args.no_graph else None)
     for _ in range(args.warmup):
         sampler.step()
 
@@ -440,6 +441,8 @@ def main():
         sampler.step()
     fence()
     elapsed = time.perf_counter() - t0
+    step_launch = ('one hipGraph replay per step (td_session_step)' if sampler.session is not None and sampler.session.last_step_was_graph()
+                   else 'launch by launch')
     # roofline leg: the next steps of the same run with HIP events around the x2h key / value launches, recorded on the
     # launch stream (td_profile_begin / td_profile_end); their launch times feed `roofline`, not `value`
     classes = capi.PROFILE_CLASSES if args.profile_all else ('x2h_k', 'x2h_v')
@@ -559,6 +562,7 @@ def main():
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
                    'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
+                   'step_launch': step_launch,
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
     }

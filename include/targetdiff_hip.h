@@ -35,7 +35,7 @@ extern "C" {
 #define TD_ENOMEM (-2)      /* workspace too small or allocation failure */
 #define TD_EHIP (-3)        /* HIP runtime error (message in td_last_error) */
 
-#define TD_ABI_VERSION 3
+#define TD_ABI_VERSION 4
 
 typedef struct td_model td_model;
 
@@ -107,7 +107,9 @@ int td_model_get_option(const td_model *m, const char *name, int32_t *value);
 
 /* ---- workspace ---------------------------------------------------------------------------------- */
 /* Bytes of scratch td_refine_forward / td_model_forward need for a batch of N nodes (N_l of them ligand)
- * in B graphs. */
+ * in B graphs.  Graph modes other than the 32-slot default (k > 32, hybrid, radius cap > 32), td_knn and td_graph_build
+ * additionally take ONE stream-ordered block (hipMallocAsync on `stream`, freed in stream order before the call returns) for
+ * the chunked neighbour table, whose size depends on the per-graph atom counts and is not known from (N, B, N_l) alone. */
 size_t td_workspace_bytes(const td_model *m, int64_t N, int64_t B, int64_t N_l);
 
 /* ---- graph bookkeeping ---------------------------------------------------------------------------
@@ -218,7 +220,9 @@ int td_center_pos(float *d_protein_pos, const int32_t *d_protein_ptr, float *d_l
  *      lists and -- for protein atoms whose 32-NN row no ligand atom enters -- the edge-gate row and the layer-0 x2h
  *      output.  td_session_forward = ScorePosNet3D.forward for the current ligand state; its results equal
  *      td_model_forward's (same kernels, same per-row arithmetic; neighbour rows bit-identical).  The session owns its
- *      device memory; one forward at a time per session. */
+ *      device memory; one forward at a time per session.  The memory is stream-ordered (hipMallocAsync / hipFreeAsync): the
+ *      stream of the session's latest call must still exist when td_session_destroy runs (if it does not, the free falls back
+ *      to a device synchronisation + hipFree). */
 typedef struct td_session td_session;
 int td_session_create(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
                       const int32_t *d_protein_ptr, int64_t N_p, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
@@ -226,6 +230,39 @@ int td_session_create(const td_model *m, const float *d_protein_pos, const float
 void td_session_destroy(td_session *s);
 int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *d_ligand_v, float *d_pred_ligand_pos,
                        float *d_pred_ligand_v, float *d_final_ligand_h, void *stream);
+/* ---- one reverse-diffusion step as a single replayable unit (replaces the loop body of ScorePosNet3D.sample_diffusion,
+ *      models/molopt_score_model.py:650-693: forward, posterior mean / variance + noise :673-679, categorical posterior +
+ *      Gumbel-max draw :682-685, trajectory appends :687-693).  = td_session_forward on the current ligand state followed by
+ *      td_posterior_step, with everything that differs from step to step held in DEVICE memory, so that the ~50 launches of a
+ *      step form one hipGraph that is captured once (second call) and replayed:
+ *        d_step[0]   index s of the step to run; incremented on the device when the step's last kernel finishes
+ *                    (d_step[1] is scratch of that hand-over and must start as 0).  The caller zeroes both once.
+ *        d_t_all     [num_steps][B] the time step of every graph at step s (:649, :652)
+ *        d_ligand_pos / d_ligand_v   the CURRENT state x_t / v_t: read by the step, then overwritten with x_{t-1} / v_{t-1}
+ *                    (pos_only, :681: the types are left alone)
+ *        d_noise [N_l][3], d_uniform [N_l][C]   this step's draws (:677, :161), refilled by the caller before every call
+ *        d_pos_traj [num_steps][N_l][3], d_v_traj [num_steps][N_l], d_v0_traj / d_vt_traj [num_steps][N_l][C] (or NULL):
+ *                    slot s receives x_{t-1}, v_{t-1}, log v0 (:683) and the log posterior (:684)
+ *      use_graph = 0 issues the launches one by one (also the behaviour while the kernel timers or the workgroup trace are
+ *      armed, and after a failed capture): the same kernels with the same arguments either way, so the results are the same
+ *      bits.  The captured graph belongs to the session and is re-captured if `io` changes.  td_session_step_graph reports
+ *      whether the last td_session_step replayed a graph (1) or launched eagerly (0). */
+typedef struct td_step_io {
+    int32_t *d_step;
+    const int32_t *d_t_all;
+    int32_t num_steps;
+    int32_t pos_only;
+    float *d_ligand_pos;
+    int64_t *d_ligand_v;
+    const float *d_noise;
+    const float *d_uniform;
+    float *d_pos_traj;
+    int64_t *d_v_traj;
+    float *d_v0_traj;
+    float *d_vt_traj;
+} td_step_io;
+int td_session_step(td_session *s, const td_step_io *io, int32_t use_graph, void *stream);
+int td_session_step_graph(const td_session *s);
 /* rows processed by the last td_session_forward: counts[0] = N, counts[1] = rows recomputed at layer 0 (ligand +
  * displaced protein rows), counts[2 + k] = size of receptive-field level k + 1 of the ligand outputs (level 1 = ligand
  * atoms + their neighbours, level k + 1 = level k + its neighbours; the layer e from the end updates level e + 1 only),
@@ -251,6 +288,10 @@ int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const f
 /* ---- test hook: one wave evaluates the cross-lane reduction helpers on 64 inputs; out[6][64] =
  *      {sum over groups of 8, sum over half-waves, sum over the wave, lo+hi half sum, lo/hi half max, other half}. */
 int td_debug_reductions(const float *d_in64, float *d_out6x64, void *stream);
+
+/* ---- test hook (fault injection): the nth stream-ordered device allocation the library makes from now on fails with
+ *      TD_ENOMEM (0 = off).  Used to check that no entry point leaks the blocks it took before the failing one. */
+int td_debug_fail_alloc(int32_t nth);
 
 /* ---- profiling hook: wall clock of every workgroup of the x2h key / x2h value / fused h2x launches.  d_buf [slots][3 passes]
  *      [256 workgroups][8] uint64 in s_memrealtime ticks (the 100 MHz reference clock: comparable across CUs): 0 = the row loop

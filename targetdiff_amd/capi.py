@@ -31,7 +31,7 @@ class TdConfig(ctypes.Structure):
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
 MAX_FANIN = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 # every symbol include/targetdiff_hip.h declares: (restype, argtypes)
@@ -69,12 +69,22 @@ SIGNATURES = {
     'td_session_destroy': (None, [_P]),
     'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
     'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
+    'td_session_step': (c_int32, [_P, _P, c_int32, _P]),
+    'td_session_step_graph': (c_int32, [_P]),
+    'td_debug_fail_alloc': (c_int32, [c_int32]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
     'td_debug_wg_trace': (c_int32, [_P, c_int32]),
     'td_profile_begin': (c_int32, [ctypes.c_uint32]),
     'td_profile_end': (c_int32, [POINTER(c_float), POINTER(c_int32), c_int32]),
 }
+
+class StepIO(ctypes.Structure):
+    """td_step_io of include/targetdiff_hip.h: the per-step arguments of td_session_step, all in device memory"""
+    _fields_ = [('d_step', c_void_p), ('d_t_all', c_void_p), ('num_steps', c_int32), ('pos_only', c_int32),
+                ('d_ligand_pos', c_void_p), ('d_ligand_v', c_void_p), ('d_noise', c_void_p), ('d_uniform', c_void_p),
+                ('d_pos_traj', c_void_p), ('d_v_traj', c_void_p), ('d_v0_traj', c_void_p), ('d_vt_traj', c_void_p)]
+
 
 PROFILE_CLASSES = ('knn', 'gate', 'node_proj', 'x2h_k', 'x2h_v', 'h2x_k', 'h2x_v', 'compose', 'head', 'posterior')
 
@@ -462,6 +472,36 @@ class NativeSession:
                                            _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(pred_pos), _ptr(pred_v),
                                            _ptr(lig_h), _stream(self.device)), 'td_session_forward')
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': None, 'final_ligand_h': lig_h}
+
+    def make_step_io(self, step_index, t_all, ligand_pos, ligand_v, noise, uniform, pos_traj, v_traj, v0_traj=None,
+                     vt_traj=None, pos_only=False) -> StepIO:
+        """The argument block of :meth:`step`; the tensors must stay alive (and in place) for as long as it is used."""
+        S = int(t_all.shape[0])
+        if step_index.numel() != 2 or pos_traj.shape[0] != S or v_traj.shape[0] != S:
+            raise ValueError('step_index must hold 2 int32, the trajectories one slot per step')
+        io = StepIO()
+        io.d_step = _ptr(step_index, torch.int32, 'step_index').value
+        io.d_t_all = _ptr(t_all, torch.int32, 't_all').value
+        io.num_steps, io.pos_only = S, int(bool(pos_only))
+        io.d_ligand_pos = _ptr(ligand_pos, torch.float32, 'ligand_pos').value
+        io.d_ligand_v = _ptr(ligand_v, torch.int64, 'ligand_v').value
+        io.d_noise = _ptr(noise, torch.float32, 'noise').value
+        io.d_uniform = _ptr(uniform, torch.float32, 'uniform').value
+        io.d_pos_traj = _ptr(pos_traj, torch.float32, 'pos_traj').value
+        io.d_v_traj = _ptr(v_traj, torch.int64, 'v_traj').value
+        io.d_v0_traj = _ptr(v0_traj, torch.float32, 'v0_traj').value if v0_traj is not None and v0_traj.numel() else None
+        io.d_vt_traj = _ptr(vt_traj, torch.float32, 'vt_traj').value if vt_traj is not None and vt_traj.numel() else None
+        return io
+
+    def step(self, io: StepIO, use_graph=True):
+        """One reverse-diffusion step (denoiser + posterior update + trajectory record) as one replayable unit
+        (td_session_step): captured into a hipGraph at the second call, replayed from then on."""
+        with _on(self.device):
+            _check(self.lib.td_session_step(self.handle, ctypes.byref(io), int(bool(use_graph)), _stream(self.device)),
+                   'td_session_step')
+
+    def last_step_was_graph(self) -> bool:
+        return bool(self.lib.td_session_step_graph(self.handle))
 
     def row_counts(self):
         """(N, rows recomputed at layer 0, [receptive-field level sizes ...]) of the last forward; synchronises.

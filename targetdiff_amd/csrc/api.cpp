@@ -740,8 +740,40 @@ struct GraphPlan {
     float *ew = nullptr, *alpha = nullptr;
 };
 
+void free_async_or_sync(void *p, hipStream_t s);
+// td_debug_fail_alloc: the n-th stream-ordered allocation from now fails (fault injection for the error paths)
+std::atomic<int> g_fail_alloc{0};
+hipError_t td_malloc_async(void **p, size_t bytes, hipStream_t s) {
+    int n = g_fail_alloc.load(std::memory_order_relaxed);
+    while (n > 0 && !g_fail_alloc.compare_exchange_weak(n, n - 1)) {}
+    if (n == 1) { *p = nullptr; return hipErrorOutOfMemory; }
+    return hipMallocAsync(p, bytes, s);
+}
+// stream-ordered scratch of one call: every block taken so far is given back on every exit path (a failing second or third
+// allocation used to leak the earlier ones)
+struct AsyncScratch {
+    hipStream_t s;
+    std::vector<void *> blocks;
+    explicit AsyncScratch(hipStream_t st) : s(st) {}
+    AsyncScratch(const AsyncScratch &) = delete;
+    AsyncScratch &operator=(const AsyncScratch &) = delete;
+    ~AsyncScratch() { for (void *b : blocks) free_async_or_sync(b, s); }
+    template <class T>
+    int take(T **out, size_t bytes, const char *who) {
+        void *p = nullptr;
+        hipError_t e = td_malloc_async(&p, bytes ? bytes : 4, s);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            td_set_error("%s: hipMallocAsync(%zu) failed: %s", who, bytes, hipGetErrorString(e));
+            return TD_ENOMEM;
+        }
+        blocks.push_back(p);
+        *out = static_cast<T *>(p);
+        return TD_OK;
+    }
+};
 void plan_destroy(GraphPlan &p, hipStream_t s) {
-    if (p.block) (void)hipFreeAsync(p.block, s);
+    free_async_or_sync(p.block, s);
     p.block = nullptr;
 }
 
@@ -774,7 +806,7 @@ int plan_create(const td_config &c, const int32_t *host_pptr, const int32_t *hos
                  o_nbr = reserve((size_t)nc * TD_K * 4), o_ew = reserve((size_t)nc * TD_K * 4),
                  o_al = reserve((size_t)nc * TD_HEADS * TD_K * 4), o_pn = reserve((size_t)p.Np * 4),
                  o_pp = reserve((size_t)(B + 1) * 4), o_meta = reserve(meta.size() * 4);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&p.block), off, s);
+    hipError_t e = td_malloc_async(reinterpret_cast<void **>(&p.block), off, s);
     if (e != hipSuccess) { td_set_error("graph plan: hipMallocAsync(%zu) failed: %s", off, hipGetErrorString(e)); return TD_ENOMEM; }
     char *b = p.block;
     p.cptr = reinterpret_cast<int32_t *>(b + o_cptr); p.chunk_node = reinterpret_cast<int32_t *>(b + o_cn);
@@ -882,13 +914,15 @@ extern "C" int td_knn(const float *d_x, const int32_t *d_node_ptr, int64_t N, in
     if (N == 0) return TD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scratch: float4 coordinates + graph ids (stream-ordered allocation keeps the call self-contained)
+    AsyncScratch scratch(s);
     float4 *x4 = nullptr;
     int32_t *gid = nullptr;
-    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&x4), (size_t)N * sizeof(float4), s));
-    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&gid), (size_t)N * sizeof(int32_t), s));
+    int rc;
+    if ((rc = scratch.take(&x4, (size_t)N * sizeof(float4), "td_knn")) != TD_OK) return rc;
+    if ((rc = scratch.take(&gid, (size_t)N * sizeof(int32_t), "td_knn")) != TD_OK) return rc;
     TD_CHECK_HIP(hipMemsetAsync(gid, 0, (size_t)N * sizeof(int32_t), s));
     // the ligand flag (.w) is irrelevant for the search: pack with an all-zero mask (gid is zero-filled scratch)
-    int rc = td_launch_pack_x(d_x, reinterpret_cast<const uint8_t *>(gid), N, x4, s);
+    rc = td_launch_pack_x(d_x, reinterpret_cast<const uint8_t *>(gid), N, x4, s);
     if (rc == TD_OK) rc = td_launch_node_gid(d_node_ptr, N, B, gid, s);
     if (rc == TD_OK && k == TD_K) rc = td_launch_knn(x4, d_node_ptr, gid, N, max_graph_nodes, d_out_nbr, s);
     else if (rc == TD_OK) {
@@ -909,8 +943,6 @@ extern "C" int td_knn(const float *d_x, const int32_t *d_node_ptr, int64_t N, in
             plan_destroy(p, s);
         }
     }
-    (void)hipFreeAsync(x4, s);
-    (void)hipFreeAsync(gid, s);
     return rc;
 }
 
@@ -922,12 +954,14 @@ extern "C" int td_graph_build(const td_model *m, const float *d_x, const uint8_t
     }
     if (N == 0) return TD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    AsyncScratch scratch(s);
     float4 *x4 = nullptr;
     int32_t *gid = nullptr, *lig = nullptr;
-    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&x4), (size_t)N * sizeof(float4), s));
-    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&gid), (size_t)N * sizeof(int32_t), s));
-    TD_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&lig), (size_t)(N + 1) * sizeof(int32_t), s));
-    int rc = td_launch_pack_x(d_x, d_mask_ligand, N, x4, s);
+    int rc;
+    if ((rc = scratch.take(&x4, (size_t)N * sizeof(float4), "td_graph_build")) != TD_OK) return rc;
+    if ((rc = scratch.take(&gid, (size_t)N * sizeof(int32_t), "td_graph_build")) != TD_OK) return rc;
+    if ((rc = scratch.take(&lig, (size_t)(N + 1) * sizeof(int32_t), "td_graph_build")) != TD_OK) return rc;
+    rc = td_launch_pack_x(d_x, d_mask_ligand, N, x4, s);
     if (rc == TD_OK) rc = td_launch_node_gid(d_node_ptr, N, B, gid, s);
     if (rc == TD_OK) rc = td_launch_ligand_list(d_mask_ligand, N, lig, lig + N, s);
     GraphPlan p;
@@ -940,9 +974,6 @@ extern "C" int td_graph_build(const td_model *m, const float *d_x, const uint8_t
         if (rc == TD_OK) rc = td_launch_slots_to_dense(p.cptr, p.cnbr, N, width, d_out_nbr, s);
         plan_destroy(p, s);
     }
-    (void)hipFreeAsync(x4, s);
-    (void)hipFreeAsync(gid, s);
-    (void)hipFreeAsync(lig, s);
     return rc;
 }
 
@@ -1316,6 +1347,11 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
     return td_launch_node_proj(stage == 0 ? L.nodeX2h : L.nodeH2x, d_h, N, nullptr, 0x1f, d_P, d_q, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int td_debug_fail_alloc(int32_t nth) {
+    g_fail_alloc.store(nth > 0 ? nth : 0);
+    return TD_OK;
+}
+
 extern "C" int td_debug_wg_trace(uint64_t *d_buf, int32_t slots) {
     return td_set_wg_trace(reinterpret_cast<unsigned long long *>(d_buf), d_buf ? slots : 0);
 }
@@ -1356,6 +1392,13 @@ struct td_session {
     bool caching;                // static-protein caching + receptive-field pruning (false: PLAIN)
     bool chunked;                // general graph: the neighbour table lives in `plan`
     GraphPlan plan;
+    // td_session_step: the denoiser's outputs of the step, and the step as a captured graph
+    float *pred_pos, *pred_v;
+    hipGraph_t graph;
+    hipGraphExec_t graph_exec;
+    td_step_io graph_io;         // the arguments the graph was captured with
+    int eager_steps;             // steps issued launch by launch so far (the first one also does the one-time kernel set-up)
+    bool graph_failed, last_step_graph;
 };
 
 namespace {
@@ -1367,10 +1410,28 @@ GraphTab session_tab(td_session *S) {
     return gt;
 }
 
+// stream-ordered free with a fallback: the stream may have been destroyed by the caller in the meantime (a C-ABI user with its own
+// hipStreamCreate / hipStreamDestroy) -- then synchronise the device and free synchronously instead of leaking the block
+void free_async_or_sync(void *p, hipStream_t s) {
+    if (!p) return;
+    if (hipFreeAsync(p, s) == hipSuccess) return;
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p);
+}
+
+void session_drop_graph(td_session *S) {
+    if (S->graph_exec) (void)hipGraphExecDestroy(S->graph_exec);
+    if (S->graph) (void)hipGraphDestroy(S->graph);
+    S->graph_exec = nullptr;
+    S->graph = nullptr;
+}
+
 void session_free(td_session *S, hipStream_t s) {
     if (!S) return;
+    session_drop_graph(S);
     if (S->chunked) plan_destroy(S->plan, s);
-    if (S->block) (void)hipFreeAsync(S->block, s);
+    free_async_or_sync(S->block, s);
     delete S;
 }
 }  // namespace
@@ -1414,8 +1475,9 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
                  o_frows = reserve(C ? n * 4 : 0), o_frest = reserve(C ? n * 4 : 0), o_fcnt = reserve(256),
                  o_P0 = reserve(C ? n * 4 * TD_H * 4 : 0), o_q0 = reserve(C ? n * TD_H * 4 : 0), o_clean = reserve(C ? n : 0),
                  o_dirty = reserve(C ? n * 4 : 0), o_dcnt = reserve(256), o_hop = reserve(C ? n * 4 * TD_HOP_LEVELS : 0),
-                 o_hcnt = reserve(256), o_dchunks = reserve(C && S->chunked ? nc * 4 : 0);
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&S->block), off, s);
+                 o_hcnt = reserve(256), o_dchunks = reserve(C && S->chunked ? nc * 4 : 0),
+                 o_ppos = reserve((size_t)N_l * 3 * 4), o_pv = reserve((size_t)N_l * TD_MAXC * 4);
+    hipError_t e = td_malloc_async(reinterpret_cast<void **>(&S->block), off, s);
     if (e != hipSuccess) {
         td_set_error("td_session_create: hipMallocAsync(%zu) failed: %s", off, hipGetErrorString(e));
         S->block = nullptr;
@@ -1446,6 +1508,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->hop_rows = reinterpret_cast<int32_t *>(b + o_hop);
     S->hop_count = reinterpret_cast<int32_t *>(b + o_hcnt);
     S->dirty_chunks = reinterpret_cast<int32_t *>(b + o_dchunks);
+    S->pred_pos = reinterpret_cast<float *>(b + o_ppos);
+    S->pred_v = reinterpret_cast<float *>(b + o_pv);
     {
         // receptive-field levels tracked per step (each prunes one more layer from the end)
         int lv = m->opt.session_hop_levels;
@@ -1624,6 +1688,63 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     return td_launch_head(m->head, w.h, xf, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
 }
+
+namespace {
+// the launches of one step, in order (eagerly or into a capturing stream)
+int session_step_issue(td_session *S, const td_step_io &io, hipStream_t s) {
+    const td_model *m = S->m;
+    int rc = td_session_forward(S, io.d_ligand_pos, io.d_ligand_v, S->pred_pos, S->pred_v, nullptr, s);
+    if (rc != TD_OK) return rc;
+    ProfScope ps(PC_POST, s);
+    return td_launch_posterior_step(m->sched, m->cfg.num_timesteps, io.d_step, io.d_t_all, io.num_steps, S->lptr, S->Nl, S->B,
+                                    m->cfg.ligand_num_classes, io.d_ligand_pos, io.d_ligand_v, S->pred_pos, S->pred_v, io.d_noise,
+                                    io.d_uniform, io.d_pos_traj, io.d_v_traj, io.d_v0_traj, io.d_vt_traj, io.pos_only, s);
+}
+}  // namespace
+
+extern "C" int td_session_step(td_session *S, const td_step_io *io, int32_t use_graph, void *stream) {
+    if (!S || !io || !io->d_step || !io->d_t_all || io->num_steps < 1 || !io->d_ligand_pos || !io->d_ligand_v || !io->d_noise ||
+        !io->d_uniform || !io->d_pos_traj || !io->d_v_traj) {
+        td_set_error("td_session_step: bad argument");
+        return TD_EINVAL;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    S->last_step_graph = false;
+    // measurement hooks put events / trace pointers into the launch sequence: those steps are issued launch by launch
+    const bool graph_ok = use_graph && !S->graph_failed && g_prof.mask == 0 && !td_wg_trace_armed();
+    if (graph_ok && S->graph_exec && memcmp(&S->graph_io, io, sizeof(td_step_io)) != 0) session_drop_graph(S);
+    if (graph_ok && !S->graph_exec && S->eager_steps > 0) {
+        // capture the launch sequence of a step (nothing executes while the stream captures), instantiate it once
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+        if (e == hipSuccess) {
+            const int rc = session_step_issue(S, *io, s);
+            hipGraph_t g = nullptr;
+            e = hipStreamEndCapture(s, &g);
+            if (rc == TD_OK && e == hipSuccess && g) {
+                e = hipGraphInstantiate(&S->graph_exec, g, nullptr, nullptr, 0);
+                if (e == hipSuccess) { S->graph = g; S->graph_io = *io; }
+                else { (void)hipGraphDestroy(g); S->graph_exec = nullptr; }
+            } else if (g) {
+                (void)hipGraphDestroy(g);
+            }
+        }
+        if (!S->graph_exec) {       // not fatal: this session keeps issuing its steps launch by launch
+            (void)hipGetLastError();
+            S->graph_failed = true;
+        }
+    }
+    if (graph_ok && S->graph_exec) {
+        S->last_stream = s;
+        TD_CHECK_HIP(hipGraphLaunch(S->graph_exec, s));
+        S->last_step_graph = true;
+        return TD_OK;
+    }
+    const int rc = session_step_issue(S, *io, s);
+    if (rc == TD_OK) ++S->eager_steps;
+    return rc;
+}
+
+extern "C" int td_session_step_graph(const td_session *S) { return S && S->last_step_graph ? 1 : 0; }
 
 extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_t n_counts, void *stream) {
     if (!S || !host_counts || n_counts < 2) { td_set_error("td_session_row_counts: bad argument"); return TD_EINVAL; }

@@ -1377,6 +1377,7 @@ int td_set_wg_trace(unsigned long long *buf, int slots) {
     g_wg_trace_launch[0] = g_wg_trace_launch[1] = g_wg_trace_launch[2] = 0;
     return TD_OK;
 }
+bool td_wg_trace_armed() { return g_wg_trace != nullptr; }
 static unsigned long long *wg_trace_slot(int pass) {
     if (!g_wg_trace) return nullptr;
     const int n = g_wg_trace_launch[pass]++ % g_wg_trace_slots;

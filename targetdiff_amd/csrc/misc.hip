@@ -83,24 +83,34 @@ __device__ __forceinline__ int td_find_graph_l(const int32_t *__restrict__ ptr, 
     return lo;
 }
 
-__global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restrict__ tg,
-                                 const int32_t *__restrict__ lptr, int64_t Nl, int B, int C,
-                                 const float *__restrict__ pos, const int64_t *__restrict__ v,
-                                 const float *__restrict__ pred_pos, const float *__restrict__ pred_v,
-                                 const float *__restrict__ noise, const float *__restrict__ uni,
-                                 float *__restrict__ pos_next, int64_t *__restrict__ v_next,
-                                 float *__restrict__ log_v0_out, float *__restrict__ log_post_out) {
-    const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (at >= Nl) return;
+// one ligand atom of the posterior update.  pos / v may alias pos_next / v_next (the in-place form of td_session_step): every input of
+// the atom is read before its outputs are written, and atoms do not read each other.  pos_cur / v_cur (optional): second copies
+// of x_{t-1} / v_{t-1} (the trajectory slot and the current state of td_session_step); v_frozen: pos_only, v_next = the input type.
+__device__ __forceinline__ void td_posterior_atom(const TdSchedules &sc, int T, const int32_t *__restrict__ tg,
+                                                  const int32_t *__restrict__ lptr, int B, int C, int64_t at,
+                                                  const float *pos, const int64_t *v,
+                                                  const float *__restrict__ pred_pos, const float *__restrict__ pred_v,
+                                                  const float *__restrict__ noise, const float *__restrict__ uni,
+                                                  float *pos_next, int64_t *v_next,
+                                                  float *__restrict__ log_v0_out, float *__restrict__ log_post_out,
+                                                  float *pos_cur = nullptr, int64_t *v_cur = nullptr, bool v_frozen = false) {
     const int g = td_find_graph_l(lptr, B, (int)at);
     int t = tg[g];
     t = t < 0 ? 0 : (t >= T ? T - 1 : t);
     // ---- positions: mean = c0[t] x0 + ct[t] x_t ; x_{t-1} = mean + [t != 0] exp(0.5 logvar[t]) eps  (:673-679)
     const float c0 = sc.c0[t], ct = sc.ct[t];
     const float sd = t == 0 ? 0.f : expf(0.5f * sc.logvar[t]);
+    float xn[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-        pos_next[at * 3 + d] = (c0 * pred_pos[at * 3 + d] + ct * pos[at * 3 + d]) + sd * noise[at * 3 + d];
+    for (int d = 0; d < 3; ++d)       // three products, two sums, each rounded on its own -- PyTorch's eager arithmetic (:376, :679), and the
+                                      // same bits in every kernel this function is inlined into (no compiler-chosen FMA contraction)
+        xn[d] = td_add_rn(td_add_rn(td_mul_rn(c0, pred_pos[at * 3 + d]), td_mul_rn(ct, pos[at * 3 + d])), td_mul_rn(sd, noise[at * 3 + d]));
+    const int vt = (int)v[at];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        pos_next[at * 3 + d] = xn[d];
+        if (pos_cur) pos_cur[at * 3 + d] = xn[d];
+    }
     // ---- types (:682-685)
     float lg[TD_MAXC];
     float mx = -INFINITY;
@@ -117,7 +127,6 @@ __global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restric
     const float lnK = logf((float)C);
     const float l_ca = sc.log_ca[tm1], l_1mca = sc.log_1mca[tm1] - lnK;
     const float l_a = sc.log_a[t], l_1ma = sc.log_1ma[t] - lnK;
-    const int vt = (int)v[at];
     const float LOG_EPS = logf(1e-30f);                         // log(clamp(onehot, 1e-30)), :129
     float un[TD_MAXC];
     float umx = -INFINITY;
@@ -150,8 +159,51 @@ __global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restric
             if (sc2 > bestv) { bestv = sc2; best = cc; }        // first maximum, like argmax
         }
     }
+    if (v_frozen) best = vt;
     v_next[at] = best;
+    if (v_cur) v_cur[at] = best;
 }
+
+__global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restrict__ tg,
+                                 const int32_t *__restrict__ lptr, int64_t Nl, int B, int C,
+                                 const float *__restrict__ pos, const int64_t *__restrict__ v,
+                                 const float *__restrict__ pred_pos, const float *__restrict__ pred_v,
+                                 const float *__restrict__ noise, const float *__restrict__ uni,
+                                 float *__restrict__ pos_next, int64_t *__restrict__ v_next,
+                                 float *__restrict__ log_v0_out, float *__restrict__ log_post_out) {
+    const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (at >= Nl) return;
+    td_posterior_atom(sc, T, tg, lptr, B, C, at, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0_out, log_post_out);
+}
+
+// td_session_step: the same update with its per-step arguments taken from device memory -- step index s = step[0] selects the
+// time-step row t_all[s] and slot s of the trajectories; the current state (pos / v) is updated in place.  The last workgroup
+// to finish advances the step index (all workgroups have read it by then): the launch is replayable as a graph node.
+__global__ void posterior_step_kernel(TdSchedules sc, int T, int32_t *__restrict__ step, const int32_t *__restrict__ t_all,
+                                      int num_steps, const int32_t *__restrict__ lptr, int64_t Nl, int B, int C,
+                                      float *pos, int64_t *v, const float *__restrict__ pred_pos,
+                                      const float *__restrict__ pred_v, const float *__restrict__ noise,
+                                      const float *__restrict__ uni, float *__restrict__ pos_traj, int64_t *__restrict__ v_traj,
+                                      float *__restrict__ v0_traj, float *__restrict__ vt_traj, int pos_only) {
+    int s = *reinterpret_cast<volatile int32_t *>(step);
+    s = s < 0 ? 0 : (s >= num_steps ? num_steps - 1 : s);
+    const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (at < Nl) {
+        const size_t so = (size_t)s * (size_t)Nl;
+        td_posterior_atom(sc, T, t_all + (size_t)s * B, lptr, B, C, at, pos, v, pred_pos, pred_v, noise, uni, pos_traj + so * 3,
+                          v_traj + so, v0_traj ? v0_traj + so * C : nullptr, vt_traj ? vt_traj + so * C : nullptr, pos,
+                          pos_only ? nullptr : v, pos_only != 0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(step + 1, 1) == (int)gridDim.x - 1) {
+            step[1] = 0;
+            atomicAdd(step, 1);
+        }
+    }
+}
+
 
 int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B,
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
@@ -161,6 +213,18 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
     posterior_kernel<<<dim3((unsigned)((Nl + 127) / 128)), dim3(128), 0, s>>>(
         sc, T, t, lptr, Nl, (int)B, classes, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0,
         log_post);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+int td_launch_posterior_step(const TdSchedules &sc, int T, int32_t *step, const int32_t *t_all, int num_steps, const int32_t *lptr,
+                             int64_t Nl, int64_t B, int classes, float *pos, int64_t *v, const float *pred_pos, const float *pred_v,
+                             const float *noise, const float *uni, float *pos_traj, int64_t *v_traj, float *v0_traj, float *vt_traj,
+                             int pos_only, hipStream_t s) {
+    if (Nl == 0) return TD_OK;
+    posterior_step_kernel<<<dim3((unsigned)((Nl + 127) / 128)), dim3(128), 0, s>>>(
+        sc, T, step, t_all, num_steps, lptr, Nl, (int)B, classes, pos, v, pred_pos, pred_v, noise, uni, pos_traj, v_traj, v0_traj,
+        vt_traj, pos_only);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -124,9 +124,21 @@ __device__ __forceinline__ unsigned long long td_wave_min_u64(unsigned long long
     return v;
 }
 
+// Products and sums rounded one by one, whatever the surrounding expression: HIP's __fmul_rn / __fadd_rn are plain `x * y` / `x + y`
+// (unless OCML_BASIC_ROUNDED_OPERATIONS is defined) and -ffp-contract=fast-honor-pragmas, hipcc's default, may fuse them into FMAs --
+// differently in every kernel the expression is inlined into.  The pragma takes contraction off for these two operations only.
+__device__ __forceinline__ float td_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float td_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 // distance^2 with the project's fixed association and no FMA contraction (oracle/shims.py)
 __device__ __forceinline__ float td_dist2(float dx, float dy, float dz) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return td_add_rn(td_add_rn(td_mul_rn(dx, dx), td_mul_rn(dy, dy)), td_mul_rn(dz, dz));
 }
 
 // 16-byte-per-lane async global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane * 16.

@@ -238,6 +238,7 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
                            hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0,
                            const int32_t *mixed_count = nullptr);
 int td_set_wg_trace(unsigned long long *buf, int slots);
+bool td_wg_trace_armed();
 // graph.hip, general graphs
 int td_launch_layout(const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid, const int32_t *g_cbase,
                      const int32_t *g_cl, const int32_t *g_lbase, int cpn_p, int64_t N, int32_t *cptr, int32_t *chunk_node,
@@ -267,6 +268,10 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
                         const float *pred_v, const float *noise, const float *uni, float *pos_next,
                         int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
+int td_launch_posterior_step(const TdSchedules &sc, int T, int32_t *step, const int32_t *t_all, int num_steps, const int32_t *lptr,
+                             int64_t Nl, int64_t B, int classes, float *pos, int64_t *v, const float *pred_pos, const float *pred_v,
+                             const float *noise, const float *uni, float *pos_traj, int64_t *v_traj, float *v0_traj, float *vt_traj,
+                             int pos_only, hipStream_t s);
 // egnn.hip / node.hip
 int td_launch_egnn_edge(const TdEgnnLayer &L, const float4 *x4, float4 *x4_out, const int32_t *nbr, const float *P, float *mi,
                         int64_t N, hipStream_t s);

@@ -417,17 +417,17 @@ class ScorePosNet3D(nn.Module):
     # ------------------------------------------------------------------------------------------ sampling
     def begin_sampling(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                        num_steps=None, center_pos_mode=None, max_graph_nodes=0, noise_source=None, use_session=True,
-                       pos_only=False):
+                       pos_only=False, generator=None, use_graph=None):
         """Set up the reverse-diffusion state on the device and return a :class:`ReverseSampler`
         (``.step()`` = one iteration of the loop at models/molopt_score_model.py:650-693)."""
         return ReverseSampler(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
                               batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session,
-                              pos_only)
+                              pos_only, generator, use_graph)
 
     @torch.no_grad()
     def sample_diffusion(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                          num_steps=None, center_pos_mode=None, pos_only=False, max_graph_nodes=0,
-                         noise_source=None, use_session=True):
+                         noise_source=None, use_session=True, use_graph=None):
         """Ancestral sampling loop (models/molopt_score_model.py:633-703).
 
         Differences from the reference are confined to *where* things run, not what is computed: no
@@ -436,10 +436,13 @@ class ScorePosNet3D(nn.Module):
         tensors, positions de-centred).  ``noise_source(step, name, like)`` may inject the Gaussian /
         uniform draws (parity tests); by default torch.randn_like / rand_like are used in the reference's
         order.  ``use_session=False`` evaluates the stateless td_model_forward at every step (no static-protein
-        caching); the two are bit-identical (tests/test_gpu_long_parity.py)."""
+        caching); the two are bit-identical (tests/test_gpu_long_parity.py).  With a session the ~50 launches of a step are
+        one replayable unit (td_session_step): ``use_graph=True`` captures them once into a hipGraph and replays it, False issues
+        them one by one, None (default) replays when the caller runs on a real stream -- the same kernels with the same arguments
+        either way, hence the same bits (tests/test_gpu_step_graph.py)."""
         sampler = self.begin_sampling(protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v,
                                       batch_ligand, num_steps, center_pos_mode, max_graph_nodes, noise_source,
-                                      use_session=use_session, pos_only=pos_only)
+                                      use_session=use_session, pos_only=pos_only, use_graph=use_graph)
         while not sampler.done:
             sampler.step()
         return sampler.finish()
@@ -450,8 +453,10 @@ class ReverseSampler:
 
     @torch.no_grad()
     def __init__(self, model, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
-                 num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True, pos_only=False):
+                 num_steps, center_pos_mode, max_graph_nodes, noise_source, use_session=True, pos_only=False, generator=None,
+                 use_graph=None):
         self.pos_only = bool(pos_only)
+        self.generator = generator          # None: torch's global generator (the reference's stream of draws)
         if center_pos_mode not in ('protein', 'none'):
             # center_pos (models/molopt_score_model.py:110-120) raises for anything else -- including the signature
             # default None, which would otherwise sample un-centred (off-distribution) without a word
@@ -489,39 +494,71 @@ class ReverseSampler:
         self.noise_source = noise_source
         self.bufs = {}
         self.s = 0
+        # this step's draws live in fixed buffers, refilled in place every step (the captured step reads them by address)
+        self._noise = torch.empty(Nl, 3, dtype=torch.float32, device=dev)
+        self._uniform = self._half if self.pos_only else torch.empty(Nl, C, dtype=torch.float32, device=dev)
         # loop-invariant protein state lives in a native session (td_session); opt out with use_session=False
         self.session = None
+        self._io = None
+        self.use_graph = use_graph
         if use_session and self.Nl > 0 and self.ppos.shape[0] > 0:
             self.session = capi.NativeSession(native, self.ppos, self.pv, self.pptr, self.lptr, self.Nl, max_graph_nodes)
+            # the whole step (forward + posterior + trajectory record) is one replayable unit: its per-step arguments (step
+            # index -> time step and trajectory slot, current state, draws) sit in device memory
+            self._step_index = torch.zeros(2, dtype=torch.int32, device=dev)
+            if S > 0:
+                self._io = self.session.make_step_io(self._step_index, self.t_all, self.lpos, self.lv, self._noise,
+                                                     self._uniform, self.pos_traj, self.v_traj, self.v0_traj, self.vt_traj,
+                                                     self.pos_only)
+
+    def _graph_now(self):
+        """Replay the step as a captured hipGraph?  ``use_graph=None`` (default): when the caller runs on a real stream (the
+        overlapped batches of sample_diffusion_ligand, a serving loop with its own stream) -- a step cannot be captured on the
+        device's legacy default stream, and moving it to a side stream behind event fences costs more (C1: +10 %) than the
+        replay saves there."""
+        if self.use_graph is not None:
+            return bool(self.use_graph)
+        dev = self.lpos.device
+        return dev.type == 'cuda' and torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev)
 
     @property
     def done(self):
         return self.s >= self.S
 
+    def _draw(self, s):
+        """This step's Gaussian / uniform draws into the fixed buffers, in the reference's order (:677, then :161)."""
+        if self.noise_source is None:
+            # == torch.randn_like(lpos) / torch.rand(Nl, C): the same generator stream, written in place
+            self._noise.normal_(generator=self.generator)
+            if not self.pos_only:
+                self._uniform.uniform_(generator=self.generator)
+        else:
+            self._noise.copy_(self.noise_source(s, 'noise', self.lpos))
+            if not self.pos_only:
+                self._uniform.copy_(self.noise_source(s, 'uniform', self.v0_traj[s]))
+
     @torch.no_grad()
     def step(self):
         s, native = self.s, self.native
-        if self.session is not None:
-            preds = self.session.forward(self.lpos, self.lv, out=self.bufs)
-        else:
-            preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
-                                         max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
+        if self.session is not None and self.S > 0:
+            self._draw(s)
+            self.session.step(self._io, use_graph=self._graph_now())     # lpos / lv are updated in place, slot s of the trajectories filled
+            self.s += 1
+            return
+        preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
+                                     max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
         self.bufs = preds
-        noise = torch.randn_like(self.lpos) if self.noise_source is None else self.noise_source(s, 'noise', self.lpos)   # :677
+        self._draw(s)
         if self.pos_only:
             native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
-                                  preds['pred_ligand_v'], noise, self._half, pos_next=self.pos_traj[s],
+                                  preds['pred_ligand_v'], self._noise, self._half, pos_next=self.pos_traj[s],
                                   v_next=self._v_scratch)
             self.v_traj[s].copy_(self.lv)                                                  # :689
             self.lpos = self.pos_traj[s]
             self.s += 1
             return
-        if self.noise_source is None:
-            uniform = torch.rand(self.Nl, self.C, dtype=torch.float32, device=self.lpos.device)   # :161
-        else:
-            uniform = self.noise_source(s, 'uniform', self.v0_traj[s])
         native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
-                              preds['pred_ligand_v'], noise, uniform, pos_next=self.pos_traj[s],
+                              preds['pred_ligand_v'], self._noise, self._uniform, pos_next=self.pos_traj[s],
                               v_next=self.v_traj[s], log_v0=self.v0_traj[s], log_post=self.vt_traj[s])
         self.lpos, self.lv = self.pos_traj[s], self.v_traj[s]
         self.s += 1

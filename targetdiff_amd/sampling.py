@@ -51,7 +51,7 @@ def unbatch_v_traj(ligand_v_traj, n_data, ligand_cum_atoms):
 def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cuda:0', num_steps=None,
                             pos_only=False, center_pos_mode='protein', sample_num_atoms='prior',
                             atom_num_sampler=None, ligand_num_atoms=None, generator=None, noise_source=None,
-                            overlap_batches=None):
+                            overlap_batches=False, max_resident_batches=8, use_graph=None):
     """Returns (pred_pos, pred_v, pred_pos_traj, pred_v_traj, pred_v0_traj, pred_vt_traj, time_list).
 
     Extra keyword arguments (not in the reference signature; all optional): ``atom_num_sampler`` / ``ligand_num_atoms``
@@ -59,20 +59,23 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
     name, like)`` injects every Gaussian / uniform draw (``step == -1``: the initial positions / types of :60-70; ``step
     >= 0``: the sampler's per-step draws) -- the parity tests use it to replay the reference's draws.
 
-    ``overlap_batches`` (default None = automatic: on when the pocket takes several batches and the draws come from torch's
-    generator, off when they are injected): the sample batches of the pocket (independent of each other, :40) advance together, each
-    on its own HIP stream, instead of one after the other.  A small batch (the signature's default batch_size=16 is ~10 k
-    nodes) cannot fill the GPU -- its step is a chain of ~60 dependent launches -- so overlapping the chains of several
-    batches raises throughput several-fold.  Results per batch are the same bits as in the sequential order when the draws
-    are injected; with torch's global generator the draws are consumed in step-major instead of batch-major order (a
-    different but equally distributed sample), and ``time_list`` holds the wall time of the whole call divided evenly."""
+    ``overlap_batches`` (default False: the reference's order, one batch after the other, torch's global generator consumed
+    batch-major exactly as scripts/sample_diffusion.py does): when True, the sample batches of the pocket (independent of each
+    other, :40) advance together, each on its own HIP stream.  A small batch (the signature's default batch_size=16 is ~10 k
+    nodes) cannot fill the GPU -- its step is a chain of ~50 dependent launches -- so overlapping the chains of several batches
+    raises throughput (1.35x at batch_size 16).  In this mode every batch draws from its OWN generator, seeded from torch's global
+    generator in batch order when the batch is set up, so the result does not depend on how the batches interleave (it differs from
+    the sequential order's sample, equally distributed); injected draws (``noise_source``) give the same bits in both orders.  At
+    most ``max_resident_batches`` batches (sessions + trajectories) are alive at a time: the pocket's batches are processed in
+    groups of that size.  ``time_list`` then holds, per batch, the wall time of its group divided evenly.  ``use_graph``: see
+    ScorePosNet3D.sample_diffusion (None = a captured hipGraph per batch wherever the batch runs on a real stream, i.e. in the
+    overlapped mode)."""
     pocket = _as_pocket(data)
     pocket_dev = None
     time_list = []
     num_batch = int(np.ceil(num_samples / batch_size))
-    if overlap_batches is None:
-        overlap_batches = (noise_source is None and num_batch > 1 and hasattr(model, 'begin_sampling')
-                           and torch.device(device).type == 'cuda')
+    overlap_batches = bool(overlap_batches) and num_batch > 1 and hasattr(model, 'begin_sampling') and torch.device(device).type == 'cuda'
+    max_resident_batches = max(1, int(max_resident_batches))
     current_i = 0
     jobs = []                      # overlap_batches: (n_data, sizes, sampler) per sample batch
     parts = None                   # the six result lists accumulated so far
@@ -113,20 +116,30 @@ def sample_diffusion_ligand(model, data, num_samples, batch_size=16, device='cud
                   batch_protein=batch.protein_element_batch, init_ligand_pos=init_pos, init_ligand_v=init_v,
                   batch_ligand=batch.ligand_element_batch, num_steps=num_steps, pos_only=pos_only,
                   center_pos_mode=center_pos_mode, max_graph_nodes=pocket.num_atoms + max(sizes))
+        if use_graph is not None:
+            kw['use_graph'] = use_graph
         if noise_source is not None:
             kw['noise_source'] = (lambda st, name, like, _i=i: noise_source(_i, st, name, like))
-        if overlap_batches and num_batch > 1:
+        if overlap_batches:
+            if noise_source is None:
+                # the batch's own stream of draws (see the docstring): seeded from the global generator, in batch order
+                g_batch = torch.Generator(device=device)
+                g_batch.manual_seed(int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()))
+                kw['generator'] = g_batch
             jobs.append((n_data, sizes, model.begin_sampling(
                 kw.pop('protein_pos'), kw.pop('protein_v'), kw.pop('batch_protein'), kw.pop('init_ligand_pos'),
                 kw.pop('init_ligand_v'), kw.pop('batch_ligand'), **kw)))
+            if len(jobs) == max_resident_batches or i == num_batch - 1:
+                part = _unbatch(_run_overlapped(jobs, device), pos_only)
+                parts = part if parts is None else tuple(a + b for a, b in zip(parts, part))
+                time_list += [(time.time() - t_all) / len(jobs)] * len(jobs)
+                jobs = []
+                t_all = time.time()
         else:
             part = _unbatch([(n_data, sizes, model.sample_diffusion(**kw))], pos_only)      # inside the timed span, as :86-114
             parts = part if parts is None else tuple(a + b for a, b in zip(parts, part))
             time_list.append(time.time() - t1)
         current_i += n_data
-    if jobs:
-        parts = _unbatch(_run_overlapped(jobs, device), pos_only)
-        time_list = [(time.time() - t_all) / len(jobs)] * len(jobs)
     if parts is None:
         parts = ([], [], [], [], [], [])
     return parts + (time_list,)

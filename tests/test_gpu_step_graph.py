@@ -1,0 +1,235 @@
+"""td_session_step: one reverse-diffusion step (denoiser forward + posterior update + trajectory record) as one replayable unit.
+The captured hipGraph, the same launches issued one by one, the two-call form (td_session_forward + td_posterior_step) and the
+stateless forward must produce the same bits; the sampler's in-place draws must be the reference-order draws; full-size
+session == stateless checks (the geometry the benchmark times); error paths give their device memory back."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pocket_1h36
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def model(state_dict):
+    from oracle import weights
+    from targetdiff_amd.models import ScorePosNet3D
+    m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+    assert not m.load_state_dict(state_dict, strict=False).unexpected_keys
+    return m.to(_dev()).eval()
+
+
+def _run(model, batch, lpos, lv, steps, base, **kw):
+    from oracle import draws
+    dev = _dev()
+    b = batch.to(dev)
+    sampler = model.begin_sampling(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev),
+                                   b.ligand_element_batch, num_steps=steps, center_pos_mode='protein',
+                                   noise_source=draws.Source(base, dev), **kw)
+    graph_steps = 0
+    side = torch.cuda.Stream(device=dev)          # a step is captured on a real stream (not the device's legacy default stream)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        while not sampler.done:
+            sampler.step()
+            if sampler.session is not None and sampler.session.last_step_was_graph():
+                graph_steps += 1
+        out = sampler.finish()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    return out, graph_steps
+
+
+def _two_call_run(model, batch, lpos, lv, steps, base):
+    """the pre-graph form of the loop body: td_session_forward, then td_posterior_step into the trajectory slot"""
+    from oracle import draws
+    from targetdiff_amd import capi
+    dev = _dev()
+    b = batch.to(dev)
+    nat = model._native(dev)
+    B = b.num_graphs
+    pptr, lptr = nat.graph_ptr(b.protein_element_batch, B), nat.graph_ptr(b.ligand_element_batch, B)
+    ppos, pos = b.protein_pos.clone(), lpos.to(dev).clone().float()
+    nat.center_pos(ppos, pptr, pos, lptr)
+    v = lv.to(dev).clone()
+    sess = capi.NativeSession(nat, ppos, b.protein_atom_feature.float(), pptr, lptr, pos.shape[0], 0)
+    src = draws.Source(base, dev)
+    T, C = model.num_timesteps, model.num_classes
+    pos_traj, v_traj, v0_traj, vt_traj = [], [], [], []
+    for s, t in enumerate(reversed(range(T - steps, T))):
+        preds = sess.forward(pos, v)
+        t32 = torch.full((B,), t, dtype=torch.int32, device=dev)
+        l0, lp = torch.empty(pos.shape[0], C, device=dev), torch.empty(pos.shape[0], C, device=dev)
+        pos, v = nat.posterior_step(t32, lptr, pos, v, preds['pred_ligand_pos'], preds['pred_ligand_v'], src(s, 'noise', pos),
+                                    src(s, 'uniform', l0), log_v0=l0, log_post=lp)
+        pos_traj.append(pos.clone()); v_traj.append(v.clone()); v0_traj.append(l0); vt_traj.append(lp)
+    return [torch.stack(x).cpu() for x in (pos_traj, v_traj, v0_traj, vt_traj)]
+
+
+def test_graph_step_eager_step_two_call_form_and_stateless_are_the_same_bits(model):
+    from targetdiff_amd import workloads
+    pocket, sizes = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 4, sizes[:4])
+    lpos, lv = workloads.init_ligand(batch, generator=torch.Generator().manual_seed(5))
+    steps = 14
+    (rg, n_graph), (re, n_eager), (rs, _) = (_run(model, batch, lpos, lv, steps, 7100, use_graph=True),
+                                            _run(model, batch, lpos, lv, steps, 7100, use_graph=False),
+                                            _run(model, batch, lpos, lv, steps, 7100, use_session=False))
+    assert n_eager == 0
+    assert n_graph == steps - 1, f'{n_graph} of {steps} steps replayed the captured graph (the first one is issued launch by launch)'
+    two = _two_call_run(model, batch, lpos, lv, steps, 7100)
+    for k, key in enumerate(('pos_traj', 'v_traj', 'v0_traj', 'vt_traj')):
+        a = torch.stack(rg[key])
+        assert torch.equal(a, torch.stack(re[key])), ('graph vs eager', key)
+        assert torch.equal(a, torch.stack(rs[key])), ('graph vs stateless', key)
+        ref = two[k]
+        if key == 'pos_traj':          # finish() de-centres the trajectory; the two-call run above stays centred
+            continue
+        assert torch.equal(a, ref), ('graph vs two-call form', key)
+    assert torch.equal(rg['pos'], re['pos']) and torch.equal(rg['v'], re['v'])
+
+
+def test_graph_step_pos_only_and_a_second_sampler(model):
+    """pos_only (the types are frozen, :681) through the captured step; a second sampler of the same model captures its own graph"""
+    from targetdiff_amd import workloads
+    pocket, sizes = pocket_1h36()
+    batch = workloads.pack_samples(pocket, 3, [int(sizes[0])] * 3)
+    lpos, lv = workloads.init_ligand(batch, generator=torch.Generator().manual_seed(6))
+    out = [_run(model, batch, lpos, lv, 6, 7200, use_graph=g, pos_only=True) for g in (True, False, True)]
+    assert out[0][1] == 5 and out[1][1] == 0 and out[2][1] == 5
+    for key in ('pos_traj', 'v_traj'):
+        assert torch.equal(torch.stack(out[0][0][key]), torch.stack(out[1][0][key])), key
+        assert torch.equal(torch.stack(out[0][0][key]), torch.stack(out[2][0][key])), key
+    assert all(torch.equal(v, lv) for v in out[0][0]['v_traj'])
+    assert out[0][0]['v0_traj'] == [] and out[0][0]['vt_traj'] == []
+
+
+def test_in_place_draws_are_the_reference_order_draws():
+    """the sampler refills fixed buffers with normal_() / uniform_(): the same generator stream as torch.randn_like(ligand_pos)
+    followed by torch.rand(N_l, K) (models/molopt_score_model.py:677, :161)"""
+    dev = _dev()
+    x = torch.empty(2231, 3, device=dev)
+    torch.manual_seed(11)
+    a1, b1, a2 = torch.randn_like(x), torch.rand(2231, 13, device=dev), torch.randn_like(x)
+    torch.manual_seed(11)
+    n, u = torch.empty_like(x), torch.empty(2231, 13, device=dev)
+    n.normal_(); u.uniform_()
+    assert torch.equal(n, a1) and torch.equal(u, b1)
+    n.normal_()
+    assert torch.equal(n, a2)
+    g = torch.Generator(device=dev).manual_seed(5)
+    c1 = torch.randn(2231, 3, device=dev, generator=g)
+    g.manual_seed(5)
+    n.normal_(generator=g)
+    assert torch.equal(n, c1)
+
+
+def test_seeded_sampling_is_reproducible_and_overlap_is_interleaving_independent(model):
+    from targetdiff_amd import sampling, workloads
+    dev = _dev()
+    pocket = workloads.synthetic_pocket(78, 140)
+    sizes = [9 + (k % 5) for k in range(11)]
+
+    def run(**kw):
+        torch.manual_seed(123)
+        np.random.seed(123)
+        return sampling.sample_diffusion_ligand(model, pocket, 11, batch_size=3, device=dev, num_steps=8, ligand_num_atoms=sizes, **kw)
+    a, b = run(), run()
+    for x, y in zip(a[:6], b[:6]):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))
+    # overlapped: every batch draws from its own generator (seeded in batch order), so the grouping does not matter
+    c, d, e = run(overlap_batches=True), run(overlap_batches=True, max_resident_batches=2), run(overlap_batches=True, max_resident_batches=1)
+    for x, y, z in zip(c[:6], d[:6], e[:6]):
+        assert all(np.array_equal(p, q) and np.array_equal(p, r) for p, q, r in zip(x, y, z))
+    assert len(c[6]) == len(d[6]) == 4
+
+
+# ------------------------------------------------------------------------------------------ full-size session == stateless
+def _consecutive_steps_equal(model, pockets, spp, sizes, steps, spread, base):
+    from targetdiff_amd import workloads
+    batch = workloads.pack_samples(pockets, spp, sizes)
+    lpos, lv = workloads.init_ligand(batch, generator=torch.Generator().manual_seed(2021), spread=spread)
+    (a, n_graph), (b, _) = _run(model, batch, lpos, lv, steps, base, use_graph=True), _run(model, batch, lpos, lv, steps, base, use_session=False)
+    assert n_graph == steps - 1
+    for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
+        x, y = torch.stack(a[key]), torch.stack(b[key])
+        if not torch.equal(x, y):
+            first = int((x != y).flatten(1).any(dim=1).float().argmax())
+            raise AssertionError(f'{key}: session and stateless differ from step {first} on')
+
+
+def test_session_equals_stateless_50_steps_at_full_c2_size(model):
+    """BASELINE config 2 as the benchmark times it: 1h36 x 100 samples (N = 60,708), a 2 A ligand cloud, 50 consecutive steps (steps 2
+    .. 50 of the session run on merged k-NN lists, cached gate / layer-0 rows and pruned row lists, replayed as a graph): every
+    trajectory entry equals the stateless forward's"""
+    pocket, sizes = pocket_1h36()
+    _consecutive_steps_equal(model, [pocket], 100, [int(s) for s in sizes], 50, 2.0, 7300)
+
+
+@pytest.mark.parametrize('graph', ['knn48', 'hybrid'])
+def test_session_equals_stateless_10_steps_at_c5_size(state_dict, graph):
+    """BASELINE config 5 (a 1000-atom pocket x 256 samples, N = 264k) on the chunked neighbour table: k = 48 and `hybrid`, 10 steps"""
+    from oracle import weights
+    from targetdiff_amd import workloads
+    from targetdiff_amd.models import ScorePosNet3D
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    cfg.update(dict(knn=48) if graph == 'knn48' else dict(cutoff_mode='hybrid'))
+    m = ScorePosNet3D(cfg, 27, 13)
+    m.load_state_dict(state_dict, strict=False)
+    m = m.to(_dev()).eval()
+    pocket = workloads.synthetic_pocket(5000, 1000, 4.0, 21.0)
+    _consecutive_steps_equal(m, [pocket], 256, [30] * 256, 10, 2.0, 7400)
+
+
+# ------------------------------------------------------------------------------------------ error paths
+def test_failing_allocations_leak_nothing(model):
+    """Fault injection (td_debug_fail_alloc): the n-th stream-ordered allocation of an entry point fails -- it must report
+    TD_ENOMEM and give back the blocks it had taken.  60 failing calls on a 2 M-node input would strand >= 1.9 GB if they did not."""
+    from targetdiff_amd import capi
+    dev = _dev()
+    lib = capi.load_library()
+    nat = model._native(dev)
+    N, B = 2_000_000, 4000
+    x = torch.randn(N, 3, device=dev)
+    ptr = torch.arange(0, N + 1, N // B, dtype=torch.int32, device=dev)
+    mask = torch.zeros(N, dtype=torch.uint8, device=dev)
+    out = torch.empty(N, 32, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(dev)
+        return total - free
+    # one good call first: the pool's steady state
+    assert lib.td_knn(x.data_ptr(), ptr.data_ptr(), N, B, 32, 0, out.data_ptr(), st) == 0
+    base = used()
+    for k in range(60):
+        nth = 1 + k % 3
+        lib.td_debug_fail_alloc(nth)
+        if nth <= 2:
+            rc = lib.td_knn(x.data_ptr(), ptr.data_ptr(), N, B, 32, 0, out.data_ptr(), st)
+        else:
+            rc = lib.td_graph_build(nat.handle, x.data_ptr(), mask.data_ptr(), ptr.data_ptr(), N, B, 0, out.data_ptr(), 32, st)
+        lib.td_debug_fail_alloc(0)
+        assert rc == -2 and b'hipMallocAsync' in lib.td_last_error(), (k, rc, lib.td_last_error())
+    grown = used() - base
+    assert grown < 256 * 2 ** 20, f'{grown / 2 ** 20:.0f} MiB stranded by 60 failing calls'
+    # a session whose block cannot be allocated reports it and leaves nothing behind either
+    lib.td_debug_fail_alloc(1)
+    with pytest.raises(RuntimeError, match='hipMallocAsync'):
+        pocket, sizes = pocket_1h36()
+        from targetdiff_amd import workloads
+        b = workloads.pack_samples(pocket, 2, sizes[:2]).to(dev)
+        lpos, lv = workloads.init_ligand(workloads.pack_samples(pocket, 2, sizes[:2]))
+        try:
+            model.begin_sampling(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev),
+                                 b.ligand_element_batch, num_steps=2, center_pos_mode='protein')
+        finally:
+            lib.td_debug_fail_alloc(0)
+    assert lib.td_knn(x.data_ptr(), ptr.data_ptr(), N, B, 32, 0, out.data_ptr(), st) == 0

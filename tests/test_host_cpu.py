@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f'{name} declared in targetdiff_hip.h but not exported'
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
-    assert lib.td_abi_version() == capi.ABI_VERSION == 3
+    assert lib.td_abi_version() == capi.ABI_VERSION == 4
 
 
 def test_weight_blob_layout_matches_library():

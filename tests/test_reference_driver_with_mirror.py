@@ -81,6 +81,29 @@ class StubSession:
         n, pp, pv, pptr, lptr = self.a
         return n.model_forward(pp, pv, pptr, ligand_pos, ligand_v, lptr)
 
+    # td_session_step: forward + posterior update on the state held in `io` (current positions / types updated in place, slot s of
+    # the trajectories filled, the step index advanced)
+    def make_step_io(self, step_index, t_all, ligand_pos, ligand_v, noise, uniform, pos_traj, v_traj, v0_traj=None, vt_traj=None,
+                     pos_only=False):
+        return dict(step=step_index, t_all=t_all, pos=ligand_pos, v=ligand_v, noise=noise, uniform=uniform, pos_traj=pos_traj,
+                    v_traj=v_traj, v0_traj=v0_traj, vt_traj=vt_traj, pos_only=pos_only)
+
+    def step(self, io, use_graph=True):
+        n, pp, pv, pptr, lptr = self.a
+        s = int(io['step'][0])
+        preds = n.model_forward(pp, pv, pptr, io['pos'], io['v'], lptr)
+        full = not io['pos_only']
+        v_next = io['v_traj'][s] if full else torch.empty_like(io['v'])
+        n.posterior_step(io['t_all'][s], lptr, io['pos'], io['v'], preds['pred_ligand_pos'], preds['pred_ligand_v'], io['noise'],
+                         io['uniform'], pos_next=io['pos_traj'][s], v_next=v_next, log_v0=io['v0_traj'][s] if full else None,
+                         log_post=io['vt_traj'][s] if full else None)
+        io['pos'].copy_(io['pos_traj'][s])
+        if full:
+            io['v'].copy_(io['v_traj'][s])
+        else:
+            io['v_traj'][s].copy_(io['v'])
+        io['step'][0] += 1
+
 
 def test_reference_driver_runs_on_the_mirror_and_reproduces_its_own_outputs(monkeypatch):
     from oracle.make_golden import SEED
@@ -95,6 +118,14 @@ def test_reference_driver_runs_on_the_mirror_and_reproduces_its_own_outputs(monk
     native = RecordingNative(sd, cfg, mirror.num_classes, log)
     monkeypatch.setattr(models.ScorePosNet3D, '_native', lambda self, device: native)
     monkeypatch.setattr(capi, 'NativeSession', StubSession)
+
+    # the sampler refills fixed draw buffers in place (normal_ / uniform_); route the draws through randn_like / rand, which the
+    # counter draws below patch, in the same order
+    def draw(self, s):
+        self._noise.copy_(torch.randn_like(self.lpos))
+        if not self.pos_only:
+            self._uniform.copy_(torch.rand(self.Nl, self.C, dtype=torch.float32))
+    monkeypatch.setattr(models.ReverseSampler, '_draw', draw)
     # the mirror draws its per-step uniforms with torch.rand(N_l, K) where the reference calls torch.rand_like (inside
     # log_sample_categorical): route it through rand_like so that the counter draws patched over randn_like / rand_like serve both
     monkeypatch.setattr(torch, 'rand', lambda *size, **kw: torch.rand_like(torch.empty(*size, dtype=kw.get('dtype', torch.float32))))
