@@ -409,7 +409,7 @@ class NativeModel:
         B = protein_ptr.numel() - 1
         compute = offset is None
         if compute:
-            offset = torch.empty(B, 3, dtype=torch.float32, device=ligand_pos.device)
+            offset = torch.empty(B, 3, dtype=torch.float32, device=protein_ptr.device)
         _check(self.lib.td_center_pos(_ptr(protein_pos) if protein_pos is not None else None,
                                       _ptr(protein_ptr, torch.int32, 'protein_ptr'), _ptr(ligand_pos),
                                       _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), B, _ptr(offset), int(compute), sign,

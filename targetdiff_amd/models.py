@@ -32,11 +32,14 @@ def _cfg_get(config, key, default=None):
     return getattr(config, key, default)
 
 
-def _check_graph_inputs(batch_protein, batch_ligand, ligand_v, num_classes):
-    """Host-side input checks at the points where the reference would raise or silently re-order:
+def _check_graph_inputs(batch_protein, batch_ligand, ligand_v, num_classes, allow_unsorted=False):
+    """Host-side input checks at the points where the reference would raise or re-order; returns ``(protein_unsorted,
+    ligand_unsorted)``:
 
-    * ``compose_context`` stable-sorts by graph id (models/common.py:126), so unsorted ``batch_*`` vectors are legal
-      there; the HIP path builds CSR offsets from sorted vectors (td_graph_ptr) -> refuse unsorted input loudly;
+    * ``compose_context`` stable-sorts the concatenated nodes by graph id (models/common.py:126), so unsorted ``batch_*`` vectors
+      are legal there.  The HIP path builds CSR offsets from sorted vectors (td_graph_ptr): callers on that seam pass
+      ``allow_unsorted=True`` and re-order their inputs with :func:`_stable_order` when a flag comes back set (the sorted case
+      -- every PyG batch vector -- pays nothing); the others refuse unsorted input loudly;
     * ``F.one_hot(ligand_v, num_classes)`` (models/molopt_score_model.py:317) and ``index_to_log_onehot`` (:125) raise
       on out-of-range atom types; the kernels would clamp them silently -> same check here.
     One host sync per call (the reference syncs at :316 anyway): the checks reduce to one small device tensor."""
@@ -46,12 +49,21 @@ def _check_graph_inputs(batch_protein, batch_ligand, ligand_v, num_classes):
     if ligand_v is not None and ligand_v.numel():
         flags.append(((ligand_v < 0) | (ligand_v >= num_classes)).any())
     bad = torch.stack([f.to(flags[0].device) for f in flags]).tolist()             # the one synchronisation
-    for name, is_bad in zip(('batch_protein', 'batch_ligand'), bad[:2]):
-        if is_bad:
-            raise ValueError(f'{name} must be sorted by graph id (PyG batch vectors are); got an unsorted vector')
+    if not allow_unsorted:
+        for name, is_bad in zip(('batch_protein', 'batch_ligand'), bad[:2]):
+            if is_bad:
+                raise ValueError(f'{name} must be sorted by graph id (PyG batch vectors are); got an unsorted vector')
     if len(bad) > 2 and bad[2]:
         raise ValueError(f'ligand_v must be in [0, {num_classes}); got values in '
                          f'[{int(ligand_v.min())}, {int(ligand_v.max())}]')
+    return bool(bad[0]), bool(bad[1])
+
+
+def _stable_order(batch):
+    """compose_context's order of one node kind: graphs ascending, the nodes of a graph in their original relative order
+    (``torch.sort(..., stable=True)``, models/common.py:126; protein nodes precede ligand nodes inside a graph because the
+    concatenation puts them first).  Device-side."""
+    return torch.sort(batch, stable=True).indices
 
 
 def _check_sorted(batch, name='batch'):
@@ -364,7 +376,15 @@ class ScorePosNet3D(nn.Module):
         network when time_emb_dim == 0, as in the reference."""
         native = self._native(protein_pos.device)
         B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
-        _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, self.num_classes)
+        unsorted_p, unsorted_l = _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, self.num_classes, allow_unsorted=True)
+        # compose_context (models/common.py:120-137) accepts unsorted batch vectors: it stable-sorts the nodes by graph and the
+        # outputs come back in THAT order (`final_pos[mask_ligand]`, :352 -- the ligand rows are not put back in input order)
+        if unsorted_p:
+            o = _stable_order(batch_protein)
+            protein_pos, protein_v, batch_protein = protein_pos[o], protein_v[o], batch_protein[o]
+        if unsorted_l:
+            o = _stable_order(batch_ligand)
+            init_ligand_pos, init_ligand_v, batch_ligand = init_ligand_pos[o], init_ligand_v[o], batch_ligand[o]
         pptr = native.graph_ptr(batch_protein.contiguous(), B)
         lptr = native.graph_ptr(batch_ligand.contiguous(), B)
         lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
@@ -461,14 +481,22 @@ class ReverseSampler:
             # center_pos (models/molopt_score_model.py:110-120) raises for anything else -- including the signature
             # default None, which would otherwise sample un-centred (off-distribution) without a word
             raise NotImplementedError(f'center_pos_mode={center_pos_mode!r}: pass \'protein\' (configs/sampling.yml) or \'none\'')
-        _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, model.num_classes)
+        unsorted_p, unsorted_l = _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, model.num_classes, allow_unsorted=True)
         dev = protein_pos.device
         self.native = native = model._native(dev)
         T = model.num_timesteps
         num_steps = T if num_steps is None else num_steps
         self.B = B = int(batch_protein.max().item()) + 1                                 # :638 (once, not per step)
+        if unsorted_p:              # the protein never changes: put it in compose_context's order once
+            o = _stable_order(batch_protein)
+            protein_pos, protein_v, batch_protein = protein_pos[o], protein_v[o], batch_protein[o]
+        # Unsorted ligand vector: the reference's loop keeps its state (ligand_pos / ligand_v, :644-646) in INPUT order while every
+        # forward returns its predictions in compose_context's order, and combines the two element by element (:663-685).  Reproduced
+        # as it is: the state stays in input order, each step gathers it into graph order for the denoiser (the slow two-call form
+        # of the step; a sorted vector -- every PyG batch -- takes the fused step).
+        self._lig_order = _stable_order(batch_ligand) if unsorted_l else None
         self.pptr = native.graph_ptr(batch_protein.contiguous(), B)
-        self.lptr = native.graph_ptr(batch_ligand.contiguous(), B)
+        self.lptr = native.graph_ptr((batch_ligand[self._lig_order] if unsorted_l else batch_ligand).contiguous(), B)
         self.ppos = protein_pos.detach().clone().contiguous().float()
         self.lpos = init_ligand_pos.detach().clone().contiguous().float()
         self.lv = init_ligand_v.detach().clone().contiguous()
@@ -477,7 +505,11 @@ class ReverseSampler:
         self.Nl, self.C = self.lpos.shape[0], model.num_classes
         self.offset = None
         if center_pos_mode == 'protein':
-            self.offset = native.center_pos(self.ppos, self.pptr, self.lpos, self.lptr)   # :642
+            if unsorted_l:          # :113-118 with the ligand in input order: the per-graph protein centroid, taken off atom by atom
+                self.offset = native.center_pos(self.ppos, self.pptr, None, self.lptr)
+                self.lpos -= self.offset[batch_ligand]
+            else:
+                self.offset = native.center_pos(self.ppos, self.pptr, self.lpos, self.lptr)   # :642
         steps = list(reversed(range(T - num_steps, T)))                                   # :649
         self.S = S = len(steps)
         Nl, C = self.Nl, self.C
@@ -540,13 +572,19 @@ class ReverseSampler:
     @torch.no_grad()
     def step(self):
         s, native = self.s, self.native
-        if self.session is not None and self.S > 0:
+        if self.session is not None and self.S > 0 and self._lig_order is None:
             self._draw(s)
             self.session.step(self._io, use_graph=self._graph_now())     # lpos / lv are updated in place, slot s of the trajectories filled
             self.s += 1
             return
-        preds = native.model_forward(self.ppos, self.pv, self.pptr, self.lpos, self.lv, self.lptr,
-                                     max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
+        lpos_in, lv_in = self.lpos, self.lv
+        if self._lig_order is not None:
+            lpos_in, lv_in = self.lpos[self._lig_order].contiguous(), self.lv[self._lig_order].contiguous()
+        if self.session is not None:
+            preds = self.session.forward(lpos_in, lv_in, out=self.bufs)
+        else:
+            preds = native.model_forward(self.ppos, self.pv, self.pptr, lpos_in, lv_in, self.lptr,
+                                         max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
         self.bufs = preds
         self._draw(s)
         if self.pos_only:

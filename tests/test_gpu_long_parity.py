@@ -364,18 +364,67 @@ def test_center_pos_mode_none_raises_like_the_reference(model):
                                batch.ligand_element_batch, num_steps=1)
 
 
-def test_unsorted_batch_and_bad_types_are_refused(model):
+def test_unsorted_batch_vectors_follow_compose_context(model, state_dict):
+    """compose_context stable-sorts the nodes by graph id (models/common.py:126): unsorted batch vectors are legal, and the
+    ligand outputs come back in THAT order (not the input order).  Forward: equal to the forward on the pre-sorted inputs bit
+    for bit, and to the oracle restatement on the unsorted inputs within the forward tolerance (the restatement is held to the
+    real reference on unsorted inputs by tests/test_oracle_vs_reference.py).  Out-of-range atom types still raise."""
+    from oracle import restatement as R
+    from oracle import weights
     dev = _dev()
-    batch = _small_batch().to(dev)
-    lpos = torch.zeros(22, 3, device=dev)
-    lv = torch.zeros(22, dtype=torch.long, device=dev)
-    args = (batch.protein_pos, batch.protein_atom_feature.float())
-    with pytest.raises(ValueError, match='sorted'):
-        model(*args, batch.protein_element_batch.flip(0), lpos, lv, batch.ligand_element_batch)
+    batch = _small_batch()
+    g = torch.Generator().manual_seed(9)
+    Np, Nl = batch.protein_pos.shape[0], 22
+    lpos = batch.protein_pos.mean(0) + torch.randn(Nl, 3, generator=g)
+    lv = torch.randint(0, 13, (Nl,), generator=g)
+    bl = batch.ligand_element_batch
+    pp, pl = torch.randperm(Np, generator=g), torch.randperm(Nl, generator=g)
+    u = [batch.protein_pos[pp], batch.protein_atom_feature.float()[pp], batch.protein_element_batch[pp], lpos[pl], lv[pl], bl[pl]]
+    assert bool((u[2][1:] < u[2][:-1]).any()) and bool((u[5][1:] < u[5][:-1]).any())
+    got = model(*[t.to(dev) for t in u])
+    sp, sl = torch.sort(u[2], stable=True).indices, torch.sort(u[5], stable=True).indices
+    pre = model(u[0][sp].to(dev), u[1][sp].to(dev), u[2][sp].to(dev), u[3][sl].to(dev), u[4][sl].to(dev), u[5][sl].to(dev))
+    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h', 'final_h'):
+        assert torch.equal(got[k], pre[k]), k
+    want = R.model_forward(state_dict, None, *u)
+    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= 2e-5
+    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= 2e-4
     with pytest.raises(ValueError, match='ligand_v'):
-        model(*args, batch.protein_element_batch, lpos, lv + 13, batch.ligand_element_batch)
+        model(*[t.to(dev) for t in u[:4]], (u[4] + 13).to(dev), u[5].to(dev))
 
 
+def test_sampling_with_unsorted_batch_vectors_follows_the_reference_loop(model, state_dict):
+    """The reference's loop with an unsorted ligand vector keeps its state in input order while each forward answers in
+    compose_context's order (models/molopt_score_model.py:644-685): reproduced as it is -- 3 steps against the oracle's loop
+    (restatement forward + posterior on the same draws), protein unsorted as well."""
+    from oracle import draws
+    from oracle import restatement as R
+    dev = _dev()
+    batch = _small_batch()
+    g = torch.Generator().manual_seed(10)
+    Np, Nl = batch.protein_pos.shape[0], 22
+    lpos = batch.protein_pos.mean(0) + torch.randn(Nl, 3, generator=g)
+    lv = torch.randint(0, 13, (Nl,), generator=g)
+    pp, pl = torch.randperm(Np, generator=g), torch.randperm(Nl, generator=g)
+    ppos, pv, bp = batch.protein_pos[pp], batch.protein_atom_feature.float()[pp], batch.protein_element_batch[pp]
+    lpos, lv, bl = lpos[pl], lv[pl], batch.ligand_element_batch[pl]
+    steps = 3
+    r = model.sample_diffusion(ppos.to(dev), pv.to(dev), bp.to(dev), lpos.to(dev), lv.to(dev), bl.to(dev), num_steps=steps,
+                               center_pos_mode='protein', noise_source=draws.Source(8100, dev))
+    # the oracle's version of the same loop (CPU)
+    cfg = None
+    sched = R.diffusion_schedules(dict(__import__('oracle.weights', fromlist=['x']).DEFAULT_MODEL_CONFIG))
+    src = draws.Source(8100, torch.device('cpu'))
+    cp, cl, off = R.center_positions(ppos, lpos, bp, bl)
+    x, v = cl.clone(), lv.clone()
+    T = 1000
+    for s, t in enumerate(reversed(range(T - steps, T))):
+        preds = R.model_forward(state_dict, cfg, cp, pv, bp, x, v, bl)            # answers in compose_context's order
+        tt = torch.full((int(bp.max()) + 1,), t, dtype=torch.long)
+        x, v, l0, lp = R.posterior_step(sched, tt, x, v, preds['pred_ligand_pos'], preds['pred_ligand_v'], bl,
+                                        src(s, 'noise', x), src(s, 'uniform', preds['pred_ligand_v']), 13)
+        assert _maxdiff(r['pos_traj'][s], x + off[bl]) <= 5e-5, s
+        assert torch.equal(r['v_traj'][s], v), s
 def test_model_copy_after_first_use(model):
     """copy.deepcopy / pickle after a forward has created the native handle; the copy packs its own weights."""
     import copy

@@ -156,3 +156,41 @@ def test_call_signatures_are_drop_in():
     from oracle import weights
     m = M.ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
     assert m.num_classes == 13 and m.num_timesteps == 1000 and m.center_pos_mode == 'protein'
+
+
+def test_unsorted_batch_vectors_forward_and_sampling_loop(ref_model):
+    """Unsorted batch vectors are legal input of the reference (compose_context stable-sorts, models/common.py:126): the forward
+    answers in compose_context's order (the ligand rows are NOT put back in input order), and the sampling loop combines those
+    answers element by element with its state in input order.  The restatement follows both, which is what the GPU tests then
+    hold the HIP path to (tests/test_gpu_long_parity.py::test_unsorted_batch_vectors_*)."""
+    ref, model, sd = ref_model
+    b, lpos, lv = _batch(4)
+    g = torch.Generator().manual_seed(12)
+    pp, pl = torch.randperm(b.protein_pos.shape[0], generator=g), torch.randperm(lpos.shape[0], generator=g)
+    ppos, pv, bp = b.protein_pos[pp], b.protein_atom_feature.float()[pp], b.protein_element_batch[pp]
+    xl, vl, bl = lpos[pl], lv[pl], b.ligand_element_batch[pl]
+    cp, cl, off = ref.center_pos(ppos, xl, bp, bl, mode='protein')
+    with torch.no_grad():
+        want = model(cp, pv, bp, cl, vl, bl)
+        sp, sl = torch.sort(bp, stable=True).indices, torch.sort(bl, stable=True).indices
+        pre = model(cp[sp], pv[sp], bp[sp], cl[sl], vl[sl], bl[sl])
+    assert torch.equal(want['pred_ligand_pos'], pre['pred_ligand_pos']) and torch.equal(want['final_h'], pre['final_h'])
+    got = R.model_forward(sd, None, cp, pv, bp, cl, vl, bl)
+    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) < 2e-5
+    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) < 2e-5
+    # three steps of the reference's own loop on the unsorted vectors vs the restatement's loop on the same draws
+    from oracle import draws
+    from oracle.make_golden_r2 import counter_draws
+    steps = 3
+    with counter_draws(9100), torch.no_grad():
+        r = model.sample_diffusion(ppos, pv, bp, xl, vl, bl, num_steps=steps, center_pos_mode='protein')
+    sched = R.diffusion_schedules(dict(weights.DEFAULT_MODEL_CONFIG))
+    rcp, rcl, roff = R.center_positions(ppos, xl, bp, bl)
+    x, v = rcl.clone(), vl.clone()
+    for s, t in enumerate(reversed(range(1000 - steps, 1000))):
+        preds = R.model_forward(sd, None, rcp, pv, bp, x, v, bl)                 # answers in compose_context's order ...
+        tt = torch.full((int(bp.max()) + 1,), t, dtype=torch.long)
+        x, v, _, _ = R.posterior_step(sched, tt, x, v, preds['pred_ligand_pos'], preds['pred_ligand_v'], bl,    # ... met by the state in input order
+                                      draws.normal(9100, s, tuple(x.shape)), draws.uniform(9101, s, (x.shape[0], 13)), 13)
+        assert _maxdiff(r['pos_traj'][s], x + roff[bl]) < 5e-5, s
+        assert torch.equal(r['v_traj'][s], v), s
