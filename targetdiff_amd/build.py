@@ -23,7 +23,9 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', f'--offload-arch={
 # per-file additions.  edge16.hip: no SLP vectorisation -- it turns the 64 P_i adds of a row (and other adjacent fp32 adds) into
 # v_pk_add_f32, which costs more than two plain adds next to the co-resident waves' matrix instructions (x2h key pass -2 %, h2x -1.5 %
 # per C2 step, A/B in one gpurun call; MI355X_MICROARCH.md lists packed fp32 as an anti-lever beside MFMAs)
-FILE_FLAGS = {'edge16.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'edge16.hip': ['-fno-slp-vectorize'],
+              # node.hip: the LDS-DMA asm statement names m0 as clobbered; clang reports m0 as a reserved register for every instantiation
+              'node.hip': ['-Wno-inline-asm']}
 
 
 def hipcc() -> str:

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
 // 24 rounds then starts by waiting out a full L2 round trip (98 us per full-size launch against 33 us of MFMA time, round 2).
 // (Staging through registers instead costs 24 VGPRs the kernel does not have: the chunk lands in scratch.)
 __device__ __forceinline__ void td_glds16_asm(const uint4 *gsrc_lane, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory", "m0");      // m0 is an ordinary allocatable SGPR to LLVM (v_movrel, readlane selects, LDS-DMA builtins): declared clobbered
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory", "m0");      // m0 named as clobbered: the compiler sets it itself for v_movrel / readlane selects / its own LDS-DMA (clang calls it "reserved" and warns: -Wno-inline-asm)
 }
 template <bool ASYNC, bool BPIPE>
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, const float *__restrict__ h) {
