@@ -108,6 +108,50 @@ def make_workload(name: str, rank: int):
     raise ValueError(name)
 
 
+def geometry_sweep(model, pocket, sizes, dev, steps=10):
+    """The session's step time depends on how far the ligand reaches into the pocket (rows no ligand atom can influence are not
+    recomputed): time `steps` session steps from Gaussian clouds of 1 / 2 / 3 / 4 A per coordinate around the pocket centroid (1 A =
+    the sampler's own initial state, 2 A = the headline's state) and from the DOCKED pose of the reference's example ligand
+    (examples/1h36_A_rec_1h36_r88_lig_tt_docked_0.sdf, 25 atoms, replicated per sample with 0.25 A of noise: the geometry a trained
+    model's trajectory ends in).  The stateless floor is geometry-independent (reported beside it)."""
+    out = {}
+    n = len(sizes)
+
+    def run(batch, lpos, lv, max_nodes):
+        b = batch.to(dev)
+        s = model.begin_sampling(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev),
+                                 b.ligand_element_batch, num_steps=steps + 3, center_pos_mode='protein', max_graph_nodes=max_nodes,
+                                 use_session=True)
+        for _ in range(3):
+            s.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        n_all, n_dirty, levels = s.session.row_counts()
+        return {'ms_per_step': ms, 'value': n / ms, 'layer0_rows': n_dirty, 'receptive_field_levels': levels}
+    packed = workloads.pack_samples([pocket], n, sizes)
+    for spread in (1.0, 2.0, 3.0, 4.0):
+        gen = torch.Generator(device='cpu').manual_seed(2021)
+        lpos, lv = workloads.init_ligand(packed, generator=gen, spread=spread)
+        out[f'cloud_{spread:.0f}A'] = run(packed, lpos, lv, pocket.num_atoms + max(sizes))
+    dpath = os.path.join(ROOT, 'tests', 'golden', 'ligand_1h36_docked.npz')
+    if os.path.exists(dpath):
+        with np.load(dpath) as z:
+            dock = torch.from_numpy(z['pos'].astype(np.float32))
+        na = dock.shape[0]
+        packed_d = workloads.pack_samples([pocket], n, [na] * n)
+        gen = torch.Generator(device='cpu').manual_seed(2021)
+        lpos = dock.repeat(n, 1) + 0.25 * torch.randn(n * na, 3, generator=gen)
+        _, lv = workloads.init_ligand(packed_d, generator=gen)
+        out['docked_pose'] = run(packed_d, lpos, lv, pocket.num_atoms + na)
+        out['docked_pose']['ligand_atoms'] = na
+    out['steps'] = steps
+    return out
+
+
 def seeded_state_dict(model, seed=2021):
     """Random-init weights of the reference architecture (no checkpoint ships with the reference)."""
     g = torch.Generator().manual_seed(seed)
@@ -372,6 +416,8 @@ def main():
                          'initial state N(0, I) (see --initial-state)')
     ap.add_argument('--initial-state', action='store_true',
                     help='after the timed region, also time 10 steps from the sampler\'s initial state N(0, I)')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the geometry sweep (c2, N = 1): the session\'s step time at ligand clouds of 1 / 2 / '
+                    '3 / 4 A and at the docked pose of the reference\'s example ligand')
     ap.add_argument('--no-graph', action='store_true', help='issue the launches of a step one by one instead of replaying the captured hipGraph')
     ap.add_argument('--no-session', action='store_true', help='stateless td_model_forward per step (no static-protein caching)')
     ap.add_argument('--no-stateless', action='store_true', help='skip the 10 stateless steps reported as stateless_ms_per_step')
@@ -509,8 +555,14 @@ def main():
         if os.path.exists(tpath) and sampler.session is not None and default_graph:
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
-            source = f'profiles/{traffic_file} (static: PMC pass of an earlier run of this command, not measured in this run)'
+            same = tj.get('build_tag') == capi.build_tag()
+            if same:
+                traffic = (2.0 * tj['fetch_kb'] + tj['write_kb']) * 1024.0
+                source = (f'profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this very library '
+                          f'build ({tj["build_tag"]}; PMC counters cannot be read in-process), tools/refresh_headline.sh')
+            else:
+                source = (f'profiles/{traffic_file} describes library build {tj.get("build_tag")}, this run is build {capi.build_tag()}: '
+                          'stale, not reported (tools/refresh_headline.sh re-collects the PMC passes)')
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
@@ -562,7 +614,7 @@ def main():
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
                    'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
-                   'step_launch': step_launch,
+                   'step_launch': step_launch, 'build_tag': capi.build_tag(),
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
     }
@@ -598,6 +650,8 @@ def main():
                     print(f'  {k:10s} {v["ms"] / prof_steps:9.3f} ms/step  ({v["launches"] // prof_steps} launches/step)',
                           file=sys.stderr)
         # a complete run the driver's own clock can witness: outside the timed region, the 20-step line above is unchanged
+        if world == 1 and args.workload == 'c2' and not args.no_sweep and not args.no_session and default_graph:
+            out['geometry_sweep'] = geometry_sweep(model, pockets[0], sizes, dev)
         if world == 1 and args.workload == 'c2' and not args.no_full_run and not args.no_session and default_graph:
             out['full_run'] = full_run(model, pockets[0], sizes, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -76,6 +76,9 @@ typedef struct td_config {
 /* ---- library ------------------------------------------------------------------------------------ */
 int td_abi_version(void);
 const char *td_last_error(void);
+/* 12 hex digits naming the SOURCES this binary was built from (SHA-256 over csrc/, this header and the compiler flags, set by
+ * targetdiff_amd/build.py): bench lines and committed PMC profiles carry it, so a profile can be matched to the build it describes. */
+const char *td_build_tag(void);
 
 /* ---- model (replaces: ScorePosNet3D.__init__ + load_state_dict, models/molopt_score_model.py:194-311,
  *      scripts/sample_diffusion.py:158-163).  `host_weights` is the flat fp32 blob of the reference

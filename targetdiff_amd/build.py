@@ -35,6 +35,22 @@ def hipcc() -> str:
     return exe
 
 
+def source_tag() -> str:
+    """First 12 hex digits of the SHA-256 over every source file of the library and the compiler flags: compiled into the library
+    (td_build_tag) so that a measurement -- a bench line, a PMC profile -- names the sources of the binary it ran, and a rebuild of
+    the same sources (hipcc's output is not bit-reproducible) keeps the name."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.cpp', '.h', '.map'))]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'targetdiff_hip.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    h.update(repr((FLAGS, sorted(FILE_FLAGS.items()))).encode())
+    return h.hexdigest()[:12]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -48,12 +64,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'targetdiff_hip.h'))
     objs, procs = [], []
+    tag = source_tag()
+    tag_file = os.path.join(OBJDIR, 'source_tag.txt')
+    tag_changed = not os.path.exists(tag_file) or open(tag_file).read().strip() != tag
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
-        if force or _stale(obj, [sp, os.path.abspath(__file__)] + headers):
-            cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ['-c', sp, '-o', obj]
+        if force or _stale(obj, [sp, os.path.abspath(__file__)] + headers) or (src == 'api.cpp' and tag_changed):
+            cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ([f'-DTD_BUILD_TAG="{tag}"'] if src == 'api.cpp' else []) + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -69,6 +88,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print(out, file=sys.stderr)
     if failed:
         raise RuntimeError('hipcc compilation failed')
+    with open(tag_file, 'w') as f:
+        f.write(tag + '\n')
     if force or procs or _stale(LIB, objs + [os.path.join(CSRC, 'exports.map')]):
         cmd = [hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', f'-Wl,--version-script,{os.path.join(CSRC, "exports.map")}',
                '-o', LIB] + objs

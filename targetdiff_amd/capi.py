@@ -71,6 +71,7 @@ SIGNATURES = {
     'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
     'td_session_step': (c_int32, [_P, _P, c_int32, _P]),
     'td_session_step_graph': (c_int32, [_P]),
+    'td_build_tag': (ctypes.c_char_p, []),
     'td_debug_fail_alloc': (c_int32, [c_int32]),
     'td_debug_node_stage': (c_int32, [_P, c_int32, c_int32, _P, c_int64, _P, _P, _P]),
     'td_debug_reductions': (c_int32, [_P, _P, _P]),
@@ -105,6 +106,11 @@ def profile_end() -> dict:
 
 
 _lib = None
+
+
+def build_tag() -> str:
+    """td_build_tag(): names the sources the loaded library was built from; ties a measurement (bench line, PMC profile) to them."""
+    return load_library().td_build_tag().decode()
 
 
 def load_library(path: str = LIB_PATH):

@@ -22,6 +22,10 @@ void td_set_error(const char *fmt, ...) {
 
 extern "C" const char *td_last_error(void) { return g_err; }
 extern "C" int td_abi_version(void) { return TD_ABI_VERSION; }
+#ifndef TD_BUILD_TAG
+#define TD_BUILD_TAG "untagged"
+#endif
+extern "C" const char *td_build_tag(void) { return TD_BUILD_TAG; }
 
 // ------------------------------------------------------------------------------------------ kernel timers
 // Optional per-kernel-class HIP-event timers (bench.py's roofline leg): events are recorded on the launch

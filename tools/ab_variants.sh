@@ -8,7 +8,7 @@ WL=${WL:-"c2 c1"}; ROUNDS=${ROUNDS:-2}
 VARS=$(ls targetdiff_amd/lib/variant_*.so | sed 's/.*variant_\(.*\)\.so/\1/')
 for W in $WL; do for R in $(seq $ROUNDS); do for V in $VARS; do
   cp targetdiff_amd/lib/variant_$V.so targetdiff_amd/lib/libtargetdiff_hip.so
-  timeout 300 python bench.py --workload $W --no-cpu-baseline --no-full-run --no-stateless --profile-all $EXTRA > gpurun_out/ab/${W}_${V}_$R.json 2> gpurun_out/ab/${W}_${V}_${R}_breakdown.txt
+  timeout 300 python bench.py --workload $W --no-cpu-baseline --no-full-run --no-stateless --no-sweep --profile-all $EXTRA > gpurun_out/ab/${W}_${V}_$R.json 2> gpurun_out/ab/${W}_${V}_${R}_breakdown.txt
   python -c "
 import json; d=json.load(open('gpurun_out/ab/${W}_${V}_$R.json')); r=d['roofline']; print('$W $V $R', round(d['ms_per_step'],3), 'value', round(r['frac'],3), 'key', round(r['key_pass']['frac'],3))"
   grep "x2h_k\|x2h_v\|node_proj\|h2x_k\|gate\|knn" gpurun_out/ab/${W}_${V}_${R}_breakdown.txt | awk '{printf "%s %s  ", $1, $2}'; echo

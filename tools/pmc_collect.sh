@@ -9,11 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -o p -- \
-      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-full-run ${BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
+      python "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-full-run --no-stateless --no-sweep ${BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
-run sq3 SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_LDS_UNALIGNED_STALL
+[ -n "${PMC_SHORT:-}" ] || run sq3 SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_LDS_UNALIGNED_STALL
 run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 find "$ROOT/$OUT" -name "*.csv" | head -20

@@ -9,6 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def parse(path):
@@ -28,6 +29,8 @@ def main():
     workload = sys.argv[2] if len(sys.argv) > 2 else 'c2'
     suffix = '' if workload == 'c2' else '_' + workload
     kernels = parse(src)
+    from targetdiff_amd import capi
+    tag = capi.build_tag()          # the PMC passes and this script run in one gpurun call, on the same library file
     # x2h stage instantiations: value pass; key pass tagged STAGE = 0, not RAW
     picks = {f'traffic_x2h_value{suffix}.json': [k for k in kernels if k.startswith('edge_value16_kernel')],
              f'traffic_x2h_key{suffix}.json': [k for k in kernels if re.match(r'edge_key16_kernel<false, \d+, 0', k)]}
@@ -40,7 +43,7 @@ def main():
         out = {'kernel': name, 'workload': f'{workload} (default bench state: ligand cloud std 2.0 A)',
                'source': f'{os.path.relpath(src, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
                          f'tools/pmc_collect.sh; mean over the {c["FETCH_SIZE"][1]} launches of the profiled run)',
-               'fetch_kb': c['FETCH_SIZE'][0], 'write_kb': c['WRITE_SIZE'][0],
+               'fetch_kb': c['FETCH_SIZE'][0], 'write_kb': c['WRITE_SIZE'][0], 'build_tag': tag,
                'note': 'bytes = (2 * fetch_kb + write_kb) * 1024: FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B, '
                        'MI355X_MICROARCH.md section HBM)'}
         with open(os.path.join(ROOT, 'profiles', fname), 'w') as f:
