@@ -70,7 +70,10 @@ typedef struct td_config {
     int32_t cutoff_mode;         /* TD_CUTOFF_* (0 = knn) */
     float radius;                /* TD_CUTOFF_RADIUS: cut-off in Angstrom */
     int32_t max_num_neighbors;   /* TD_CUTOFF_RADIUS: fan-out cap (1 .. 64) */
-    int32_t reserved[4];
+    int32_t model_mean_type;     /* 0 = 'C0' (the network predicts x0; configs/training.yml), 1 = 'noise' (it predicts x_t + eps:
+                                    x0 = sqrt_recip_alphas_cumprod[t] x_t - sqrt_recipm1_alphas_cumprod[t] (pred - x_t),
+                                    models/molopt_score_model.py:412-416, 663-666; sampling only, as in the reference) */
+    int32_t reserved[3];
 } td_config;
 
 /* ---- library ------------------------------------------------------------------------------------ */
@@ -87,7 +90,9 @@ const char *td_build_tag(void);
  *      (node-side projection split of the 340-wide first Linear, MFMA fragment order) and uploads them.
  *      `host_schedules` = 7 arrays of num_timesteps fp32 each, in this order: posterior_mean_c0_coef,
  *      posterior_mean_ct_coef, posterior_logvar, log_alphas_v, log_one_minus_alphas_v,
- *      log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (models/molopt_score_model.py:248-267). */
+ *      log_alphas_cumprod_v, log_one_minus_alphas_cumprod_v (models/molopt_score_model.py:248-267); optionally an 8th,
+ *      alphas_cumprod (td_perturb / td_likelihood_prior), and a 9th and 10th, sqrt_recip_alphas_cumprod and
+ *      sqrt_recipm1_alphas_cumprod (:228-229; required by model_mean_type = 1). */
 int td_model_create(const td_config *cfg, const float *host_weights, size_t num_weights,
                     const float *host_schedules, size_t num_schedule_floats, td_model **out);
 void td_model_destroy(td_model *m);
@@ -145,16 +150,20 @@ int td_refine_forward(const td_model *m, const float *d_h, const float *d_x, con
                       float *d_out_h, float *d_out_x, int32_t *d_out_nbr, float *d_out_ew,
                       void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* ---- one denoiser evaluation (replaces: ScorePosNet3D.forward, models/molopt_score_model.py:313-368,
- *      time_emb_dim == 0).  Protein / ligand atoms are given un-composed, each sorted by graph:
+/* ---- one denoiser evaluation (replaces: ScorePosNet3D.forward, models/molopt_score_model.py:313-368).
+ *      Protein / ligand atoms are given un-composed, each sorted by graph:
  *      d_protein_ptr / d_ligand_ptr are [B+1] int32 prefix offsets.  Outputs: pred_ligand_pos [N_l,3],
- *      pred_ligand_v [N_l,C], final_ligand_h [N_l,128]; d_final_h [N,128] may be NULL. */
+ *      pred_ligand_v [N_l,C], final_ligand_h [N_l,128]; d_final_h [N,128] may be NULL.
+ *      d_ligand_graph_bias (NULL when time_emb_dim == 0, the live configuration): [B][128] fp32, row g is added to the embedding
+ *      of every ligand atom of graph g before the bias -- the time-embedding columns of ligand_atom_emb applied to the graph's
+ *      time feature (:319-329: `simple` = (t / T) * W[:, C], `sin` = W[:, C:] time_emb(t)); column 127 (the node indicator) is 0.
+ *      The caller evaluates that small per-graph term (the mirror does it with torch). */
 int td_model_forward(const td_model *m, const float *d_protein_pos, const float *d_protein_v,
                      const int32_t *d_protein_ptr, int64_t N_p, const float *d_ligand_pos,
                      const int64_t *d_ligand_v, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
                      int32_t fix_x, int32_t max_graph_nodes, float *d_pred_ligand_pos, float *d_pred_ligand_v,
                      float *d_final_ligand_h, float *d_final_h, void *d_workspace, size_t workspace_bytes,
-                     void *stream);
+                     const float *d_ligand_graph_bias, void *stream);
 
 /* ---- posterior update of one reverse-diffusion step (replaces the loop body
  *      models/molopt_score_model.py:673-685: q_pos_posterior :424, extract :706, q_v_posterior :401,
@@ -232,7 +241,7 @@ int td_session_create(const td_model *m, const float *d_protein_pos, const float
                       int32_t max_graph_nodes, void *stream, td_session **out);
 void td_session_destroy(td_session *s);
 int td_session_forward(td_session *s, const float *d_ligand_pos, const int64_t *d_ligand_v, float *d_pred_ligand_pos,
-                       float *d_pred_ligand_v, float *d_final_ligand_h, void *stream);
+                       float *d_pred_ligand_v, float *d_final_ligand_h, const float *d_ligand_graph_bias, void *stream);
 /* ---- one reverse-diffusion step as a single replayable unit (replaces the loop body of ScorePosNet3D.sample_diffusion,
  *      models/molopt_score_model.py:650-693: forward, posterior mean / variance + noise :673-679, categorical posterior +
  *      Gumbel-max draw :682-685, trajectory appends :687-693).  = td_session_forward on the current ligand state followed by
@@ -263,6 +272,7 @@ typedef struct td_step_io {
     int64_t *d_v_traj;
     float *d_v0_traj;
     float *d_vt_traj;
+    const float *d_ligand_graph_bias;   /* [B][128] or NULL: this step's time-embedding term (see td_model_forward) */
 } td_step_io;
 int td_session_step(td_session *s, const td_step_io *io, int32_t use_graph, void *stream);
 int td_session_step_graph(const td_session *s);

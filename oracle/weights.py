@@ -151,3 +151,15 @@ def make_egnn_state_dict(seed: int = 2021, num_layers=9, hidden=128, edge_feat_d
             t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) / (fan_in ** 0.5)
         sd[key] = t
     return sd
+
+
+# ------------------------------------------------------------------------------------------ time embedding (round 4)
+def time_emb_state_dict(seed: int, ligand_dim=LIGAND_FEATURE_DIM):
+    """make_state_dict(seed) with ``ligand_atom_emb.weight`` widened to [127, ligand_dim + 1] (time_emb_mode = 'simple',
+    models/molopt_score_model.py:290-291; the first ligand_dim columns stay make_state_dict's).  'sin' does not run in the reference."""
+    sd = make_state_dict(seed)
+    w = sd['ligand_atom_emb.weight']
+    g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(b'time/ligand_atom_emb.weight')) % (2 ** 63))
+    col = (torch.rand((w.shape[0], 1), generator=g, dtype=torch.float32) * 2 - 1) / ((ligand_dim + 1) ** 0.5)
+    sd['ligand_atom_emb.weight'] = torch.cat([w, col], dim=1)
+    return sd

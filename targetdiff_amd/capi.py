@@ -26,7 +26,7 @@ class TdConfig(ctypes.Structure):
     _fields_ = [('hidden_dim', c_int32), ('n_heads', c_int32), ('knn', c_int32), ('num_layers', c_int32),
                 ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
                 ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('cutoff_mode', c_int32), ('radius', c_float),
-                ('max_num_neighbors', c_int32), ('reserved', c_int32 * 4)]
+                ('max_num_neighbors', c_int32), ('model_mean_type', c_int32), ('reserved', c_int32 * 3)]
 
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
@@ -52,7 +52,7 @@ SIGNATURES = {
     'td_refine_forward': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P,
                                     c_size_t, _P]),
     'td_model_forward': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P,
-                                   _P, _P, _P, c_size_t, _P]),
+                                   _P, _P, _P, c_size_t, _P, _P]),
     'td_posterior_step': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'td_center_pos': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int32, c_int32, _P]),
     'td_perturb': (c_int32, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     'td_egnn_forward': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     'td_session_create': (c_int32, [_P, _P, _P, _P, c_int64, _P, c_int64, c_int64, c_int32, _P, POINTER(c_void_p)]),
     'td_session_destroy': (None, [_P]),
-    'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P]),
+    'td_session_forward': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'td_session_row_counts': (c_int32, [_P, POINTER(c_int32), c_int32, _P]),
     'td_session_step': (c_int32, [_P, _P, c_int32, _P]),
     'td_session_step_graph': (c_int32, [_P]),
@@ -84,7 +84,8 @@ class StepIO(ctypes.Structure):
     """td_step_io of include/targetdiff_hip.h: the per-step arguments of td_session_step, all in device memory"""
     _fields_ = [('d_step', c_void_p), ('d_t_all', c_void_p), ('num_steps', c_int32), ('pos_only', c_int32),
                 ('d_ligand_pos', c_void_p), ('d_ligand_v', c_void_p), ('d_noise', c_void_p), ('d_uniform', c_void_p),
-                ('d_pos_traj', c_void_p), ('d_v_traj', c_void_p), ('d_v0_traj', c_void_p), ('d_vt_traj', c_void_p)]
+                ('d_pos_traj', c_void_p), ('d_v_traj', c_void_p), ('d_v0_traj', c_void_p), ('d_vt_traj', c_void_p),
+                ('d_ligand_graph_bias', c_void_p)]
 
 
 PROFILE_CLASSES = ('knn', 'gate', 'node_proj', 'x2h_k', 'x2h_v', 'h2x_k', 'h2x_v', 'compose', 'head', 'posterior')
@@ -151,6 +152,15 @@ def _ptr(t: torch.Tensor | None, dtype=None, what='tensor'):
     return c_void_p(t.data_ptr())
 
 
+def _graph_bias_ptr(t, B):
+    """[B][128] fp32 per-graph term of the ligand embedding (time embedding), or None"""
+    if t is None:
+        return None
+    if t.dim() != 2 or t.shape[1] != HIDDEN or (B is not None and t.shape[0] != B):
+        raise ValueError(f'ligand_graph_bias must be [B, {HIDDEN}] (got {tuple(t.shape)})')
+    return _ptr(t, torch.float32, 'ligand_graph_bias')
+
+
 def _stream(device=None):
     """HIP stream of torch's current stream ON `device` (the tensors' device, not the process-wide current device)."""
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -197,7 +207,8 @@ def flatten_state_dict(sd, num_layers: int) -> np.ndarray:
 SCHEDULE_ORDER = ('posterior_mean_c0_coef', 'posterior_mean_ct_coef', 'posterior_logvar', 'log_alphas_v',
                   'log_one_minus_alphas_v', 'log_alphas_cumprod_v', 'log_one_minus_alphas_cumprod_v')
 # optional 8th array: needed by td_perturb / td_likelihood_prior (likelihood estimation), not by sampling
-SCHEDULE_OPTIONAL = ('alphas_cumprod',)
+SCHEDULE_OPTIONAL = ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod')
+MEAN_TYPES = {'C0': 0, 'noise': 1}                        # td_config.model_mean_type
 
 
 def _device_bound(fn):
@@ -230,7 +241,8 @@ class NativeModel:
                             edge_feat_dim=cfg['edge_feat_dim'], protein_feat_dim=cfg['protein_feat_dim'],
                             ligand_num_classes=cfg['ligand_num_classes'], num_timesteps=cfg['num_timesteps'],
                             cutoff_mode=CUTOFF_MODES[mode], radius=float(cfg.get('radius', 0.0)),
-                            max_num_neighbors=int(cfg.get('max_num_neighbors', 32)))
+                            max_num_neighbors=int(cfg.get('max_num_neighbors', 32)),
+                            model_mean_type=MEAN_TYPES[cfg.get('model_mean_type', 'C0')])
         self.cutoff_mode, self.k = mode, int(cfg['knn'])
         self.default_graph = mode == 'knn' and self.k <= KNN       # the 32-slot fast path (and the caching session); k < 32
                                                                    # is the 32-NN row with the slots >= k masked
@@ -241,9 +253,10 @@ class NativeModel:
             raise ValueError(f'weight blob has {blob.size} floats, library expects {expect}')
         sched_ptr, sched_n = None, 0
         if schedules is not None:
+            # 7 arrays, + alphas_cumprod (8), + the two 'noise' arrays (10): the library takes these three lengths
+            opt = SCHEDULE_OPTIONAL if all(o in schedules for o in SCHEDULE_OPTIONAL) else tuple(o for o in SCHEDULE_OPTIONAL[:1] if o in schedules)
             sch = np.ascontiguousarray(np.concatenate(
-                [np.asarray(schedules[k], dtype=np.float32).reshape(-1)
-                 for k in SCHEDULE_ORDER + tuple(o for o in SCHEDULE_OPTIONAL if o in schedules)]))
+                [np.asarray(schedules[k], dtype=np.float32).reshape(-1) for k in SCHEDULE_ORDER + opt]))
             sched_ptr, sched_n = sch.ctypes.data_as(POINTER(c_float)), sch.size
         handle = c_void_p()
         with torch.cuda.device(self.device):
@@ -321,7 +334,7 @@ class NativeModel:
 
     @_device_bound
     def model_forward(self, protein_pos, protein_v, protein_ptr, ligand_pos, ligand_v, ligand_ptr, fix_x=False,
-                      max_graph_nodes=0, want_final_h=True, out=None):
+                      max_graph_nodes=0, want_final_h=True, out=None, ligand_graph_bias=None):
         Np, Nl, B = protein_pos.shape[0], ligand_pos.shape[0], protein_ptr.numel() - 1
         N, C = Np + Nl, self.num_classes
         dev = protein_pos.device
@@ -343,7 +356,7 @@ class NativeModel:
             _ptr(protein_ptr, torch.int32, 'protein_ptr'), Np, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
             _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(ligand_ptr, torch.int32, 'ligand_ptr'), Nl, B,
             int(bool(fix_x)), max_graph_nodes, _ptr(pred_pos), _ptr(pred_v), _ptr(lig_h), _ptr(final_h), _ptr(ws),
-            ws.numel(), _stream(self.device)), 'td_model_forward')
+            ws.numel(), _graph_bias_ptr(ligand_graph_bias, B), _stream(self.device)), 'td_model_forward')
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': final_h, 'final_ligand_h': lig_h}
 
     @_device_bound
@@ -462,7 +475,7 @@ class NativeSession:
                 self.lib.td_session_destroy(h)
 
     @_device_bound
-    def forward(self, ligand_pos, ligand_v, out=None):
+    def forward(self, ligand_pos, ligand_v, out=None, ligand_graph_bias=None):
         out = out or {}
         dev = ligand_pos.device
         pred_pos = out.get('pred_ligand_pos')
@@ -476,11 +489,12 @@ class NativeSession:
             lig_h = torch.empty(self.Nl, HIDDEN, dtype=torch.float32, device=dev)
         _check(self.lib.td_session_forward(self.handle, _ptr(ligand_pos, torch.float32, 'ligand_pos'),
                                            _ptr(ligand_v, torch.int64, 'ligand_v'), _ptr(pred_pos), _ptr(pred_v),
-                                           _ptr(lig_h), _stream(self.device)), 'td_session_forward')
+                                           _ptr(lig_h), _graph_bias_ptr(ligand_graph_bias, None), _stream(self.device)),
+               'td_session_forward')
         return {'pred_ligand_pos': pred_pos, 'pred_ligand_v': pred_v, 'final_h': None, 'final_ligand_h': lig_h}
 
     def make_step_io(self, step_index, t_all, ligand_pos, ligand_v, noise, uniform, pos_traj, v_traj, v0_traj=None,
-                     vt_traj=None, pos_only=False) -> StepIO:
+                     vt_traj=None, pos_only=False, ligand_graph_bias=None) -> StepIO:
         """The argument block of :meth:`step`; the tensors must stay alive (and in place) for as long as it is used."""
         S = int(t_all.shape[0])
         if step_index.numel() != 2 or pos_traj.shape[0] != S or v_traj.shape[0] != S:
@@ -497,6 +511,8 @@ class NativeSession:
         io.d_v_traj = _ptr(v_traj, torch.int64, 'v_traj').value
         io.d_v0_traj = _ptr(v0_traj, torch.float32, 'v0_traj').value if v0_traj is not None and v0_traj.numel() else None
         io.d_vt_traj = _ptr(vt_traj, torch.float32, 'vt_traj').value if vt_traj is not None and vt_traj.numel() else None
+        gb = _graph_bias_ptr(ligand_graph_bias, int(t_all.shape[1]))
+        io.d_ligand_graph_bias = gb.value if gb is not None else None
         return io
 
     def step(self, io: StepIO, use_graph=True):

@@ -391,12 +391,21 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         return TD_EINVAL;
     }
     if (host_schedules && num_schedule_floats != (size_t)7 * c.num_timesteps &&
-        num_schedule_floats != (size_t)8 * c.num_timesteps) {
+        num_schedule_floats != (size_t)8 * c.num_timesteps && num_schedule_floats != (size_t)10 * c.num_timesteps) {
         td_set_error("td_model_create: schedule blob has %zu floats, expected %zu (sampling) or %zu (+ alphas_cumprod)",
                      num_schedule_floats, (size_t)7 * c.num_timesteps, (size_t)8 * c.num_timesteps);
         return TD_EINVAL;
     }
-    const bool has_abar = host_schedules && num_schedule_floats == (size_t)8 * c.num_timesteps;
+    const bool has_rc = host_schedules && num_schedule_floats == (size_t)10 * c.num_timesteps;
+    const bool has_abar = has_rc || (host_schedules && num_schedule_floats == (size_t)8 * c.num_timesteps);
+    if (c.model_mean_type != 0 && c.model_mean_type != 1) {
+        td_set_error("td_model_create: model_mean_type must be 0 ('C0') or 1 ('noise'), got %d", c.model_mean_type);
+        return TD_EINVAL;
+    }
+    if (c.model_mean_type == 1 && !has_rc) {
+        td_set_error("td_model_create: model_mean_type 'noise' needs the 10 schedule arrays (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod)");
+        return TD_EINVAL;
+    }
     const int H = TD_H, E = H - 1, F = c.protein_feat_dim, C = c.ligand_num_classes, KV = kv_in(c), L = c.num_layers;
     Cursor cur{host_weights, num_weights};
     const float *Wp = cur.take((size_t)E * F), *bp = cur.take(E);
@@ -474,8 +483,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     // ---- schedules
     const int T = c.num_timesteps;
-    size_t oS = pk.alloc((size_t)8 * T);
-    if (host_schedules) memcpy(pk.data.data() + oS, host_schedules, (size_t)(has_abar ? 8 : 7) * T * sizeof(float));
+    size_t oS = pk.alloc((size_t)10 * T);
+    if (host_schedules) memcpy(pk.data.data() + oS, host_schedules, (size_t)(has_rc ? 10 : (has_abar ? 8 : 7)) * T * sizeof(float));
 
     td_model *m = new (std::nothrow) td_model();
     if (!m) { td_set_error("td_model_create: out of host memory"); return TD_ENOMEM; }
@@ -510,7 +519,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
     const float *S = D + oS;
-    m->sched = TdSchedules{S, S + T, S + 2 * T, S + 3 * T, S + 4 * T, S + 5 * T, S + 6 * T, has_abar ? S + 7 * T : nullptr};
+    m->sched = TdSchedules{S, S + T, S + 2 * T, S + 3 * T, S + 4 * T, S + 5 * T, S + 6 * T, has_abar ? S + 7 * T : nullptr,
+                           has_rc ? S + 8 * T : nullptr, has_rc ? S + 9 * T : nullptr};
     *out = m;
     return TD_OK;
 }
@@ -1037,7 +1047,7 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
                                 const int64_t *d_ligand_v, const int32_t *d_ligand_ptr, int64_t N_l, int64_t B,
                                 int32_t fix_x, int32_t max_graph_nodes, float *d_pred_ligand_pos,
                                 float *d_pred_ligand_v, float *d_final_ligand_h, float *d_final_h, void *d_workspace,
-                                size_t workspace_bytes, void *stream) {
+                                size_t workspace_bytes, const float *d_ligand_graph_bias, void *stream) {
     if (!m || N_p < 0 || N_l < 0 || B < 0) { td_set_error("td_model_forward: bad argument"); return TD_EINVAL; }
     const int64_t N = N_p + N_l;
     if (N == 0) return TD_OK;
@@ -1063,7 +1073,7 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
         {
             ProfScope ps(PC_COMPOSE, s);
             rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v, d_ligand_ptr, N_l, B,
-                                   h, w.x4a, w.node_ptr, w.gid, w.lig_node, p.prot_node, s);
+                                   h, w.x4a, w.node_ptr, w.gid, w.lig_node, p.prot_node, s, d_ligand_graph_bias);
         }
         if (rc == TD_OK) rc = plan_layout(p, w.node_ptr, w.gid, s);
         if (rc == TD_OK) rc = build_general_graph(m, p, w, N, N_l, max_graph_nodes, s);
@@ -1079,7 +1089,7 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
     {
         ProfScope ps(PC_COMPOSE, s);
         if ((rc = td_launch_compose(m, d_protein_pos, d_protein_v, d_protein_ptr, N_p, d_ligand_pos, d_ligand_v,
-                                    d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, nullptr, s)) != TD_OK)
+                                    d_ligand_ptr, N_l, B, h, w.x4a, w.node_ptr, w.gid, w.lig_node, nullptr, s, d_ligand_graph_bias)) != TD_OK)
             return rc;
     }
     float4 *xf = nullptr;
@@ -1105,7 +1115,7 @@ extern "C" int td_posterior_step(const td_model *m, const int32_t *d_t, const in
     ProfScope ps(PC_POST, static_cast<hipStream_t>(stream));
     return td_launch_posterior(m->sched, m->cfg.num_timesteps, d_t, d_ligand_ptr, N_l, B, m->cfg.ligand_num_classes,
                                d_ligand_pos, d_ligand_v, d_pred_pos, d_pred_v, d_noise, d_uniform, d_pos_next,
-                               d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream));
+                               d_v_next, d_log_v0, d_log_post, static_cast<hipStream_t>(stream), m->cfg.model_mean_type);
 }
 
 // ------------------------------------------------------------------------------------------ standalone EGNN refine net
@@ -1588,7 +1598,7 @@ extern "C" void td_session_destroy(td_session *S) {
 
 extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, const int64_t *d_ligand_v,
                                   float *d_pred_ligand_pos, float *d_pred_ligand_v, float *d_final_ligand_h,
-                                  void *stream) {
+                                  const float *d_ligand_graph_bias, void *stream) {
     if (!S || !d_ligand_pos || !d_ligand_v || !d_pred_ligand_pos || !d_pred_ligand_v) {
         td_set_error("td_session_forward: null pointer");
         return TD_EINVAL;
@@ -1604,7 +1614,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         {
             ProfScope ps(PC_COMPOSE, s);
             TD_CHECK_HIP(hipMemcpyAsync(w.h, S->h0, (size_t)N * TD_H * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s)) != TD_OK) return rc;
+            if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, nullptr, d_ligand_graph_bias, w.gid)) != TD_OK) return rc;
         }
         float4 *xg = nullptr;
         if (S->chunked) rc = build_general_graph(m, S->plan, w, N, Nl, S->max_graph_nodes, s);
@@ -1623,7 +1633,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
         rs.c1 = S->fwd_counts; rs.n1 = 2;
         rs.c2 = S->hop_count; rs.n2 = TD_HOP_LEVELS;
         rs.flags2 = S->use_fwd ? S->flags2 : nullptr;
-        if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, &rs)) != TD_OK) return rc;
+        if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, &rs, d_ligand_graph_bias, w.gid)) != TD_OK) return rc;
     }
     bool lists_done = false;
     {
@@ -1697,12 +1707,13 @@ namespace {
 // the launches of one step, in order (eagerly or into a capturing stream)
 int session_step_issue(td_session *S, const td_step_io &io, hipStream_t s) {
     const td_model *m = S->m;
-    int rc = td_session_forward(S, io.d_ligand_pos, io.d_ligand_v, S->pred_pos, S->pred_v, nullptr, s);
+    int rc = td_session_forward(S, io.d_ligand_pos, io.d_ligand_v, S->pred_pos, S->pred_v, nullptr, io.d_ligand_graph_bias, s);
     if (rc != TD_OK) return rc;
     ProfScope ps(PC_POST, s);
     return td_launch_posterior_step(m->sched, m->cfg.num_timesteps, io.d_step, io.d_t_all, io.num_steps, S->lptr, S->Nl, S->B,
                                     m->cfg.ligand_num_classes, io.d_ligand_pos, io.d_ligand_v, S->pred_pos, S->pred_v, io.d_noise,
-                                    io.d_uniform, io.d_pos_traj, io.d_v_traj, io.d_v0_traj, io.d_vt_traj, io.pos_only, s);
+                                    io.d_uniform, io.d_pos_traj, io.d_v_traj, io.d_v0_traj, io.d_vt_traj, io.pos_only, s,
+                                    m->cfg.model_mean_type);
 }
 }  // namespace
 

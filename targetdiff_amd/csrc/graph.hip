@@ -725,7 +725,8 @@ int td_launch_step_lists(const uint8_t *clean, const float4 *x4, const int32_t *
 __global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restrict__ lpos, const int64_t *__restrict__ lv,
                                                             const int32_t *__restrict__ lig_node, int64_t Nl, int C,
                                                             const float *__restrict__ WlT, const float *__restrict__ bl,
-                                                            float *__restrict__ h, float4 *__restrict__ x4, TdStepReset rs) {
+                                                            float *__restrict__ h, float4 *__restrict__ x4, TdStepReset rs,
+                                                            const float *__restrict__ gbias, const int32_t *__restrict__ gid) {
     const int n = threadIdx.x;
     if (blockIdx.x == 0) {
         if (rs.c0 && n < rs.n0) rs.c0[n] = 0;
@@ -740,7 +741,9 @@ __global__ __launch_bounds__(128) void ligand_update_kernel(const float *__restr
         const int64_t p = lig_node[at];
         int v = (int)lv[at];
         v = v < 0 ? 0 : (v >= C ? C - 1 : v);
-        h[p * TD_H + n] = WlT[v * TD_H + n] + bias;
+        // gbias (optional): the time-embedding columns of ligand_atom_emb applied to the graph's time feature
+        // (models/molopt_score_model.py:319-329), one row per graph
+        h[p * TD_H + n] = (gbias ? WlT[v * TD_H + n] + gbias[(size_t)gid[p] * TD_H + n] : WlT[v * TD_H + n]) + bias;
         if (n == 0) {
             x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
             if (rs.flags2) rs.flags2[p] = 0;
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(128) void compose_ligand_kernel(
     const float *__restrict__ lpos, const int64_t *__restrict__ lv, const int32_t *__restrict__ pptr,
     const int32_t *__restrict__ lptr, int64_t Nl, int B, int C, const float *__restrict__ WlT,
     const float *__restrict__ bl, float *__restrict__ h, float4 *__restrict__ x4, int32_t *__restrict__ gid,
-    int32_t *__restrict__ lig_node) {
+    int32_t *__restrict__ lig_node, const float *__restrict__ gbias) {
     const int n = threadIdx.x;
     const int64_t a0 = (int64_t)blockIdx.x * TD_COMPOSE_ATOMS;
     const float bias = bl[n];
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(128) void compose_ligand_kernel(
         int64_t p = (int64_t)pptr[g + 1] + at;
         int v = (int)lv[at];
         v = v < 0 ? 0 : (v >= C ? C - 1 : v);
-        h[p * TD_H + n] = WlT[v * TD_H + n] + bias;
+        h[p * TD_H + n] = (gbias ? WlT[v * TD_H + n] + gbias[(size_t)g * TD_H + n] : WlT[v * TD_H + n]) + bias;
         if (n == 0) {
             x4[p] = make_float4(lpos[3 * at], lpos[3 * at + 1], lpos[3 * at + 2], 1.f);
             gid[p] = g;
@@ -819,7 +822,7 @@ __global__ void node_ptr_kernel(const int32_t *__restrict__ pptr, const int32_t 
 int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
                       const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
                       float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, int32_t *prot_node,
-                      hipStream_t s) {
+                      hipStream_t s, const float *gbias) {
     node_ptr_kernel<<<dim3((unsigned)((B + 1 + 255) / 256)), dim3(256), 0, s>>>(pptr, lptr, (int)B, node_ptr);
     TD_CHECK_HIP(hipGetLastError());
     if (Np > 0) {
@@ -833,19 +836,20 @@ int td_launch_compose(const td_model *m, const float *ppos, const float *pv, con
         unsigned nb = (unsigned)((Nl + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
         compose_ligand_kernel<<<dim3(nb), dim3(128), 0, s>>>(lpos, lv, pptr, lptr, Nl, (int)B,
                                                             m->cfg.ligand_num_classes, m->emb.WlT, m->emb.bl, h, x4,
-                                                            gid, lig_node);
+                                                            gid, lig_node, gbias);
         TD_CHECK_HIP(hipGetLastError());
     }
     return TD_OK;
 }
 
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
-                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset) {
+                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset, const float *gbias,
+                            const int32_t *gid) {
     if (Nl == 0) return TD_OK;
     unsigned nb = (unsigned)((Nl + TD_COMPOSE_ATOMS - 1) / TD_COMPOSE_ATOMS);
     const TdStepReset rs = reset ? *reset : TdStepReset{};
     ligand_update_kernel<<<dim3(nb), dim3(128), 0, s>>>(lpos, lv, lig_node, Nl, m->cfg.ligand_num_classes, m->emb.WlT,
-                                                      m->emb.bl, h, x4, rs);
+                                                      m->emb.bl, h, x4, rs, gbias, gid);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -93,7 +93,8 @@ __device__ __forceinline__ void td_posterior_atom(const TdSchedules &sc, int T, 
                                                   const float *__restrict__ noise, const float *__restrict__ uni,
                                                   float *pos_next, int64_t *v_next,
                                                   float *__restrict__ log_v0_out, float *__restrict__ log_post_out,
-                                                  float *pos_cur = nullptr, int64_t *v_cur = nullptr, bool v_frozen = false) {
+                                                  float *pos_cur = nullptr, int64_t *v_cur = nullptr, bool v_frozen = false,
+                                                  int mean_type = 0) {
     const int g = td_find_graph_l(lptr, B, (int)at);
     int t = tg[g];
     t = t < 0 ? 0 : (t >= T ? T - 1 : t);
@@ -104,7 +105,13 @@ __device__ __forceinline__ void td_posterior_atom(const TdSchedules &sc, int T, 
 #pragma unroll
     for (int d = 0; d < 3; ++d)       // three products, two sums, each rounded on its own -- PyTorch's eager arithmetic (:376, :679), and the
                                       // same bits in every kernel this function is inlined into (no compiler-chosen FMA contraction)
-        xn[d] = td_add_rn(td_add_rn(td_mul_rn(c0, pred_pos[at * 3 + d]), td_mul_rn(ct, pos[at * 3 + d])), td_mul_rn(sd, noise[at * 3 + d]));
+    {
+        const float xt = pos[at * 3 + d];
+        float x0 = pred_pos[at * 3 + d];
+        // model_mean_type 'noise' (:412-416, :663-666): the network's output is x_t + eps; x0 = rc[t] x_t - rm1[t] eps
+        if (mean_type == 1) x0 = td_add_rn(td_mul_rn(sc.rc[t], xt), -td_mul_rn(sc.rm1[t], td_add_rn(x0, -xt)));
+        xn[d] = td_add_rn(td_add_rn(td_mul_rn(c0, x0), td_mul_rn(ct, xt)), td_mul_rn(sd, noise[at * 3 + d]));
+    }
     const int vt = (int)v[at];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -170,10 +177,11 @@ __global__ void posterior_kernel(TdSchedules sc, int T, const int32_t *__restric
                                  const float *__restrict__ pred_pos, const float *__restrict__ pred_v,
                                  const float *__restrict__ noise, const float *__restrict__ uni,
                                  float *__restrict__ pos_next, int64_t *__restrict__ v_next,
-                                 float *__restrict__ log_v0_out, float *__restrict__ log_post_out) {
+                                 float *__restrict__ log_v0_out, float *__restrict__ log_post_out, int mean_type) {
     const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (at >= Nl) return;
-    td_posterior_atom(sc, T, tg, lptr, B, C, at, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0_out, log_post_out);
+    td_posterior_atom(sc, T, tg, lptr, B, C, at, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0_out, log_post_out,
+                      nullptr, nullptr, false, mean_type);
 }
 
 // td_session_step: the same update with its per-step arguments taken from device memory -- step index s = step[0] selects the
@@ -184,7 +192,7 @@ __global__ void posterior_step_kernel(TdSchedules sc, int T, int32_t *__restrict
                                       float *pos, int64_t *v, const float *__restrict__ pred_pos,
                                       const float *__restrict__ pred_v, const float *__restrict__ noise,
                                       const float *__restrict__ uni, float *__restrict__ pos_traj, int64_t *__restrict__ v_traj,
-                                      float *__restrict__ v0_traj, float *__restrict__ vt_traj, int pos_only) {
+                                      float *__restrict__ v0_traj, float *__restrict__ vt_traj, int pos_only, int mean_type) {
     int s = *reinterpret_cast<volatile int32_t *>(step);
     s = s < 0 ? 0 : (s >= num_steps ? num_steps - 1 : s);
     const int64_t at = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +200,7 @@ __global__ void posterior_step_kernel(TdSchedules sc, int T, int32_t *__restrict
         const size_t so = (size_t)s * (size_t)Nl;
         td_posterior_atom(sc, T, t_all + (size_t)s * B, lptr, B, C, at, pos, v, pred_pos, pred_v, noise, uni, pos_traj + so * 3,
                           v_traj + so, v0_traj ? v0_traj + so * C : nullptr, vt_traj ? vt_traj + so * C : nullptr, pos,
-                          pos_only ? nullptr : v, pos_only != 0);
+                          pos_only ? nullptr : v, pos_only != 0, mean_type);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -208,11 +216,11 @@ __global__ void posterior_step_kernel(TdSchedules sc, int T, int32_t *__restrict
 int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B,
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
                         const float *pred_v, const float *noise, const float *uni, float *pos_next,
-                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s) {
+                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s, int mean_type) {
     if (Nl == 0) return TD_OK;
     posterior_kernel<<<dim3((unsigned)((Nl + 127) / 128)), dim3(128), 0, s>>>(
         sc, T, t, lptr, Nl, (int)B, classes, pos, v, pred_pos, pred_v, noise, uni, pos_next, v_next, log_v0,
-        log_post);
+        log_post, mean_type);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -220,11 +228,11 @@ int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const in
 int td_launch_posterior_step(const TdSchedules &sc, int T, int32_t *step, const int32_t *t_all, int num_steps, const int32_t *lptr,
                              int64_t Nl, int64_t B, int classes, float *pos, int64_t *v, const float *pred_pos, const float *pred_v,
                              const float *noise, const float *uni, float *pos_traj, int64_t *v_traj, float *v0_traj, float *vt_traj,
-                             int pos_only, hipStream_t s) {
+                             int pos_only, hipStream_t s, int mean_type) {
     if (Nl == 0) return TD_OK;
     posterior_step_kernel<<<dim3((unsigned)((Nl + 127) / 128)), dim3(128), 0, s>>>(
         sc, T, step, t_all, num_steps, lptr, Nl, (int)B, classes, pos, v, pred_pos, pred_v, noise, uni, pos_traj, v_traj, v0_traj,
-        vt_traj, pos_only);
+        vt_traj, pos_only, mean_type);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

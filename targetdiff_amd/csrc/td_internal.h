@@ -124,6 +124,7 @@ struct TdEgnnLayer {
 struct TdSchedules {       // [T] each
     const float *c0, *ct, *logvar, *log_a, *log_1ma, *log_ca, *log_1mca;
     const float *abar;     // alphas_cumprod of the position schedule; nullptr when the model was created without it
+    const float *rc, *rm1; // sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod (model_mean_type 'noise'); nullptr without them
 };
 
 // Per-model switches (td_model_set_option; defaults = the shipped configuration).  They live in the model, i.e. per device
@@ -168,7 +169,7 @@ int td_launch_knn(const float4 *x4, const int32_t *node_ptr, const int32_t *gid,
 int td_launch_compose(const td_model *m, const float *ppos, const float *pv, const int32_t *pptr, int64_t Np,
                       const float *lpos, const int64_t *lv, const int32_t *lptr, int64_t Nl, int64_t B,
                       float *h, float4 *x4, int32_t *node_ptr, int32_t *gid, int32_t *lig_node, int32_t *prot_node,
-                      hipStream_t s);
+                      hipStream_t s, const float *gbias = nullptr);
 int td_launch_knn_rows(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
                        int max_graph_nodes, int32_t *nbr, hipStream_t s, int k = TD_K);
 int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_t *gid, const int32_t *rows, int64_t count,
@@ -208,7 +209,8 @@ struct TdStepReset {
     uint8_t *flags2 = nullptr;
 };
 int td_launch_ligand_update(const td_model *m, const float *lpos, const int64_t *lv, const int32_t *lig_node, int64_t Nl,
-                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset = nullptr);
+                            float *h, float4 *x4, hipStream_t s, const TdStepReset *reset = nullptr, const float *gbias = nullptr,
+                            const int32_t *gid = nullptr);
 int td_launch_ligand_list(const uint8_t *mask, int64_t N, int32_t *lig_node, int32_t *count, hipStream_t s);
 // node.hip
 // rows: optional list of node ids (N = its length); mat_mask bits 0..3 = [k_i, k_j, v_i, v_j] projections, bit 4 = query MLP
@@ -267,11 +269,11 @@ int td_launch_head(const TdHead &hd, const float *h, const float4 *x4, const int
 int td_launch_posterior(const TdSchedules &sc, int T, const int32_t *t, const int32_t *lptr, int64_t Nl, int64_t B,
                         int classes, const float *pos, const int64_t *v, const float *pred_pos,
                         const float *pred_v, const float *noise, const float *uni, float *pos_next,
-                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s);
+                        int64_t *v_next, float *log_v0, float *log_post, hipStream_t s, int mean_type = 0);
 int td_launch_posterior_step(const TdSchedules &sc, int T, int32_t *step, const int32_t *t_all, int num_steps, const int32_t *lptr,
                              int64_t Nl, int64_t B, int classes, float *pos, int64_t *v, const float *pred_pos, const float *pred_v,
                              const float *noise, const float *uni, float *pos_traj, int64_t *v_traj, float *v0_traj, float *vt_traj,
-                             int pos_only, hipStream_t s);
+                             int pos_only, hipStream_t s, int mean_type = 0);
 // egnn.hip / node.hip
 int td_launch_egnn_edge(const TdEgnnLayer &L, const float4 *x4, float4 *x4_out, const int32_t *nbr, const float *P, float *mi,
                         int64_t N, hipStream_t s);

@@ -244,10 +244,8 @@ class ScorePosNet3D(nn.Module):
         self.model_mean_type = g('model_mean_type')
         self.loss_v_weight = g('loss_v_weight')
         self.sample_time_method = g('sample_time_method')
-        if self.model_mean_type != 'C0':
-            raise NotImplementedError("model_mean_type != 'C0' is not built (configs/training.yml:10)")
-        if g('time_emb_dim', 0) != 0:
-            raise NotImplementedError('time_emb_dim > 0 is not built (configs/training.yml:20)')
+        if self.model_mean_type not in ('C0', 'noise'):       # :205; 'noise': the network predicts x_t + eps (:663-666)
+            raise ValueError(f'model_mean_type={self.model_mean_type!r}')
         if not g('node_indicator', True):
             raise NotImplementedError('node_indicator=False is not built')
 
@@ -300,8 +298,18 @@ class ScorePosNet3D(nn.Module):
         emb_dim = self.hidden_dim - 1
         self.protein_atom_emb = nn.Linear(protein_atom_feature_dim, emb_dim)
         self.center_pos_mode = g('center_pos_mode')
-        self.time_emb_dim = 0
-        self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim, emb_dim)
+        # time embedding (:286-303): extra input columns of ligand_atom_emb, fed with a per-graph feature of the time step
+        self.time_emb_dim = int(g('time_emb_dim', 0) or 0)
+        self.time_emb_mode = g('time_emb_mode', 'simple')
+        if self.time_emb_dim > 0:
+            if self.time_emb_mode == 'simple':
+                self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim + 1, emb_dim)
+            else:
+                # 'sin' is dead code in the reference: forward concatenates the per-GRAPH feature time_emb(time_step) [B, dim] with the
+                # per-ATOM one-hot [N_l, C] (:326-327, no [batch_ligand]) and raises unless B == N_l -- nothing to reproduce
+                raise NotImplementedError(f"time_emb_mode={self.time_emb_mode!r}: only 'simple' runs in the reference (:319-329)")
+        else:
+            self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim, emb_dim)
         self.refine_net_type = g('model_type')
         if self.refine_net_type != 'uni_o2':
             # the reference builds an EGNN here but cannot run it: forward passes fix_x=, which EGNN.forward does not
@@ -363,7 +371,12 @@ class ScorePosNet3D(nn.Module):
                        num_timesteps=self.num_timesteps, cutoff_mode=rn.cutoff_mode, radius=rn.r,
                        max_num_neighbors=rn.max_num_neighbors)
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
-            self._native_model = capi.NativeModel(cfg, self.state_dict(), sched, device=device)
+            cfg['model_mean_type'] = self.model_mean_type
+            sd = self.state_dict()
+            if self.time_emb_dim > 0:         # the kernels embed the one-hot part; the time columns go through _time_bias
+                sd = dict(sd)
+                sd['ligand_atom_emb.weight'] = sd['ligand_atom_emb.weight'][:, :self.num_classes].contiguous()
+            self._native_model = capi.NativeModel(cfg, sd, sched, device=device)
             for name, value in getattr(self, '_native_options', {}).items():
                 self._native_model.set_option(name, value)
             self._native_key = key
@@ -372,10 +385,11 @@ class ScorePosNet3D(nn.Module):
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, protein_pos, protein_v, batch_protein, init_ligand_pos, init_ligand_v, batch_ligand,
                 time_step=None, return_all=False, fix_x=False):
-        """One denoiser evaluation (models/molopt_score_model.py:313-368).  ``time_step`` is unused by the
-        network when time_emb_dim == 0, as in the reference."""
+        """One denoiser evaluation (models/molopt_score_model.py:313-368).  ``time_step`` [B] is unused by the
+        network when time_emb_dim == 0, as in the reference; with a time embedding it is required."""
         native = self._native(protein_pos.device)
         B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
+        gbias = self._time_bias(time_step, B)
         unsorted_p, unsorted_l = _check_graph_inputs(batch_protein, batch_ligand, init_ligand_v, self.num_classes, allow_unsorted=True)
         # compose_context (models/common.py:120-137) accepts unsorted batch vectors: it stable-sorts the nodes by graph and the
         # outputs come back in THAT order (`final_pos[mask_ligand]`, :352 -- the ligand rows are not put back in input order)
@@ -389,13 +403,34 @@ class ScorePosNet3D(nn.Module):
         lptr = native.graph_ptr(batch_ligand.contiguous(), B)
         lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
         preds = native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr, lpos, lv, lptr,
-                                     fix_x=fix_x)
+                                     fix_x=fix_x, ligand_graph_bias=gbias)
         if return_all:
             # :360-367 -- the refine net records the state before and after each block; num_blocks == 1 here, so the
             # lists hold the block input (the embedded ligand atoms at their input positions) and the block output
             preds['layer_pred_ligand_pos'] = [lpos.clone(), preds['pred_ligand_pos']]
-            preds['layer_pred_ligand_v'] = [native.v_inference(native.embed_ligand(lv)), preds['pred_ligand_v']]
+            emb0 = native.embed_ligand(lv)
+            if gbias is not None:
+                emb0 = emb0 + gbias[batch_ligand]
+            preds['layer_pred_ligand_v'] = [native.v_inference(emb0), preds['pred_ligand_v']]
         return preds
+
+    def _time_bias(self, time_step, B):
+        """The time-embedding term of the ligand atoms' embedding, one row per graph ([B, 128] fp32, the node-indicator column
+        zero), or None when time_emb_dim == 0 (models/molopt_score_model.py:319-329): ligand_atom_emb is linear in its input
+        ``[one_hot(v), time feature]``, so its time columns applied to the graph's time feature are a per-graph vector added to
+        every ligand atom's embedding -- a few hundred multiplies, done here with torch; the kernels add the row."""
+        if self.time_emb_dim <= 0:
+            return None
+        if time_step is None:
+            raise ValueError('time_emb_dim > 0: forward needs time_step (one entry per graph)')
+        W = self.ligand_atom_emb.weight                                       # [127, C + 1]
+        t = time_step.to(W.device)
+        if t.numel() != B:
+            raise ValueError(f'time_step has {t.numel()} entries for {B} graphs')
+        feat = (t / self.num_timesteps).to(torch.float32).unsqueeze(-1)           # :321-324 ('simple', the only mode that runs)
+        out = torch.zeros(B, self.hidden_dim, dtype=torch.float32, device=W.device)
+        out[:, :W.shape[0]] = feat.to(torch.float32) @ W[:, self.num_classes:].t().to(torch.float32)
+        return out
 
     @torch.no_grad()
     def likelihood_estimation(self, protein_pos, protein_v, batch_protein, ligand_pos, ligand_v, batch_ligand, time_step,
@@ -426,7 +461,10 @@ class ScorePosNet3D(nn.Module):
             noise = noise_source(0, 'noise', lpos)
             uniform = noise_source(0, 'uniform', None)
         pos_t, v_t = native.perturb(t32, lptr, lpos, lv, noise, uniform)                    # :582-586
-        preds = native.model_forward(ppos, protein_v.contiguous().float(), pptr, pos_t, v_t, lptr, want_final_h=False)
+        if self.model_mean_type != 'C0':
+            raise ValueError(self.model_mean_type)                                # :601-605: the reference raises here as well
+        preds = native.model_forward(ppos, protein_v.contiguous().float(), pptr, pos_t, v_t, lptr, want_final_h=False,
+                                     ligand_graph_bias=self._time_bias(time_step, B))
         return native.likelihood_terms(t32, lptr, lpos, pos_t, lv, v_t, preds['pred_ligand_pos'], preds['pred_ligand_v'])
 
     @torch.no_grad()
@@ -527,6 +565,10 @@ class ReverseSampler:
         self.bufs = {}
         self.s = 0
         # this step's draws live in fixed buffers, refilled in place every step (the captured step reads them by address)
+        self.model = model
+        self._gbias = None
+        if model.time_emb_dim > 0:           # this step's time-embedding rows, in a fixed buffer (the captured step reads it by address)
+            self._gbias = torch.zeros(B, model.hidden_dim, dtype=torch.float32, device=dev)
         self._noise = torch.empty(Nl, 3, dtype=torch.float32, device=dev)
         self._uniform = self._half if self.pos_only else torch.empty(Nl, C, dtype=torch.float32, device=dev)
         # loop-invariant protein state lives in a native session (td_session); opt out with use_session=False
@@ -541,7 +583,7 @@ class ReverseSampler:
             if S > 0:
                 self._io = self.session.make_step_io(self._step_index, self.t_all, self.lpos, self.lv, self._noise,
                                                      self._uniform, self.pos_traj, self.v_traj, self.v0_traj, self.vt_traj,
-                                                     self.pos_only)
+                                                     self.pos_only, ligand_graph_bias=self._gbias)
 
     def _graph_now(self):
         """Replay the step as a captured hipGraph?  ``use_graph=None`` (default): when the caller runs on a real stream (the
@@ -558,7 +600,10 @@ class ReverseSampler:
         return self.s >= self.S
 
     def _draw(self, s):
-        """This step's Gaussian / uniform draws into the fixed buffers, in the reference's order (:677, then :161)."""
+        """This step's Gaussian / uniform draws into the fixed buffers, in the reference's order (:677, then :161); with a time
+        embedding, also this step's per-graph embedding rows (:652 time_step = t for every graph)."""
+        if self._gbias is not None:
+            self._gbias.copy_(self.model._time_bias(self.t_all[s], self.B))
         if self.noise_source is None:
             # == torch.randn_like(lpos) / torch.rand(Nl, C): the same generator stream, written in place
             self._noise.normal_(generator=self.generator)
@@ -580,13 +625,14 @@ class ReverseSampler:
         lpos_in, lv_in = self.lpos, self.lv
         if self._lig_order is not None:
             lpos_in, lv_in = self.lpos[self._lig_order].contiguous(), self.lv[self._lig_order].contiguous()
+        self._draw(s)
         if self.session is not None:
-            preds = self.session.forward(lpos_in, lv_in, out=self.bufs)
+            preds = self.session.forward(lpos_in, lv_in, out=self.bufs, ligand_graph_bias=self._gbias)
         else:
             preds = native.model_forward(self.ppos, self.pv, self.pptr, lpos_in, lv_in, self.lptr,
-                                         max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs)
+                                         max_graph_nodes=self.max_graph_nodes, want_final_h=False, out=self.bufs,
+                                         ligand_graph_bias=self._gbias)
         self.bufs = preds
-        self._draw(s)
         if self.pos_only:
             native.posterior_step(self.t_all[s], self.lptr, self.lpos, self.lv, preds['pred_ligand_pos'],
                                   preds['pred_ligand_v'], self._noise, self._half, pos_next=self.pos_traj[s],

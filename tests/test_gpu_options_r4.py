@@ -1,0 +1,88 @@
+"""Configurations of ScorePosNet3D outside configs/training.yml that the mirror accepts since round 4, against fixtures the REAL reference
+produced (oracle/make_golden_r4.py): the time embedding (time_emb_mode = 'simple': one more input column of ligand_atom_emb, fed with
+t / T per graph; 'sin' is dead code in the reference and refused) and model_mean_type = 'noise' (the network's position output is
+x_t + eps).  Every step form: the captured graph, launch by launch, and the stateless forward."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL_X, TOL_H, TOL_TRAJ = 2e-5, 2e-4, 5e-5
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def _model(sd, **over):
+    from oracle import weights
+    from targetdiff_amd.models import ScorePosNet3D
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    cfg.update(over)
+    m = ScorePosNet3D(cfg, 27, 13)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    return m.to(_dev()).eval()
+
+
+def test_forward_with_simple_time_embedding_vs_reference():
+    from oracle import weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    g = load_golden('forward_time_simple.npz')
+    model = _model(weights.time_emb_state_dict(SEED), time_emb_dim=int(g['time_emb_dim']), time_emb_mode='simple')
+    assert model.ligand_atom_emb.weight.shape == (127, 14)
+    b = small_batch()[0].to(dev)
+    t = torch.from_numpy(g['time_step']).to(dev)
+    p = model(torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+              torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch, time_step=t,
+              return_all=True)
+    assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
+    assert _maxdiff(p['pred_ligand_v'], g['pred_ligand_v']) <= TOL_H
+    assert _maxdiff(p['final_ligand_h'], g['final_ligand_h']) <= TOL_H
+    assert _maxdiff(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v']) <= TOL_H
+    # the time step matters (another one moves the outputs), and it is required
+    p2 = model(torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+               torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch, time_step=t * 0)
+    assert _maxdiff(p2['pred_ligand_v'], g['pred_ligand_v']) > 1e-3
+    with pytest.raises(ValueError, match='time_step'):
+        model(torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+              torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch)
+
+
+@pytest.mark.parametrize('fixture,over', [('sample_time_simple_6.npz', dict(time_emb_dim=8, time_emb_mode='simple')),
+                                          ('sample_noise_6.npz', dict(model_mean_type='noise'))])
+def test_sampling_with_time_embedding_and_noise_mean_type_vs_reference(fixture, over):
+    from oracle import draws, weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    g = load_golden(fixture)
+    sd = weights.time_emb_state_dict(SEED) if 'time_emb_dim' in over else weights.make_state_dict(SEED)
+    model = _model(sd, **over)
+    b = small_batch()[0].to(dev)
+    steps = int(g['steps'])
+    side = torch.cuda.Stream(device=dev)
+    outs = []
+    for kw in (dict(use_graph=True), dict(use_graph=False), dict(use_session=False)):
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            r = model.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                                       torch.from_numpy(g['init_ligand_pos']).to(dev), torch.from_numpy(g['init_ligand_v']).to(dev),
+                                       b.ligand_element_batch, num_steps=steps, center_pos_mode='protein',
+                                       noise_source=draws.Source(int(g['draws_base']), dev), **kw)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        assert np.array_equal(torch.stack(r['v_traj']).numpy(), g['v_traj'].astype(np.int64)), (fixture, kw)
+        assert _maxdiff(torch.stack(r['pos_traj']), g['pos_traj']) <= TOL_TRAJ, (fixture, kw)
+        assert _maxdiff(torch.stack(r['v0_traj']), g['v0_traj']) <= TOL_H, (fixture, kw)
+        outs.append(r)
+    for r in outs[1:]:
+        for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
+            assert torch.equal(torch.stack(outs[0][key]), torch.stack(r[key])), (fixture, key)

@@ -187,3 +187,19 @@ def test_radius_mode_warns_that_it_is_the_projects_rule():
     from targetdiff_amd.models import ScorePosNet3D
     with pytest.warns(UserWarning, match="no counterpart in the reference"):
         ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, cutoff_mode='radius', r=5.0), 27, 13)
+
+
+def test_round4_config_options_are_accepted_or_refused_like_the_reference():
+    """model_mean_type 'noise' and time_emb_mode 'simple' construct (state_dict layout as the reference's: one more column of
+    ligand_atom_emb); time_emb_mode 'sin' -- dead code in the reference (torch.cat of [N_l, C] with [B, dim], :326-327) -- and the
+    other architectures outside configs/training.yml raise."""
+    from targetdiff_amd.models import ScorePosNet3D
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    m = ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='simple', model_mean_type='noise'), 27, 13)
+    assert m.ligand_atom_emb.weight.shape == (127, 14) and m.model_mean_type == 'noise'
+    sd = weights.time_emb_state_dict(5)
+    assert not m.load_state_dict(sd, strict=False).unexpected_keys
+    with pytest.raises(NotImplementedError, match='sin'):
+        ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='sin'), 27, 13)
+    with pytest.raises(ValueError):
+        ScorePosNet3D(dict(cfg, model_mean_type='x0'), 27, 13)
