@@ -50,7 +50,7 @@ class RecordingNative:
         return off
 
     def model_forward(self, protein_pos, protein_v, protein_ptr, ligand_pos, ligand_v, ligand_ptr, fix_x=False, max_graph_nodes=0,
-                      want_final_h=True, out=None):
+                      want_final_h=True, out=None, ligand_graph_bias=None):
         self._rec('model_forward', protein_pos=protein_pos, protein_v=protein_v, ligand_pos=ligand_pos, ligand_v=ligand_v)
         assert protein_v.dtype == torch.float32 and ligand_v.dtype == torch.int64
         return R.model_forward(self.sd, self.cfg, protein_pos, protein_v, _batch_of(protein_ptr), ligand_pos, ligand_v,
@@ -77,14 +77,15 @@ class StubSession:
         native._rec('session_create', protein_pos=protein_pos, protein_v=protein_v)
         self.a = (native, protein_pos, protein_v, protein_ptr, ligand_ptr)
 
-    def forward(self, ligand_pos, ligand_v, out=None):
+    def forward(self, ligand_pos, ligand_v, out=None, ligand_graph_bias=None):
         n, pp, pv, pptr, lptr = self.a
         return n.model_forward(pp, pv, pptr, ligand_pos, ligand_v, lptr)
 
     # td_session_step: forward + posterior update on the state held in `io` (current positions / types updated in place, slot s of
     # the trajectories filled, the step index advanced)
     def make_step_io(self, step_index, t_all, ligand_pos, ligand_v, noise, uniform, pos_traj, v_traj, v0_traj=None, vt_traj=None,
-                     pos_only=False):
+                     pos_only=False, ligand_graph_bias=None):
+        assert ligand_graph_bias is None               # time_emb_dim == 0 in this configuration
         return dict(step=step_index, t_all=t_all, pos=ligand_pos, v=ligand_v, noise=noise, uniform=uniform, pos_traj=pos_traj,
                     v_traj=v_traj, v0_traj=v0_traj, vt_traj=vt_traj, pos_only=pos_only)
 
