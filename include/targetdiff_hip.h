@@ -73,7 +73,11 @@ typedef struct td_config {
     int32_t model_mean_type;     /* 0 = 'C0' (the network predicts x0; configs/training.yml), 1 = 'noise' (it predicts x_t + eps:
                                     x0 = sqrt_recip_alphas_cumprod[t] x_t - sqrt_recipm1_alphas_cumprod[t] (pred - x_t),
                                     models/molopt_score_model.py:412-416, 663-666; sampling only, as in the reference) */
-    int32_t reserved[3];
+    int32_t num_blocks;          /* 0 or 1 (configs/training.yml) .. 8: the layer stack is applied num_blocks times, the graph and the
+                                    edge gate rebuilt from the current coordinates before every pass, same weights
+                                    (models/uni_transformer.py:306-323).  > 1: sampling sessions do not cache (their static-protein
+                                    tables describe the first pass only) */
+    int32_t reserved[2];
 } td_config;
 
 /* ---- library ------------------------------------------------------------------------------------ */

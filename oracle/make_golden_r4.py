@@ -7,7 +7,9 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
       (return_all) on the small batch with a different time step per graph.  ('sin' cannot be run: the reference concatenates
       a [B, dim] feature with the [N_l, C] one-hot, :326-327, and raises -- checked here.)
   sample_time_simple_6.npz   6 reverse steps of the reference's loop with that embedding (it changes every step), counter draws;
-  sample_noise_6.npz         6 reverse steps with model_mean_type = 'noise' (:663-666).
+  sample_noise_6.npz         6 reverse steps with model_mean_type = 'noise' (:663-666);
+  forward_blocks2.npz / sample_blocks2_4.npz   num_blocks = 2 (models/uni_transformer.py:306-323: the nine layers applied twice, graph and
+      edge gate rebuilt from the moved coordinates in between): forward on the small batch, 4 reverse steps.
 Weights: oracle.weights.time_emb_state_dict / make_state_dict (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
 
@@ -56,6 +58,19 @@ def gen_forward_time(ref, mode):
     print(f'forward_time_{mode}: |pred_v| max', float(p['pred_ligand_v'].abs().max()))
 
 
+def gen_forward_blocks(ref):
+    model = build(ref, num_blocks=2)
+    b, lpos, lv = small_batch()
+    ppos, lposc, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    with torch.no_grad():
+        p = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch)
+        f = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch, fix_x=True)
+    _save(os.path.join(GOLDEN_DIR, 'forward_blocks2.npz'), protein_pos=ppos.numpy(), ligand_pos=lposc.numpy(), ligand_v=lv.numpy(),
+          pred_ligand_pos=p['pred_ligand_pos'].numpy(), pred_ligand_v=p['pred_ligand_v'].numpy(),
+          final_ligand_h=p['final_ligand_h'].numpy(), final_h=p['final_h'].numpy(), fix_x_final_ligand_h=f['final_ligand_h'].numpy())
+    print('forward_blocks2: |pred_v| max', float(p['pred_ligand_v'].abs().max()))
+
+
 def gen_sample(ref, name, base, **over):
     model = build(ref, **over)
     b, lpos, lv = small_batch()
@@ -86,6 +101,10 @@ def main():
         print("reference, time_emb_mode='sin' raises:", str(exc).splitlines()[0])
     gen_sample(ref, 'sample_time_simple_6.npz', 4300, time_emb_dim=TIME_EMB_DIM, time_emb_mode='simple')
     gen_sample(ref, 'sample_noise_6.npz', 4400, model_mean_type='noise')
+    gen_forward_blocks(ref)
+    global STEPS
+    STEPS = 4
+    gen_sample(ref, 'sample_blocks2_4.npz', 4500, num_blocks=2)
 
 
 if __name__ == '__main__':

@@ -26,7 +26,7 @@ class TdConfig(ctypes.Structure):
     _fields_ = [('hidden_dim', c_int32), ('n_heads', c_int32), ('knn', c_int32), ('num_layers', c_int32),
                 ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
                 ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('cutoff_mode', c_int32), ('radius', c_float),
-                ('max_num_neighbors', c_int32), ('model_mean_type', c_int32), ('reserved', c_int32 * 3)]
+                ('max_num_neighbors', c_int32), ('model_mean_type', c_int32), ('num_blocks', c_int32), ('reserved', c_int32 * 2)]
 
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
@@ -242,7 +242,7 @@ class NativeModel:
                             ligand_num_classes=cfg['ligand_num_classes'], num_timesteps=cfg['num_timesteps'],
                             cutoff_mode=CUTOFF_MODES[mode], radius=float(cfg.get('radius', 0.0)),
                             max_num_neighbors=int(cfg.get('max_num_neighbors', 32)),
-                            model_mean_type=MEAN_TYPES[cfg.get('model_mean_type', 'C0')])
+                            model_mean_type=MEAN_TYPES[cfg.get('model_mean_type', 'C0')], num_blocks=int(cfg.get('num_blocks', 1) or 1))
         self.cutoff_mode, self.k = mode, int(cfg['knn'])
         self.default_graph = mode == 'knn' and self.k <= KNN       # the 32-slot fast path (and the caching session); k < 32
                                                                    # is the 32-NN row with the slots >= k masked

@@ -398,6 +398,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     const bool has_rc = host_schedules && num_schedule_floats == (size_t)10 * c.num_timesteps;
     const bool has_abar = has_rc || (host_schedules && num_schedule_floats == (size_t)8 * c.num_timesteps);
+    if (c.num_blocks < 0 || c.num_blocks > 8) {
+        td_set_error("td_model_create: num_blocks must be 1 .. 8 (0 = 1), got %d", c.num_blocks);
+        return TD_EINVAL;
+    }
     if (c.model_mean_type != 0 && c.model_mean_type != 1) {
         td_set_error("td_model_create: model_mean_type must be 0 ('C0') or 1 ('noise'), got %d", c.model_mean_type);
         return TD_EINVAL;
@@ -726,6 +730,8 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
     return TD_OK;
 }
 
+inline int num_blocks(const td_config &c) { return c.num_blocks > 1 ? c.num_blocks : 1; }
+
 // graph + edge gate of a composed batch on the default graph (32-slot rows: k-NN with k <= 32, radius with cap <= 32)
 int build_default_graph(const td_model *m, Workspace &w, int64_t N, int max_graph_nodes, hipStream_t s) {
     int rc;
@@ -1028,14 +1034,21 @@ extern "C" int td_refine_forward(const td_model *m, const float *d_h, const floa
         int64_t nl_all = 0;
         if ((rc = plan_from_mask(m->cfg, d_mask_ligand, w.node_ptr, N, B, s, &p, &nl_all)) != TD_OK) return rc;
         rc = plan_layout(p, w.node_ptr, w.gid, s);
-        if (rc == TD_OK) rc = build_general_graph(m, p, w, N, nl_all, max_graph_nodes, s);
-        if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), d_out_h, N, nl_all, fix_x, &xf, s, true);
+        // every block: graph + gate from the current coordinates (in w.x4a), then the layer stack (models/uni_transformer.py:306-323)
+        for (int blk = 0; rc == TD_OK && blk < num_blocks(m->cfg); ++blk) {
+            rc = build_general_graph(m, p, w, N, nl_all, max_graph_nodes, s);
+            if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), d_out_h, N, nl_all, fix_x, &xf, s, true);
+            if (rc == TD_OK && xf == w.x4b) std::swap(w.x4a, w.x4b);
+        }
         if (rc == TD_OK) rc = td_launch_unpack_x(xf, N, d_out_x, s);
         plan_destroy(p, s);
         return rc;
     }
-    if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
-    if ((rc = run_backbone(m, w, default_tab(w), d_out_h, N, nl, fix_x, &xf, s, true)) != TD_OK) return rc;
+    for (int blk = 0; blk < num_blocks(m->cfg); ++blk) {
+        if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
+        if ((rc = run_backbone(m, w, default_tab(w), d_out_h, N, nl, fix_x, &xf, s, true)) != TD_OK) return rc;
+        if (xf == w.x4b) std::swap(w.x4a, w.x4b);
+    }
     if ((rc = td_launch_unpack_x(xf, N, d_out_x, s)) != TD_OK) return rc;
     if (d_out_nbr) TD_CHECK_HIP(hipMemcpyAsync(d_out_nbr, w.nbr, (size_t)N * TD_K * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     if (d_out_ew) TD_CHECK_HIP(hipMemcpyAsync(d_out_ew, w.ew, (size_t)N * TD_K * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1076,8 +1089,11 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
                                    h, w.x4a, w.node_ptr, w.gid, w.lig_node, p.prot_node, s, d_ligand_graph_bias);
         }
         if (rc == TD_OK) rc = plan_layout(p, w.node_ptr, w.gid, s);
-        if (rc == TD_OK) rc = build_general_graph(m, p, w, N, N_l, max_graph_nodes, s);
-        if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), h, N, N_l, fix_x, &xg, s, true);
+        for (int blk = 0; rc == TD_OK && blk < num_blocks(m->cfg); ++blk) {
+            rc = build_general_graph(m, p, w, N, N_l, max_graph_nodes, s);
+            if (rc == TD_OK) rc = run_backbone(m, w, plan_tab(p), h, N, N_l, fix_x, &xg, s, true);
+            if (rc == TD_OK && xg == w.x4b) std::swap(w.x4a, w.x4b);
+        }
         if (rc == TD_OK) {
             ProfScope ps(PC_HEAD, s);
             rc = td_launch_head(m->head, h, xg, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,
@@ -1093,8 +1109,11 @@ extern "C" int td_model_forward(const td_model *m, const float *d_protein_pos, c
             return rc;
     }
     float4 *xf = nullptr;
-    if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
-    if ((rc = run_backbone(m, w, default_tab(w), h, N, N_l, fix_x, &xf, s, true)) != TD_OK) return rc;
+    for (int blk = 0; blk < num_blocks(m->cfg); ++blk) {
+        if ((rc = build_default_graph(m, w, N, max_graph_nodes, s)) != TD_OK) return rc;
+        if ((rc = run_backbone(m, w, default_tab(w), h, N, N_l, fix_x, &xf, s, true)) != TD_OK) return rc;
+        if (xf == w.x4b) std::swap(w.x4a, w.x4b);
+    }
     ProfScope ps(PC_HEAD, s);
     return td_launch_head(m->head, h, xf, w.lig_node, N_l, m->cfg.ligand_num_classes, d_pred_ligand_pos,
                           d_pred_ligand_v, d_final_ligand_h, s);
@@ -1471,7 +1490,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     for (int64_t g = 0; g < B; ++g) gmax = std::max(gmax, (hp[g + 1] - hp[g]) + (hl[g + 1] - hl[g]));
     S->graph_nodes_max = gmax;
     const bool knn_like = m->cfg.cutoff_mode == TD_CUTOFF_KNN || m->cfg.cutoff_mode == TD_CUTOFF_HYBRID;
-    S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES);
+    S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES) && num_blocks(m->cfg) == 1;
     if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
     const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table
     const int KS = S->chunked ? 64 : TD_K;                   // static keys kept per protein row
@@ -1617,9 +1636,14 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
             if ((rc = td_launch_ligand_update(m, d_ligand_pos, d_ligand_v, w.lig_node, Nl, w.h, w.x4a, s, nullptr, d_ligand_graph_bias, w.gid)) != TD_OK) return rc;
         }
         float4 *xg = nullptr;
-        if (S->chunked) rc = build_general_graph(m, S->plan, w, N, Nl, S->max_graph_nodes, s);
-        else rc = build_default_graph(m, w, N, S->max_graph_nodes, s);          // 32-slot rows (radius, cap <= 32)
-        if (rc == TD_OK) rc = run_backbone(m, w, gt, w.h, N, Nl, 0, &xg, s, true);
+        Workspace wb = w;             // (a block that ends in x4b hands its coordinates to the next one by swapping the two buffers)
+        rc = TD_OK;
+        for (int blk = 0; rc == TD_OK && blk < num_blocks(m->cfg); ++blk) {
+            if (S->chunked) rc = build_general_graph(m, S->plan, wb, N, Nl, S->max_graph_nodes, s);
+            else rc = build_default_graph(m, wb, N, S->max_graph_nodes, s);          // 32-slot rows
+            if (rc == TD_OK) rc = run_backbone(m, wb, gt, wb.h, N, Nl, 0, &xg, s, true);
+            if (rc == TD_OK && xg == wb.x4b) std::swap(wb.x4a, wb.x4b);
+        }
         if (rc != TD_OK) return rc;
         ProfScope ps(PC_HEAD, s);
         return td_launch_head(m->head, w.h, xg, w.lig_node, Nl, m->cfg.ligand_num_classes, d_pred_ligand_pos, d_pred_ligand_v,

@@ -129,7 +129,7 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
                  sync_twoup=False, r=None, max_num_neighbors=32):
         super().__init__()
         unsupported = []
-        if num_blocks != 1: unsupported.append(f'num_blocks={num_blocks}')
+        if not 1 <= int(num_blocks) <= 8: unsupported.append(f'num_blocks={num_blocks} (1..8)')
         if cutoff_mode not in capi.CUTOFF_MODES: unsupported.append(f'cutoff_mode={cutoff_mode!r}')
         if ew_net_type != 'global': unsupported.append(f'ew_net_type={ew_net_type!r}')
         if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
@@ -184,6 +184,8 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         out_h, out_x, _, _ = native.refine_forward(h_in, x_in, mask_ligand, node_ptr, fix_x=fix_x)
         outputs = {'x': out_x, 'h': out_h}
         if return_all:
+            if self.num_blocks != 1:        # the states between two blocks stay inside the library
+                raise NotImplementedError('return_all with num_blocks > 1: only the final state leaves td_refine_forward')
             outputs.update({'all_x': [x_in, out_x], 'all_h': [h_in, out_h]})
         return outputs
 
@@ -372,6 +374,7 @@ class ScorePosNet3D(nn.Module):
                        max_num_neighbors=rn.max_num_neighbors)
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             cfg['model_mean_type'] = self.model_mean_type
+            cfg['num_blocks'] = int(rn.num_blocks)
             sd = self.state_dict()
             if self.time_emb_dim > 0:         # the kernels embed the one-hot part; the time columns go through _time_bias
                 sd = dict(sd)
@@ -404,6 +407,8 @@ class ScorePosNet3D(nn.Module):
         lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
         preds = native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr, lpos, lv, lptr,
                                      fix_x=fix_x, ligand_graph_bias=gbias)
+        if return_all and self.refine_net.num_blocks != 1:
+            raise NotImplementedError('return_all with num_blocks > 1: only the final state leaves the library')
         if return_all:
             # :360-367 -- the refine net records the state before and after each block; num_blocks == 1 here, so the
             # lists hold the block input (the embedded ligand atoms at their input positions) and the block output

@@ -86,3 +86,46 @@ def test_sampling_with_time_embedding_and_noise_mean_type_vs_reference(fixture, 
     for r in outs[1:]:
         for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
             assert torch.equal(torch.stack(outs[0][key]), torch.stack(r[key])), (fixture, key)
+
+
+def test_two_blocks_vs_reference():
+    """num_blocks = 2 (models/uni_transformer.py:306-323): the nine layers applied twice with the graph and the edge gate rebuilt from the
+    moved coordinates in between.  Forward (and fix_x) on the small batch, 4 reverse steps -- session (which does not cache with several
+    blocks), launch by launch, stateless -- and the hybrid graph for the chunked path (self-consistency: session == stateless)."""
+    from oracle import draws, weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    g = load_golden('forward_blocks2.npz')
+    sd = weights.make_state_dict(SEED)
+    model = _model(sd, num_blocks=2)
+    b = small_batch()[0].to(dev)
+    args = (torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+            torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch)
+    p = model(*args)
+    assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
+    assert _maxdiff(p['pred_ligand_v'], g['pred_ligand_v']) <= TOL_H
+    assert _maxdiff(p['final_ligand_h'], g['final_ligand_h']) <= TOL_H
+    assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
+    f = model(*args, fix_x=True)
+    assert _maxdiff(f['final_ligand_h'], g['fix_x_final_ligand_h']) <= TOL_H
+    with pytest.raises(NotImplementedError, match='return_all'):
+        model(*args, return_all=True)
+    one = _model(sd)(*args)                       # one block gives something else
+    assert _maxdiff(one['pred_ligand_v'], g['pred_ligand_v']) > 1e-3
+    gs = load_golden('sample_blocks2_4.npz')
+    outs = []
+    for kw in (dict(use_graph=False), dict(use_session=False)):
+        r = model.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                                   torch.from_numpy(gs['init_ligand_pos']).to(dev), torch.from_numpy(gs['init_ligand_v']).to(dev),
+                                   b.ligand_element_batch, num_steps=int(gs['steps']), center_pos_mode='protein',
+                                   noise_source=draws.Source(int(gs['draws_base']), dev), **kw)
+        assert np.array_equal(torch.stack(r['v_traj']).numpy(), gs['v_traj'].astype(np.int64)), kw
+        assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
+        outs.append(r)
+    assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[1]['pos_traj']))
+    hyb = _model(sd, num_blocks=2, cutoff_mode='hybrid')
+    rs = [hyb.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                               torch.from_numpy(gs['init_ligand_pos']).to(dev), torch.from_numpy(gs['init_ligand_v']).to(dev),
+                               b.ligand_element_batch, num_steps=3, center_pos_mode='protein',
+                               noise_source=draws.Source(4600, dev), use_session=us) for us in (True, False)]
+    assert torch.equal(torch.stack(rs[0]['pos_traj']), torch.stack(rs[1]['pos_traj']))

@@ -56,7 +56,7 @@ def test_unsupported_config_is_rejected_not_emulated():
                          max_num_neighbors=32)
     assert lib.td_model_create(ctypes.byref(cfg3), dummy, 4, None, 0, ctypes.byref(h)) == -1      # radius mode needs r > 0
     from targetdiff_amd.models import ScorePosNet3D
-    for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='r'), dict(num_blocks=2), dict(hidden_dim=256)):
+    for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='r'), dict(num_blocks=9), dict(x2h_out_fc=True), dict(hidden_dim=256)):
         with pytest.raises(NotImplementedError):
             ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **bad), 27, 13)
     for ok in (dict(cutoff_mode='hybrid'), dict(knn=48), dict(cutoff_mode='radius', r=6.0, max_num_neighbors=16)):
