@@ -76,6 +76,8 @@ def main(argv=None, model_factory=build_model):
                     'instead of the reference\'s i %% N round-robin')
     ap.add_argument('--pin-devices', action='store_true', help='self-spawned ranks see one GPU each (HIP_VISIBLE_DEVICES=r), the '
                     'reference\'s CUDA_VISIBLE_DEVICES recipe, instead of all GPUs + set_device(LOCAL_RANK)')
+    ap.add_argument('--overlap-batches', action='store_true', help='advance the sample batches of a pocket together, one HIP stream and one '
+                    'captured hipGraph each (pays when batch_size is small; per-batch generators, see sample_diffusion_ligand)')
     ap.add_argument('--device', default='cuda', help="'cuda' (rank r uses GPU LOCAL_RANK) or 'cpu' (tests: gloo + stub model)")
     args = ap.parse_args(argv)
     if argv is None:
@@ -112,7 +114,8 @@ def main(argv=None, model_factory=build_model):
     t0 = time.time()
     sampling.run_sharded(model, pockets, args.num_samples, rank=rank, world_size=world, start_idx=args.start_idx,
                          result_path=args.result_path, keep_results=False, on_pocket=on_pocket, balance=args.balance,
-                         batch_size=args.batch_size, device=dev, num_steps=args.num_steps, ligand_num_atoms=sizes)
+                         batch_size=args.batch_size, device=dev, num_steps=args.num_steps, ligand_num_atoms=sizes,
+                         **({'overlap_batches': True} if args.overlap_batches else {}))
     if on_gpu:
         torch.cuda.synchronize()
     meta = {'rank': rank, 'wall_s': time.time() - t0, 'pockets': log}
