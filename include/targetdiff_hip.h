@@ -298,7 +298,9 @@ int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes);
 
 /* ---- test hook (not a reference seam): node-side GEMMs of one attention stage of layer `layer`
  *      (stage 0 = x2h: hk/hv/hq, stage 1 = h2x: xk/xv/xq).  d_P [N,512] = [k_i | k_j | v_i | v_j] node
- *      projections of the 340-wide first Linear (h_i part incl. bias), d_q [N,128] = MLP_q(h). */
+ *      projections of the 340-wide first Linear (h_i part incl. bias) in the form the kernels consume them -- each block centred
+ *      over its 128 hidden units and multiplied by the sign of the MLP's LayerNorm weight (the LayerNorm is folded into the two
+ *      Linears at pack time) --, d_q [N,128] = MLP_q(h). */
 int td_debug_node_stage(const td_model *m, int32_t layer, int32_t stage, const float *d_h, int64_t N, float *d_P,
                         float *d_q, void *stream);
 

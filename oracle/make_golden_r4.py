@@ -10,6 +10,8 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
   sample_noise_6.npz         6 reverse steps with model_mean_type = 'noise' (:663-666);
   forward_blocks2.npz / sample_blocks2_4.npz   num_blocks = 2 (models/uni_transformer.py:306-323: the nine layers applied twice, graph and
       edge gate rebuilt from the moved coordinates in between): forward on the small batch, 4 reverse steps.
+  forward_ln_signs.npz       the default architecture with LayerNorm weights of every sign (oracle.weights.ln_signs_state_dict: negative,
+      zero and tiny entries in every MLP): forward (return_all) on the small batch.  Pins the LayerNorm fold of the packed edge MLPs.
 Weights: oracle.weights.time_emb_state_dict / make_state_dict (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
 
@@ -58,6 +60,23 @@ def gen_forward_time(ref, mode):
     print(f'forward_time_{mode}: |pred_v| max', float(p['pred_ligand_v'].abs().max()))
 
 
+def gen_forward_ln_signs(ref):
+    model = ref.ScorePosNet3D(shims.EasyDict(dict(weights.DEFAULT_MODEL_CONFIG)), weights.PROTEIN_FEATURE_DIM, weights.LIGAND_FEATURE_DIM)
+    res = model.load_state_dict(weights.ln_signs_state_dict(SEED), strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    model.eval()
+    b, lpos, lv = small_batch()
+    ppos, lposc, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    with torch.no_grad():
+        p = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch, return_all=True)
+    _save(os.path.join(GOLDEN_DIR, 'forward_ln_signs.npz'), protein_pos=ppos.numpy(), ligand_pos=lposc.numpy(), ligand_v=lv.numpy(),
+          pred_ligand_pos=p['pred_ligand_pos'].numpy(), pred_ligand_v=p['pred_ligand_v'].numpy(),
+          final_ligand_h=p['final_ligand_h'].numpy(), final_h=p['final_h'].numpy(),
+          layer0_pred_ligand_v=p['layer_pred_ligand_v'][0].numpy(), layer0_pred_ligand_pos=p['layer_pred_ligand_pos'][0].numpy())
+    print('forward_ln_signs: |pred_v| max', float(p['pred_ligand_v'].abs().max()), '|dx| max',
+          float((p['pred_ligand_pos'] - lposc).abs().max()))
+
+
 def gen_forward_blocks(ref):
     model = build(ref, num_blocks=2)
     b, lpos, lv = small_batch()
@@ -102,6 +121,7 @@ def main():
     gen_sample(ref, 'sample_time_simple_6.npz', 4300, time_emb_dim=TIME_EMB_DIM, time_emb_mode='simple')
     gen_sample(ref, 'sample_noise_6.npz', 4400, model_mean_type='noise')
     gen_forward_blocks(ref)
+    gen_forward_ln_signs(ref)
     global STEPS
     STEPS = 4
     gen_sample(ref, 'sample_blocks2_4.npz', 4500, num_blocks=2)

@@ -163,3 +163,19 @@ def time_emb_state_dict(seed: int, ligand_dim=LIGAND_FEATURE_DIM):
     col = (torch.rand((w.shape[0], 1), generator=g, dtype=torch.float32) * 2 - 1) / ((ligand_dim + 1) ** 0.5)
     sd['ligand_atom_emb.weight'] = torch.cat([w, col], dim=1)
     return sd
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm weights of every sign (round 4)
+def ln_signs_state_dict(seed: int):
+    """make_state_dict(seed) with the LayerNorm weights of every MLP made adversarial for a fold of the LayerNorm into the neighbouring
+    Linears (the product packs the edge MLPs that way, csrc/api.cpp FoldedMlp): every 7th unit negative, units 5 (mod 31) exactly zero,
+    units 3 (mod 29) tiny (1e-3 of their value).  The seeded weights are 1 +- 0.2, i.e. all positive."""
+    sd = make_state_dict(seed)
+    for key, w in sd.items():
+        if key.endswith('.net.1.weight'):
+            n = torch.arange(w.numel())
+            w = torch.where(n % 7 == 0, -w, w)
+            w = torch.where(n % 29 == 3, w * 1e-3, w)
+            w = torch.where(n % 31 == 5, torch.zeros_like(w), w)
+            sd[key] = w.contiguous()
+    return sd

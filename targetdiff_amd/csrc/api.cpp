@@ -1,5 +1,6 @@
 // C ABI of libtargetdiff_hip.so: weight re-packing, workspace carving and the per-step launch sequence.
 // See include/targetdiff_hip.h for the contract of every entry point and the reference seam it replaces.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +108,43 @@ struct Cursor {
         m.w3 = take((size_t)out * hid); m.b3 = take(out);
         return m;
     }
+};
+
+// The LayerNorm of an edge MLP (Linear -> LayerNorm -> ReLU -> Linear, models/common.py:60-80) folded into its two Linears at pack
+// time.  With c = pre-activation minus its mean over the hidden units, sigma = sqrt(var + eps), s_n = sign(gamma_n), a_n = |gamma_n|:
+//     relu(gamma_n c_n / sigma + beta_n) = (a_n / sigma) relu(s_n c_n + (beta_n / a_n) sigma)
+//  * every column of the first Linear (and its bias) is centred over the hidden units and row n multiplied by s_n: the matrix product
+//    IS s_n c_n -- the radial/type table, the node-side projections P_i / P_j and the bias all come from these rows, so the kernels
+//    compute neither a mean nor a subtraction;
+//  * beta_n / a_n replaces beta, a_n goes into column n of the second Linear, and 1 / sigma (one number per edge) multiplies the
+//    second layer's per-edge result in the consumer (logit, xv, or the attention weight of the aggregation).
+// Exact algebra; per hidden value the kernels are left with one FMA for the variance, one FMA and one max.  (gamma_n = 0 is carried
+// as a_n = 1e-20: the unit's constant relu(beta_n) survives, nothing overflows for |beta sigma| < 1e18.)
+struct FoldedMlp {
+    std::vector<float> w0, b0, g, b, w3;
+    const float *b3;
+    FoldedMlp(const MlpSrc &m, int in, int hid, int out) : w0((size_t)hid * in), b0(hid), g(hid), b(hid), w3((size_t)out * hid), b3(m.b3) {
+        std::vector<float> sg(hid);
+        for (int n = 0; n < hid; ++n) {
+            const float a = fabsf(m.g[n]) > 1e-20f ? fabsf(m.g[n]) : 1e-20f;
+            sg[n] = m.g[n] < 0.f ? -1.f : 1.f;
+            g[n] = a;
+            b[n] = m.b[n] / a;
+        }
+        for (int k = 0; k < in; ++k) {
+            double mean = 0.0;
+            for (int n = 0; n < hid; ++n) mean += (double)m.w0[(size_t)n * in + k];
+            mean /= hid;
+            for (int n = 0; n < hid; ++n) w0[(size_t)n * in + k] = (float)((double)sg[n] * ((double)m.w0[(size_t)n * in + k] - mean));
+        }
+        double mb = 0.0;
+        for (int n = 0; n < hid; ++n) mb += (double)m.b0[n];
+        mb /= hid;
+        for (int n = 0; n < hid; ++n) b0[n] = (float)((double)sg[n] * ((double)m.b0[n] - mb));
+        for (int o = 0; o < out; ++o)
+            for (int n = 0; n < hid; ++n) w3[(size_t)o * hid + n] = m.w3[(size_t)o * hid + n] * g[n];
+    }
+    MlpSrc src() const { return MlpSrc{w0.data(), b0.data(), g.data(), b.data(), w3.data(), b3}; }
 };
 
 size_t mlp_floats(int in, int hid, int out) { return (size_t)hid * in + 3 * (size_t)hid + (size_t)out * hid + out; }
@@ -467,6 +505,9 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         MlpSrc hk = cur.mlp(KV, H, H), hv = cur.mlp(KV, H, H), hq = cur.mlp(H, H, H);
         MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
         if (!cur.ok) break;
+        // the four edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
+        const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H), fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
+        hk = fhk.src(); hv = fhv.src(); xk = fxk.src(); xv = fxv.src();
         lo[l].off = pack_vec(pk, off, TD_NG);
         lo[l].coeff = gaussian_coeff(off);
         lo[l].nx = pack_node_stage(pk, hk, hv, hq, KV);

@@ -144,12 +144,15 @@ __device__ __forceinline__ void td_sum16x4(float (&v)[4]) {
 // softmax over the 32 edges of a row for the four heads 4g + r of the lane group (lg[eb][r] = logit of edge 16eb + lo), times the edge
 // gate: p[eb][r] = exp(x - max) / sum * ew[eb].  A pad's logit is -inf, so its weight is exp(-inf) = 0 without a select; a row without
 // edges gets zeros.  1 / sum is v_rcp_f32 (1 ulp; the correctly rounded __frcp_rn is an 11-instruction sequence per head).
-__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], floatx4_t (&p)[2]) {
+// rstd[eb]: 1 / sigma of the edge's LayerNorm, which td_ln_relu16 leaves to the consumer of the second layer (the logit is linear in z).
+__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], const float (&rstd)[2],
+                                               floatx4_t (&p)[2]) {
     float x0[4], x1[4], mx[4], sm[4];
+    const float sc0 = rstd[0] * TD_ATT_SCALE_16, sc1 = rstd[1] * TD_ATT_SCALE_16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        x0[r] = valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-        x1[r] = valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+        x0[r] = valid[0] ? lg[0][r] * sc0 : -INFINITY;
+        x1[r] = valid[1] ? lg[1][r] * sc1 : -INFINITY;
         mx[r] = fmaxf(x0[r], x1[r]);
     }
     td_max16x4(mx);
@@ -174,6 +177,7 @@ struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
     bool valid[2];
     bool any[2];       // wave-uniform: does the 16-edge block hold any edge at all (false: all pads, e.g. slots 48 .. 63 at k = 48)
     float ew[2];
+    float rstd[2];     // 1 / sigma of the edge's LayerNorm: multiplies the second layer's per-edge result (td_ln_relu16)
     float rel[2][3];   // x_i - x_j
     float4 xi;
 };
@@ -217,19 +221,59 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
     for (int hb = 0; hb < 8; ++hb) r.pit[hb] = a.P[(size_t)i * (4 * TD_H) + a.p_off + 16 * hb + lo];
 }
 
-// LayerNorm over the 128 hidden units of each edge + ReLU, in the transposed accumulator layout (a lane owns 32 of an edge's
-// 128 hidden units for each of its two edges; the other 96 sit in the lanes lo + 16 g')
+// LayerNorm + ReLU of an edge MLP in the transposed accumulator layout (a lane owns 32 of an edge's 128 hidden units for each of its
+// two edges; the other 96 sit in the lanes lo + 16 g'), in the folded form the weights are packed for (FoldedMlp, api.cpp): the
+// accumulators hold the CENTRED pre-activation with the sign of gamma applied, KB[n] = beta_n / |gamma_n|, and
+//     z'_n = relu(acc_n + sigma KB[n]),   sigma = sqrt(mean_n acc_n^2 + eps)
+// is the normalised activation times sigma / |gamma_n|: |gamma_n| sits in the second Linear's columns, rstd = 1 / sigma is returned for
+// the consumer to apply to the second layer's per-edge result.  Per hidden value: one FMA (variance), one FMA, one max.
 // SKIP_EMPTY: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 instead of the LayerNorm of its padding
 template <bool SKIP_EMPTY = false>
-__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ GAM, const float *__restrict__ BET, int g,
-                                             floatx4_t (&acc)[2][8], const bool (&any)[2] = {true, true}) {
+__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2],
+                                             const bool (&any)[2] = {true, true}) {
+    float s2[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
-        if (SKIP_EMPTY && !any[eb]) {
+        float sa = 0.f, sb = 0.f;
+        if (SKIP_EMPTY && !any[eb]) { s2[eb] = 0.f; continue; }
 #pragma unroll
-            for (int hb = 0; hb < 8; ++hb) acc[eb][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-            continue;
+        for (int hb = 0; hb < 8; ++hb) {
+            sa = fmaf(acc[eb][hb][0], acc[eb][hb][0], sa); sb = fmaf(acc[eb][hb][1], acc[eb][hb][1], sb);
+            sa = fmaf(acc[eb][hb][2], acc[eb][hb][2], sa); sb = fmaf(acc[eb][hb][3], acc[eb][hb][3], sb);
         }
+        s2[eb] = sa + sb;
+    }
+    float sig[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        const float var = td_sum_groups(s2[eb]) * (1.0f / TD_H) + 1e-5f;
+        rstd[eb] = __frsqrt_rn(var);
+        sig[eb] = var * rstd[eb];
+    }
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) {
+        const float4 kb = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            if (SKIP_EMPTY && !any[eb]) { acc[eb][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; continue; }
+            acc[eb][hb][0] = fmaxf(fmaf(sig[eb], kb.x, acc[eb][hb][0]), 0.f);
+            acc[eb][hb][1] = fmaxf(fmaf(sig[eb], kb.y, acc[eb][hb][1]), 0.f);
+            acc[eb][hb][2] = fmaxf(fmaf(sig[eb], kb.z, acc[eb][hb][2]), 0.f);
+            acc[eb][hb][3] = fmaxf(fmaf(sig[eb], kb.w, acc[eb][hb][3]), 0.f);
+        }
+    }
+    if (SKIP_EMPTY) {
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+            if (!any[eb]) rstd[eb] = 0.f;
+    }
+}
+
+// the plain form (mean, variance, affine) for the edge gate's MLP, whose weights are packed as they are
+__device__ __forceinline__ void td_ln_affine_relu16(const float *__restrict__ GAM, const float *__restrict__ BET, int g,
+                                                    floatx4_t (&acc)[2][8]) {
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
         float s1 = 0.f;
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
@@ -315,7 +359,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    td_ln_relu16<SKIP_EMPTY>(GAM, BET, g, acc, ed.any);
+    td_ln_relu16<SKIP_EMPTY>(BET, g, acc, ed.rstd, ed.any);
 }
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
@@ -449,7 +493,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         products(sl, m);
     }
     if (PI_LATE) add_pi();
-    td_ln_relu16<SKIP_EMPTY>(GAM, BET, g, acc, ed.any);
+    td_ln_relu16<SKIP_EMPTY>(BET, g, acc, ed.rstd, ed.any);
 }
 
 template <bool LOAD_EW, bool SKIP_EMPTY = false>
@@ -599,7 +643,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                     const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
 #pragma unroll
                     for (int eb = 0; eb < 2; ++eb) {
-                        const float wgt = ed.valid[eb] ? ap[16 * eb] * (xv[eb][r] + bias) : 0.f;
+                        const float wgt = ed.valid[eb] ? ap[16 * eb] * fmaf(xv[eb][r], ed.rstd[eb], bias) : 0.f;
                         sx = fmaf(wgt, ed.rel[eb][0], sx);
                         sy = fmaf(wgt, ed.rel[eb][1], sy);
                         sz = fmaf(wgt, ed.rel[eb][2], sz);
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             }
             // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate ---------------------
             floatx4_t pr[2];
-            td_softmax16x4(lg, ed.valid, ed.ew, pr);
+            td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, pr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
@@ -669,10 +713,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             first_layer(i, c, acc, ed);
             logits(acc, lg, ed);
             float x0[4], x1[4], mn[4], ps[4];
+            const float sc0 = ed.rstd[0] * TD_ATT_SCALE_16, sc1 = ed.rstd[1] * TD_ATT_SCALE_16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                x0[r] = ed.valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-                x1[r] = ed.valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+                x0[r] = ed.valid[0] ? lg[0][r] * sc0 : -INFINITY;
+                x1[r] = ed.valid[1] ? lg[1][r] * sc1 : -INFINITY;
                 float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
                 dst[0] = x0[r];
                 dst[16] = x1[r];
@@ -825,7 +870,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
             }
         }
         floatx4_t al[2];
-        td_softmax16x4(lg, ed.valid, ed.ew, al);
+        td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
         if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), GAMv, BETv, offk, rv, i, lane, accv, ev);
@@ -851,7 +896,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
             const float bias = __shfl(b2, 4 * g + r);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) {
-                const float wgt = ev.valid[eb] ? al[eb][r] * (xv[eb][r] + bias) : 0.f;
+                const float wgt = ev.valid[eb] ? al[eb][r] * fmaf(xv[eb][r], ev.rstd[eb], bias) : 0.f;
                 sx = fmaf(wgt, ev.rel[eb][0], sx);
                 sy = fmaf(wgt, ev.rel[eb][1], sy);
                 sz = fmaf(wgt, ev.rel[eb][2], sz);
@@ -880,10 +925,11 @@ constexpr int V16_ZB_STRIDE = 132;
 constexpr int V16_TILE_FLOATS = 32 * V16_TB_STRIDE + 4 * 16;
 __device__ __forceinline__ int td_tile_row16(int e) { return e * V16_TB_STRIDE + (e >> 3) * 16; }
 constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // 1408 >= 8 * 132: two transpose tiles, later the Zbar half
+constexpr int V16_SB_FLOATS = 48;                         // per wave: S[16 heads] + the 32 edges' 1 / sigma (td_ln_relu16) on their way to the A operand
 constexpr size_t V16_LDS_BYTES =
-    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4) * sizeof(float);
+    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 3 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
-    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16 + 3 * TD_H + 4 + 32) * sizeof(float);
+    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 3 * TD_H + 4 + 32) * sizeof(float);
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
 // (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
@@ -910,8 +956,15 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     float *TB = lds + RF + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
-    float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * 16;
-    float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * 16;
+    float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * V16_SB_FLOATS, *RS = SB + 16;
+    float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS;
+    // the attention weights of the aggregation product (A operand: edge 8g + s, head lo) times the edges' 1 / sigma, which the first
+    // layer leaves in the lanes of the z^T layout (edge 16eb + lo): 32 floats through the wave's own LDS
+    auto scale_alpha = [&](float (&alx)[8], const Edge2 &ed) {
+        if (g < 2) RS[16 * g + lo] = g == 0 ? ed.rstd[0] : ed.rstd[1];
+        const float4 r0 = *reinterpret_cast<const float4 *>(RS + 8 * g), r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
+        alx[0] *= r0.x; alx[1] *= r0.y; alx[2] *= r0.z; alx[3] *= r0.w; alx[4] *= r1.x; alx[5] *= r1.y; alx[6] *= r1.z; alx[7] *= r1.w;
+    };
     const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
     // SPLIT: workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0)
     int my_cls = 1, GL = 0;
@@ -1073,6 +1126,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 else
                     td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rcur, lane, acc, ed);
                 asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
+                scale_alpha(al, ed);
                 auto flip_store = [&](int hb) {
                     float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
@@ -1179,6 +1233,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
         if (lane < TD_HEADS) SB[lane] = ssum;
+        scale_alpha(al, ed);
 
         // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time: flip z^T (lane = edge) through
         //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
@@ -1338,7 +1393,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
         }
-        td_ln_relu16(GAM, BET, g, acc);
+        td_ln_affine_relu16(GAM, BET, g, acc);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
             float part = 0.f;

@@ -129,3 +129,33 @@ def test_two_blocks_vs_reference():
                                b.ligand_element_batch, num_steps=3, center_pos_mode='protein',
                                noise_source=draws.Source(4600, dev), use_session=us) for us in (True, False)]
     assert torch.equal(torch.stack(rs[0]['pos_traj']), torch.stack(rs[1]['pos_traj']))
+
+
+def test_layernorm_weights_of_every_sign_vs_reference():
+    """The edge MLPs' LayerNorm is folded into their Linears at pack time (csrc/api.cpp FoldedMlp: centred first Linear, the sign of the
+    LayerNorm weight in its rows, |weight| in the second Linear's columns, 1 / sigma applied by the consumer).  The seeded weights are all
+    positive; this fixture of the real reference (oracle/make_golden_r4.py) has negative, zero and tiny LayerNorm weights in every MLP.
+    Both first-layer variants (bf16 piece triples, fp32), the stateless forward and a session's."""
+    from oracle import weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    g = load_golden('forward_ln_signs.npz')
+    sd = weights.ln_signs_state_dict(SEED)
+    lnw = sd['refine_net.base_block.0.x2h_layers.0.hk_func.net.1.weight']
+    assert (lnw < 0).sum() >= 15 and (lnw == 0).sum() >= 4 and ((lnw.abs() < 5e-3) & (lnw != 0)).sum() >= 3
+    b = small_batch()[0].to(dev)
+    args = (torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+            torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch)
+    for split in (1, 0):
+        model = _model(sd)
+        nat = model._native(dev)
+        nat.set_option('edge_key_split', split)
+        p = model(*args, return_all=True)
+        d = {k: _maxdiff(p[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h', 'final_h')}
+        print('edge_key_split', split, d)
+        assert d['pred_ligand_pos'] <= TOL_X and d['pred_ligand_v'] <= TOL_H and d['final_ligand_h'] <= TOL_H and d['final_h'] <= TOL_H
+        assert _maxdiff(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v']) <= TOL_H
+        assert _maxdiff(p['layer_pred_ligand_pos'][0], g['layer0_pred_ligand_pos']) <= TOL_X
+    # the all-positive weights give something else
+    one = _model(weights.make_state_dict(SEED))(*args)
+    assert _maxdiff(one['pred_ligand_v'], g['pred_ligand_v']) > 1e-3

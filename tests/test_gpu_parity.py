@@ -137,8 +137,12 @@ def test_node_stage_projections(model, state_dict):
             for nm in names[:2]:
                 w0 = state_dict[pre + nm + '.net.0.weight'].double()
                 b0 = state_dict[pre + nm + '.net.0.bias'].double()
-                want.append(hd @ w0[:, 84:212].T + b0)
-                want.append(hd @ w0[:, 212:340].T)
+                # the projections come out in the folded form the edge MLPs' LayerNorm is packed for (FoldedMlp, csrc/api.cpp):
+                # centred over the hidden units, times the sign of the LayerNorm weight
+                sg = torch.where(state_dict[pre + nm + '.net.1.weight'].double() < 0, -1.0, 1.0)
+                fold = lambda p: sg * (p - p.mean(dim=1, keepdim=True))
+                want.append(fold(hd @ w0[:, 84:212].T + b0))
+                want.append(fold(hd @ w0[:, 212:340].T))
             want = torch.cat(want, dim=1)
             assert _maxdiff(P, want) < 5e-5, (N, layer, stage)
             from oracle import restatement as R

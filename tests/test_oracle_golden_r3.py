@@ -99,3 +99,20 @@ def test_restatement_other_weight_sets_vs_reference(seed, gain):
                             torch.from_numpy(g['ligand_pos']), lv, b.ligand_element_batch)
     assert np.max(np.abs(preds['pred_ligand_pos'].numpy() - g['pred_ligand_pos'])) < 2e-5
     assert np.max(np.abs(preds['final_h'].numpy() - g['final_h'])) < 2e-4
+
+
+def test_restatement_layernorm_weights_of_every_sign_vs_reference(golden_small):
+    """oracle/make_golden_r4.py forward_ln_signs: LayerNorm weights with negative, zero and tiny entries in every MLP (the all-positive seeded
+    weights never exercise the sign handling of the product's LayerNorm fold)."""
+    from conftest import load_golden, small_inputs
+    from oracle import weights
+    from oracle.make_golden import SEED
+    g = load_golden('forward_ln_signs.npz')
+    inp = small_inputs(golden_small)
+    np.testing.assert_array_equal(inp['ligand_pos'].numpy(), g['ligand_pos'])
+    out = R.model_forward(weights.ln_signs_state_dict(SEED), None, inp['protein_pos'], inp['protein_v'], inp['batch_protein'],
+                          inp['ligand_pos'], inp['ligand_v'], inp['batch_ligand'])
+    md = lambda a, b: float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+    assert md(out['pred_ligand_pos'], g['pred_ligand_pos']) < 2e-5
+    assert md(out['pred_ligand_v'], g['pred_ligand_v']) < 2e-5
+    assert md(out['final_h'], g['final_h']) < 2e-5
