@@ -670,9 +670,11 @@ struct GraphTab {
 };
 GraphTab default_tab(Workspace &w) { return GraphTab{nullptr, w.nbr, w.ew, w.alpha, 1, 0, nullptr}; }
 
+// lig / Nl (x2h passes): the ligand rows of the batch, all of them among `rows`
 int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const float *ew, const int32_t *nbr,
-             const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s) {
-    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s, gt.cptr);
+             const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s,
+             const int32_t *lig = nullptr, int64_t Nl = 0) {
+    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s, gt.cptr, lig, Nl, gt.cpn_p);
 }
 // lig / Nl: the ligand rows of the batch (all of them are among `rows`: every row list of a step contains the ligand atoms)
 int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const int32_t *nbr, const float *P,
@@ -749,7 +751,7 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
             proj_done = false;
-            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, gt, gt.ew, gt.nbr, w.P, w.q, rws, cnt, N, gt.alpha, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, gt, gt.ew, gt.nbr, w.P, w.q, rws, cnt, N, gt.alpha, s, w.lig_node, Nl)) != TD_OK) return rc; }
             { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, gt, gt.nbr, w.P, rws, cnt, N, h, gt.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
             if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
@@ -1754,7 +1756,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     const TdLayer &L0 = m->layers[0];
     {   // layer 0, x2h: only ligand rows need new projections, only dirty rows need the attention passes
         { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L0.nodeX2h, w.h, Nl, w.lig_node, 0x1f, S->P0, S->q0, s)) != TD_OK) return rc; }
-        { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, gt, gt.ew, gt.nbr, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, gt.alpha, s)) != TD_OK) return rc; }
+        { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L0.hk, L0, w.x4a, gt, gt.ew, gt.nbr, S->P0, S->q0, S->dirty_rows, S->dirty_count, N, gt.alpha, s, w.lig_node, Nl)) != TD_OK) return rc; }
         { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L0.hv, L0, w.x4a, gt, gt.nbr, S->P0, S->dirty_rows, S->dirty_count, N, w.h, gt.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
     }
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)

@@ -12,6 +12,8 @@
 // so one lane owns, for each of its two edges, 32 of the 128 hidden units; the other 96 sit in lanes lo + 16 g'.
 // LayerNorm = in-lane sums + two lane-group exchanges.  The normalised z^T is directly the B operand of the
 // logits product (k-step (hb, r) pairs lane group g with hidden unit 16hb + 4g + r on both operands).
+#include <type_traits>
+
 #include "td_device.h"
 #include "td_internal.h"
 
@@ -228,14 +230,13 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
 // is the normalised activation times sigma / |gamma_n|: |gamma_n| sits in the second Linear's columns, rstd = 1 / sigma is returned for
 // the consumer to apply to the second layer's per-edge result.  Per hidden value: one FMA (variance), one FMA, one max.
 // SKIP_EMPTY: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 instead of the LayerNorm of its padding
-template <bool SKIP_EMPTY = false>
-__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2],
-                                             const bool (&any)[2] = {true, true}) {
-    float s2[2];
+// NEB = 1: only the first edge block is live (the caller has zeroed the second one)
+template <int NEB = 2>
+__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2]) {
+    float s2[NEB];
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
+    for (int eb = 0; eb < NEB; ++eb) {
         float sa = 0.f, sb = 0.f;
-        if (SKIP_EMPTY && !any[eb]) { s2[eb] = 0.f; continue; }
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) {
             sa = fmaf(acc[eb][hb][0], acc[eb][hb][0], sa); sb = fmaf(acc[eb][hb][1], acc[eb][hb][1], sb);
@@ -243,9 +244,9 @@ __device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g
         }
         s2[eb] = sa + sb;
     }
-    float sig[2];
+    float sig[NEB];
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
+    for (int eb = 0; eb < NEB; ++eb) {
         const float var = td_sum_groups(s2[eb]) * (1.0f / TD_H) + 1e-5f;
         rstd[eb] = __frsqrt_rn(var);
         sig[eb] = var * rstd[eb];
@@ -254,18 +255,25 @@ __device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g
     for (int hb = 0; hb < 8; ++hb) {
         const float4 kb = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb) {
-            if (SKIP_EMPTY && !any[eb]) { acc[eb][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; continue; }
+        for (int eb = 0; eb < NEB; ++eb) {
             acc[eb][hb][0] = fmaxf(fmaf(sig[eb], kb.x, acc[eb][hb][0]), 0.f);
             acc[eb][hb][1] = fmaxf(fmaf(sig[eb], kb.y, acc[eb][hb][1]), 0.f);
             acc[eb][hb][2] = fmaxf(fmaf(sig[eb], kb.z, acc[eb][hb][2]), 0.f);
             acc[eb][hb][3] = fmaxf(fmaf(sig[eb], kb.w, acc[eb][hb][3]), 0.f);
         }
     }
-    if (SKIP_EMPTY) {
+}
+// fp32 first layer on general graphs: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 and 1 / sigma = 0 instead of the
+// LayerNorm of its padding
+__device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2],
+                                                  const bool (&any)[2]) {
+    if (any[1]) {
+        td_ln_relu16<2>(KB, g, acc, rstd);
+    } else {
+        td_ln_relu16<1>(KB, g, acc, rstd);
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb)
-            if (!any[eb]) rstd[eb] = 0.f;
+        for (int hb = 0; hb < 8; ++hb) acc[1][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+        rstd[1] = 0.f;
     }
 }
 
@@ -359,7 +367,8 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    td_ln_relu16<SKIP_EMPTY>(BET, g, acc, ed.rstd, ed.any);
+    if (SKIP_EMPTY) td_ln_relu16_skip(BET, g, acc, ed.rstd, ed.any);
+    else td_ln_relu16<2>(BET, g, acc, ed.rstd);
 }
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
@@ -398,7 +407,11 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // before_products: called once the gathered operands have been consumed (Gaussians computed, P_i added) and before the matrix products
 // are issued -- the place to start loads whose data is needed after the first layer (the key pass's query): the live set is at its
 // lowest there and the products give them ~ 1.5 k cycles of cover.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, bool SKIP_EMPTY = false, class Hook = TdNoHook>
+// NEB = 1 (general graphs): the chunk's second 16-edge block is all padding (blocks fill from slot 0; e.g. slots 48 .. 63 of a row at
+// k = 48; the caller tests it, wave-uniform) and costs nothing: no P_i adds, no Gaussians, no products, z = 0 and 1 / sigma = 0.
+// LN_SKIP (NEB = 2 only): the LayerNorm leaves out a second block without edges (z = 0, 1 / sigma = 0) -- what the chunk-walking key pass, which
+// has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ GAM, const float *__restrict__ BET,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
@@ -419,14 +432,21 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb)
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) {
+            for (int eb = 0; eb < NEB; ++eb) {
                 acc[eb][hb][0] += pi[hb].x; acc[eb][hb][1] += pi[hb].y; acc[eb][hb][2] += pi[hb].z; acc[eb][hb][3] += pi[hb].w;
             }
     };
     if (!PI_LATE) add_pi();
-    int slot[2];
-    bool has[2][2];
-    float gv[2][8];
+    int slot[NEB];
+    bool has[2][NEB];
+    float gv[NEB][8];
+    if (NEB == 1) {
+        ed.valid[1] = false; ed.any[1] = false; ed.rstd[1] = 0.f;
+        ed.rel[1][0] = ed.rel[1][1] = ed.rel[1][2] = 0.f;
+        if (LOAD_EW) ed.ew[1] = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) acc[1][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    }
     // g_k(d) = exp(coeff (d - mu_k)^2) = exp2(c2 (d - mu_k)^2): four instructions per entry (the compiler cannot fold the two scale
     // factors of __expf(coeff * u * u) itself).  offj holds TD_FAR_CENTRE behind the 20 Gaussians, so the unused K slots come out as
     // exp2(-huge) = 0 without a select; slot k = 20 (lane group 2, j = 4) is the edge-type column, constant 1.  A pad (neighbour
@@ -434,7 +454,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     // aggregations (alpha = 0, `valid` selects) never let through.
     const float c2 = a.coeff * TD_LOG2E;
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
+    for (int eb = 0; eb < NEB; ++eb) {
         ed.valid[eb] = r.j[eb] >= 0;
         const float4 xj = r.xj[eb];
         if (LOAD_EW) ed.ew[eb] = r.ew[eb];
@@ -453,15 +473,19 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         if (g == 2) gv[eb][4] = 1.f;
     }
     before_products();
-    // products of source class sl with the edge inputs m (B operand: the edge inputs in 3 pieces)
-    auto products = [&](int sl, const float (&m)[2][8]) {
-        uint4 bm[2][3];
+    // products of source class sl with the edge inputs (B operand: the edge inputs in 3 pieces, zeros for the edges of the other class)
+    auto products = [&](int sl) {
+        uint4 bm[NEB][3];
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb) {
-            td_split_pair(m[eb][0], m[eb][1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
-            td_split_pair(m[eb][2], m[eb][3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
-            td_split_pair(m[eb][4], m[eb][5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
-            td_split_pair(m[eb][6], m[eb][7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
+        for (int eb = 0; eb < NEB; ++eb) {
+            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = keep ? gv[eb][j] : 0.f;
+            td_split_pair(m[0], m[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
+            td_split_pair(m[2], m[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
+            td_split_pair(m[4], m[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
+            td_split_pair(m[6], m[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
         }
         const uint4 *Rs = Rp + (size_t)(((ONE_CLASS ? 0 : cls * 2) + sl) * 3) * 8 * 48 + l48;
 #pragma unroll
@@ -474,7 +498,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             // lane group 3 (k = 24 .. 31) re-reads group 2's entries: its B slots are all zero, so they contribute nothing
             // low-order products first; two hidden blocks x two edge blocks interleave four accumulator chains
 #define TD_PROD(pa, pb)                                                                                  \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < 2; ++eb)      \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < NEB; ++eb)    \
         acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][pa], bm[eb][pb], acc[eb][2 * hp + h2]);
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
@@ -482,18 +506,13 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     };
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
-        if (!(has[sl][0] || has[sl][1])) continue;
-        float m[2][8];
-#pragma unroll
-        for (int eb = 0; eb < 2; ++eb) {
-            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[eb][j] = keep ? gv[eb][j] : 0.f;
-        }
-        products(sl, m);
+        bool any_sl = has[sl][0];
+        if (NEB == 2) any_sl = any_sl || has[sl][NEB - 1];
+        if (any_sl) products(sl);
     }
     if (PI_LATE) add_pi();
-    td_ln_relu16<SKIP_EMPTY>(BET, g, acc, ed.rstd, ed.any);
+    if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(BET, g, acc, ed.rstd, ed.any);
+    else td_ln_relu16<NEB>(BET, g, acc, ed.rstd);
 }
 
 template <bool LOAD_EW, bool SKIP_EMPTY = false>
@@ -520,15 +539,19 @@ constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_
 //             A operand (no U_i build); delta_x_i = mean_heads sum_e alpha[e, head] xv[e, head] (x_i - x_j)
 //             (models/uni_transformer.py:121-140), masked update of the ligand row (:205-206).
 // STAGE only tags the instantiation (0 = x2h, 1 = h2x) so that profilers report the two stages separately.
-// CHUNKED = true (general graphs): the in-edges of dst node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha (32
+// GRAPH = 2 (`hybrid` graphs, x2h): the protein rows of the list -- one chunk each, index cptr[i] -- at the speed of the default graph; the
+//             ligand rows (several chunks) are skipped here and walked by a GRAPH = 1 launch over the ligand row list.
+// GRAPH = 1 = CHUNKED (general graphs): the in-edges of dst node i are the chunks cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha (32
 //             slots each, -1 padded).  One wave still owns one dst node and walks its chunks.  Key pass: the softmax runs
 //             over ALL slots of the node (scatter_softmax over an arbitrary segment, models/uni_transformer.py:73,135) --
 //             one chunk: in registers as on the default graph; several: the scaled logits go to alpha[c] with a running
 //             (max, sum) per head, then every lane re-reads its own entries and writes exp(x - max) / sum * gate.
 //             XV: delta_x accumulates over the chunks (scatter_sum, :139).
 // SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
-template <bool XV, int WAVES, int STAGE, bool CHUNKED = false, bool SPLIT = false>
+template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
+    constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
+    constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
     constexpr int RF = SPLIT ? E16P_U4 * 4 : E16_R_FLOATS;       // floats of the radial/type table
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -602,7 +625,12 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                     qpre1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
                 }
             };
-            td_first_layer_split16<EW, false, false, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
+            // a chunk whose second block is all padding (wave-uniform): the xv pass (8 waves, 256 registers) has room for a path without
+            // it; the key pass at 168 registers does not (126 spilled registers) and only leaves the block out of its LayerNorm and logits
+            if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
+                td_first_layer_split16<EW, false, false, 1>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
+            else
+                td_first_layer_split16<EW, false, false, 2, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
     };
@@ -614,6 +642,10 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         if (CHUNKED) {
             c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]);
             nch = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]) - (int)c0;
+        }
+        if (VIA) {
+            if (__builtin_amdgcn_readfirstlane(__float_as_int(a.x4[i].w)) > __float_as_int(0.5f)) continue;
+            c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]);
         }
 
         if (XV) {
@@ -1115,43 +1147,69 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     rin.j[0] = a.nbr[(int64_t)cn * TD_K + lo];
                     rin.j[1] = a.nbr[(int64_t)cn * TD_K + 16 + lo];
                 }
-                float al[8];
-                {   // A operand of the aggregation product: alpha[edge 8g + s][head lo] of this chunk
-                    const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
-                    const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
-                    al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
-                }
-                if constexpr (SPLIT)
-                    td_first_layer_split16<false, true, false, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rcur, i, lane, acc, ed);
-                else
-                    td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rcur, lane, acc, ed);
-                asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
-                scale_alpha(al, ed);
-                auto flip_store = [&](int hb) {
-                    float *t = TB + (hb & 1) * V16_TILE_FLOATS;
-#pragma unroll
-                    for (int eb = 0; eb < 2; ++eb)
-                        *reinterpret_cast<float4 *>(t + td_tile_row16(16 * eb + lo) + 4 * g) =
-                            make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
-                };
-                auto flip_load = [&](int hb, float (&bv)[8]) {
-                    const float *t = TB + (hb & 1) * V16_TILE_FLOATS;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) bv[s] = t[td_tile_row16(8 * g + s) + lo];
-                };
-                float bvb[2][8];
-                flip_store(0);
-                flip_load(0, bvb[0]);
-#pragma unroll
-                for (int hb = 0; hb < 8; ++hb) {
-                    if (hb + 1 < 8) {
-                        flip_store(hb + 1);
-                        flip_load(hb + 1, bvb[(hb + 1) & 1]);       // read back a block ahead of its products (see the pipelined loop)
+                // The chunk's body in two versions (the choice is wave-uniform).  FULL: as in the pipelined loop below -- k-step s of the
+                // aggregation product carries edge 8g + s.  Half (the second 16-edge block is all padding, e.g. slots 48 .. 63 of a row at
+                // k = 48): first layer, flips and products of the first block only, k-step j = edge 4g + j.
+                auto chunk_body = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;
+                    constexpr int NS = FULL ? 8 : 4;
+                    float al[NS];
+                    {   // A operand of the aggregation product: alpha[edge][head lo] of this chunk
+                        const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + (FULL ? 8 : 4) * g;
+                        const float4 v0 = *reinterpret_cast<const float4 *>(ap);
+                        al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w;
+                        if constexpr (FULL) {
+                            const float4 v1 = *reinterpret_cast<const float4 *>(ap + 4);
+                            al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (SPLIT)
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rcur, i, lane, acc, ed);
+                    else
+                        td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rcur, lane, acc, ed);
+                    float part = (al[0] + al[1]) + (al[2] + al[3]);
+                    if constexpr (FULL) part += (al[4] + al[5]) + (al[6] + al[7]);
+                    asum += part;
+                    {   // times the edges' 1 / sigma (see scale_alpha)
+                        if (g < 2) RS[16 * g + lo] = g == 0 ? ed.rstd[0] : ed.rstd[1];
+                        const float4 r0 = *reinterpret_cast<const float4 *>(RS + (FULL ? 8 : 4) * g);
+                        al[0] *= r0.x; al[1] *= r0.y; al[2] *= r0.z; al[3] *= r0.w;
+                        if constexpr (FULL) {
+                            const float4 r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
+                            al[4] *= r1.x; al[5] *= r1.y; al[6] *= r1.z; al[7] *= r1.w;
+                        }
+                    }
+                    auto flip_store = [&](int hb) {
+                        float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bvb[hb & 1][s], zb[hb]);
-                }
+                        for (int eb = 0; eb < (FULL ? 2 : 1); ++eb)
+                            *reinterpret_cast<float4 *>(t + td_tile_row16(16 * eb + lo) + 4 * g) =
+                                make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+                    };
+                    // (half: rows 4g + j of the first block; groups 0 / 1 and 2 / 3 sit on different halves of the banks)
+                    auto flip_load = [&](int hb, float (&bv)[NS]) {
+                        const float *t = TB + (hb & 1) * V16_TILE_FLOATS;
+#pragma unroll
+                        for (int sx = 0; sx < NS; ++sx) bv[sx] = t[td_tile_row16((FULL ? 8 : 4) * g + sx) + lo];
+                    };
+                    float bvb[2][NS];
+                    flip_store(0);
+                    flip_load(0, bvb[0]);
+#pragma unroll
+                    for (int hb = 0; hb < 8; ++hb) {
+                        if (hb + 1 < 8) {          // read back a block ahead of its products (see the pipelined loop)
+                            flip_store(hb + 1);
+                            flip_load(hb + 1, bvb[(hb + 1) & 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int sx = 0; sx < NS; ++sx) zb[hb] = td_mfma16(al[sx], bvb[hb & 1][sx], zb[hb]);
+                    }
+                };
+                bool full = true;
+                if (SPLIT) full = __ballot(rcur.j[1] >= 0) != 0ull;        // (the fp32 first layer has no one-block path)
+                if (full) chunk_body(std::true_type());
+                else chunk_body(std::false_type());
             }
             const float ssum = td_sum_groups(asum);
             if (lane < TD_HEADS) SB[lane] = ssum;
@@ -1439,29 +1497,35 @@ static unsigned long long *wg_trace_slot(int pass) {
     return g_wg_trace + ((size_t)n * 3 + pass) * 256 * 8;
 }
 
-// cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node
+// cptr (general graphs): chunks of dst node i = cptr[i] .. cptr[i+1]-1 of nbr / ew / alpha; nullptr: one 32-slot row per node.
+// lig_rows / lig_count / cpn_p (x2h on general graphs): the ligand rows among `rows` (all of them) and the chunks per protein row.  With one
+// chunk per protein row (`hybrid`) the protein rows run as on the default graph and the ligand rows in a second, chunk-walking launch.
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                         float *alpha, hipStream_t s, const int32_t *cptr) {
+                         float *alpha, hipStream_t s, const int32_t *cptr, const int32_t *lig_rows, int64_t lig_count, int cpn_p) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     a.cptr = cptr;
-    const bool h2x = rows && !count_ptr;      // h2x key pass (ligand row list of known length): STAGE tag 1
+    const bool h2x = rows && !count_ptr && !lig_rows;      // h2x key pass (ligand row list of known length): STAGE tag 1
     if (!h2x) a.trace = wg_trace_slot(0);
     a.deal = h2x ? 0 : mlp.deal_rows;
 #define TD_KEY_LAUNCH(WAVES, STAGE, CH, SP, BYTES)                                                            \
     do {                                                                                                      \
         TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
-        edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
+        edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(a.count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
     } while (0)
     if (mlp.use_split) {                      // first layer on bf16 piece triples
-        if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, true, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, true, true, K16S_LDS_BYTES); }
-        else { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, false, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, false, true, K16S_LDS_BYTES); }
+        if (cptr && !h2x && cpn_p == 1 && lig_rows && lig_count > 0) {
+            TD_KEY_LAUNCH(K16S_WAVES, 0, 2, true, K16S_LDS_BYTES);
+            a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
+            TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
+        } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES); }
+        else { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 0, true, K16S_LDS_BYTES); }
     } else {
-        if (cptr) { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, true, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, true, false, K16_LDS_BYTES); }
-        else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, false, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, false, false, K16_LDS_BYTES); }
+        if (cptr) { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 1, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 1, false, K16_LDS_BYTES); }
+        else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 0, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 0, false, K16_LDS_BYTES); }
     }
 #undef TD_KEY_LAUNCH
     TD_CHECK_HIP(hipGetLastError());
@@ -1483,8 +1547,8 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
         TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, CH, SP>), BYTES);                  \
         edge_key16_kernel<true, XV16_WAVES, 1, CH, SP><<<grid, block, BYTES, s>>>(a);          \
     } while (0)
-    if (mlp.use_split) { if (cptr) TD_XV_LAUNCH(true, true, K16S_LDS_BYTES); else TD_XV_LAUNCH(false, true, K16S_LDS_BYTES); }
-    else { if (cptr) TD_XV_LAUNCH(true, false, K16_LDS_BYTES); else TD_XV_LAUNCH(false, false, K16_LDS_BYTES); }
+    if (mlp.use_split) { if (cptr) TD_XV_LAUNCH(1, true, K16S_LDS_BYTES); else TD_XV_LAUNCH(0, true, K16S_LDS_BYTES); }
+    else { if (cptr) TD_XV_LAUNCH(1, false, K16_LDS_BYTES); else TD_XV_LAUNCH(0, false, K16_LDS_BYTES); }
 #undef TD_XV_LAUNCH
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
