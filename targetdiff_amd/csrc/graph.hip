@@ -240,8 +240,44 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
         }
     }
     bool is_clean = !overflow && __ballot(closer) == 0ull;
-    if (!is_clean) {
-        // merge: 32 rounds of wave-minimum extraction over {static key, 2 ligand keys} (+ further ligand passes)
+    if (!is_clean && !overflow) {
+        // Merge by rank.  Only the ligand atoms below the k-th static key can enter the list (typically a handful): each is broadcast
+        // once (wave-uniform key), every static key counts the candidates below it (its shift in the merged order), and the candidate's own
+        // rank is the number of static keys + candidates below it -- three ballots.  Keys are unique (the node index sits in the low
+        // word), so the ranks are a permutation and the list comes out exactly as the k rounds of minimum extraction below produce it,
+        // at ~ 15 instructions per candidate instead of ~ 40 per round.
+        const bool c0 = kl[0] < thr, c1 = kl[1] < thr;
+        const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+        const int n_static = __popcll(__ballot(lane < TD_K && ks != TD_KEY_MAX));
+        int shift = 0;
+        bool lig_in = false;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned long long mm = u ? m1 : m0;
+            while (mm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+                mm &= mm - 1;
+                const unsigned clo = __builtin_amdgcn_readlane((int)(unsigned)kl[u], src);
+                const unsigned chi = __builtin_amdgcn_readlane((int)(unsigned)(kl[u] >> 32), src);
+                const unsigned long long ck = ((unsigned long long)chi << 32) | clo;
+                if (lane < TD_K && ck < ks) ++shift;
+                const int rank = __popcll(__ballot(lane < TD_K && ks < ck)) + __popcll(__ballot(c0 && kl[0] < ck)) +
+                                 __popcll(__ballot(c1 && kl[1] < ck));
+                if (rank < k) {
+                    lig_in = true;
+                    if (lane == 0) nbr[i * TD_K + rank] = (int32_t)clo;
+                }
+            }
+        }
+        const int total = n_static + __popcll(m0) + __popcll(m1);
+        if (lane < TD_K) {
+            const int pos = lane + shift;
+            if (ks != TD_KEY_MAX && pos < k) nbr[i * TD_K + pos] = (int32_t)(unsigned)(ks & 0xffffffffull);
+            if (lane >= (total < k ? total : k)) nbr[i * TD_K + lane] = -1;
+        }
+        is_clean = !lig_in;
+    } else if (!is_clean) {
+        // more than 128 ligand atoms in the graph: k rounds of wave-minimum extraction over {static key, 2 ligand keys} per pass of 128
         unsigned long long best = ks;
         for (int base = lbeg; base < lend; base += 128) {
             if (base != lbeg) {
