@@ -454,6 +454,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     const float *Wl = cur.take((size_t)E * C), *bl = cur.take(E);
     const float *goff = cur.take(TD_NG);
     MlpSrc gate = cur.mlp(TD_NG, H, 1);
+    const FoldedMlp fgate(gate, TD_NG, H, 1);          // LayerNorm folded into the two Linears, like the edge MLPs'
+    gate = fgate.src();
 
     Packer pk;
     // ---- embeddings (+ node indicator column, models/molopt_score_model.py:336-338)

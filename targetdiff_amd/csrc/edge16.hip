@@ -277,42 +277,10 @@ __device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, 
     }
 }
 
-// the plain form (mean, variance, affine) for the edge gate's MLP, whose weights are packed as they are
-__device__ __forceinline__ void td_ln_affine_relu16(const float *__restrict__ GAM, const float *__restrict__ BET, int g,
-                                                    floatx4_t (&acc)[2][8]) {
-#pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
-        float s1 = 0.f;
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) s1 += (acc[eb][hb][0] + acc[eb][hb][1]) + (acc[eb][hb][2] + acc[eb][hb][3]);
-        const float mean = td_sum_groups(s1) * (1.0f / TD_H);
-        float s2 = 0.f;
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dv = acc[eb][hb][r] - mean;
-                s2 = fmaf(dv, dv, s2);
-            }
-        const float rstd = __frsqrt_rn(td_sum_groups(s2) * (1.0f / TD_H) + 1e-5f);
-        const float nms = -mean * rstd;
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) {
-            const float4 gm = *reinterpret_cast<const float4 *>(GAM + 16 * hb + 4 * g);
-            const float4 bm = *reinterpret_cast<const float4 *>(BET + 16 * hb + 4 * g);
-            acc[eb][hb][0] = fmaxf(fmaf(fmaf(acc[eb][hb][0], rstd, nms), gm.x, bm.x), 0.f);
-            acc[eb][hb][1] = fmaxf(fmaf(fmaf(acc[eb][hb][1], rstd, nms), gm.y, bm.y), 0.f);
-            acc[eb][hb][2] = fmaxf(fmaf(fmaf(acc[eb][hb][2], rstd, nms), gm.z, bm.z), 0.f);
-            acc[eb][hb][3] = fmaxf(fmaf(fmaf(acc[eb][hb][3], rstd, nms), gm.w, bm.w), 0.f);
-        }
-    }
-}
-
-
 // radial / type first layer on the gathered operands + LayerNorm + ReLU: z^T in acc[eb][hb]
 template <bool LOAD_EW, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const float4 *__restrict__ Rt,
-                                                         const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                         const float *__restrict__ KB,
                                                          const float (&offk)[E16_STEPS], const RowIn16 &r, int lane,
                                                          floatx4_t (&acc)[2][8], Edge2 &ed) {
     const int g = lane >> 4;
@@ -367,8 +335,8 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    if (SKIP_EMPTY) td_ln_relu16_skip(BET, g, acc, ed.rstd, ed.any);
-    else td_ln_relu16<2>(BET, g, acc, ed.rstd);
+    if (SKIP_EMPTY) td_ln_relu16_skip(KB, g, acc, ed.rstd, ed.any);
+    else td_ln_relu16<2>(KB, g, acc, ed.rstd);
 }
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
@@ -413,7 +381,7 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
 template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
-                                                       const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                       const float *__restrict__ KB,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
                                                        floatx4_t (&acc)[2][8], Edge2 &ed, Hook before_products = Hook()) {
     const int lo = lane & 15, g = lane >> 4;
@@ -511,28 +479,28 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         if (any_sl) products(sl);
     }
     if (PI_LATE) add_pi();
-    if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(BET, g, acc, ed.rstd, ed.any);
-    else td_ln_relu16<NEB>(BET, g, acc, ed.rstd);
+    if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(KB, g, acc, ed.rstd, ed.any);
+    else td_ln_relu16<NEB>(KB, g, acc, ed.rstd);
 }
 
 template <bool LOAD_EW, bool SKIP_EMPTY = false>
 __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *__restrict__ Rt,
-                                                 const float *__restrict__ GAM, const float *__restrict__ BET,
+                                                 const float *__restrict__ KB,
                                                  const float (&offk)[E16_STEPS], int64_t i, int lane,
                                                  floatx4_t (&acc)[2][8], Edge2 &ed, int64_t c = -1) {
     RowIn16 r;
     if (c < 0) c = i;
     td_row_index16(a, i, c, lane, r);
     td_row_gather16<LOAD_EW>(a, i, c, lane, r, acc);
-    td_first_layer_compute16<LOAD_EW, SKIP_EMPTY>(a, Rt, GAM, BET, offk, r, lane, acc, ed);
+    td_first_layer_compute16<LOAD_EW, SKIP_EMPTY>(a, Rt, KB, offk, r, lane, acc, ed);
 }
 
 // ================================================================================================ key pass
 constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, one LDS copy of the weights per CU
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
-constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + 2 * TD_H + 4) * sizeof(float);       // + the row counter
+constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 4) * sizeof(float);       // + the row counter
 constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
-constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
+constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -557,7 +525,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
     const float4 *Wq = reinterpret_cast<const float4 *>(lds + RF);       // [hb][r][jq][lane] x 4 j
-    const float *GAM = lds + RF + E16_WQ_FLOATS, *BET = GAM + TD_H;
+    const float *KB = lds + RF + E16_WQ_FLOATS;          // beta / |gamma| of the folded LayerNorm (td_ln_relu16)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
@@ -566,12 +534,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + RF), nw4, tid,
                        WAVES * 64);
-        if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.gamma[tid];
-        else if (tid < 2 * TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid - TD_H];
-        else if (tid == 2 * TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H) = 0;
-        else if (SPLIT && tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {
-            const int k = tid - (2 * TD_H + 32);
-            lds[RF + E16_WQ_FLOATS + 2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
+        if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid];
+        else if (tid == TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + TD_H) = 0;
+        else if (SPLIT && tid >= TD_H + 32 && tid < TD_H + 64) {
+            const int k = tid - (TD_H + 32);
+            lds[RF + E16_WQ_FLOATS + TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
@@ -589,7 +556,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     // a workgroup had 15 or 16 units of 12 rows) and handed to the workgroup's waves one at a time through an LDS counter -- the
     // waves that share a SIMD do not progress at the same rate (the first of a workgroup's 12 is done a third of the launch before
     // the last, tools/wg_balance.py), and a SIMD left with one wave no longer hides its gathers
-    int *row_ctr = reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H);
+    int *row_ctr = reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + TD_H);
     const bool dyn = a.deal == 2;
     auto grab = [&]() -> int {
         int n = 0;
@@ -615,7 +582,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             {
                 int dep = 0;
                 asm volatile("" : "+v"(dep));
-                const float4 *op = reinterpret_cast<const float4 *>(lds + RF + E16_WQ_FLOATS + 2 * TD_H + 4 + 8 * g + dep);
+                const float4 *op = reinterpret_cast<const float4 *>(lds + RF + E16_WQ_FLOATS + TD_H + 4 + 8 * g + dep);
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
@@ -628,11 +595,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             // a chunk whose second block is all padding (wave-uniform): the xv pass (8 waves, 256 registers) has room for a path without
             // it; the key pass at 168 registers does not (126 spilled registers) and only leaves the block out of its LayerNorm and logits
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<EW, false, false, 1>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
-            td_first_layer16<EW, CHUNKED>(a, Rt, GAM, BET, offk, i, lane, acc, ed, c);
+            td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
 
     for (int64_t it = dyn ? row_of(grab()) : begin + wid; it < end; it = dyn ? row_of(grab()) : it + stride) {
@@ -806,22 +773,13 @@ constexpr int H2X16_WAVES = 8;
 constexpr int H2X16_WX_FLOATS = 8 * 4 * 64;                                  // W2xv16[hb][r][lane]
 template <bool SPLIT> constexpr int h2x16_table_floats() { return SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS / 2; }
 template <bool SPLIT> constexpr size_t h2x16_lds_bytes() {
-    return (size_t)(2 * h2x16_table_floats<SPLIT>() + E16_WQ_FLOATS + H2X16_WX_FLOATS + 4 * TD_H) * sizeof(float);
+    return (size_t)(2 * h2x16_table_floats<SPLIT>() + E16_WQ_FLOATS + H2X16_WX_FLOATS + 2 * TD_H) * sizeof(float);
 }
 
 struct ArgsH2x {
     Args16 a;              // a.mlp = xk MLP (keys), a.p_off = 0
     TdEdgeMlp mlp_v;       // xv MLP
 };
-
-// the fp32 tables of one edge MLP in the layout of edge_key16_kernel: radial/type table, second-layer weights, LayerNorm affine
-template <int WAVES>
-__device__ __forceinline__ void td_stage_tables16(float *lds, const TdEdgeMlp &mlp, int nw4, int tid) {
-    td_stage_lds16(reinterpret_cast<const float4 *>(mlp.R16), reinterpret_cast<float4 *>(lds), E16_R_FLOATS / 4, tid, WAVES * 64);
-    td_stage_lds16(reinterpret_cast<const float4 *>(mlp.Walt16), reinterpret_cast<float4 *>(lds + E16_R_FLOATS), nw4, tid, WAVES * 64);
-    if (tid < TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.gamma[tid];
-    else if (tid < 2 * TD_H) lds[E16_R_FLOATS + E16_WQ_FLOATS + tid] = mlp.beta[tid - TD_H];
-}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar) {
@@ -833,7 +791,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     float *Rk = lds, *WqF = Rk + RH, *Rv = WqF + E16_WQ_FLOATS, *WxF = Rv + RH, *GB = WxF + H2X16_WX_FLOATS;
     const float4 *Wq = reinterpret_cast<const float4 *>(WqF);
     const float *Wx = WxF;
-    const float *GAMk = GB, *BETk = GB + TD_H, *GAMv = GB + 2 * TD_H, *BETv = GB + 3 * TD_H;
+    const float *KBk = GB, *KBv = GB + TD_H;              // beta / |gamma| of the two MLPs' folded LayerNorms
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
@@ -843,10 +801,8 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? ar.mlp_v.R16p : ar.mlp_v.R16), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
-        if (tid < TD_H) GB[tid] = a.mlp.gamma[tid];
-        else if (tid < 2 * TD_H) GB[tid] = a.mlp.beta[tid - TD_H];
-        else if (tid < 3 * TD_H) GB[tid] = ar.mlp_v.gamma[tid - 2 * TD_H];
-        else if (tid < 4 * TD_H) GB[tid] = ar.mlp_v.beta[tid - 3 * TD_H];
+        if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
+        else if (tid < 2 * TD_H) GB[tid] = ar.mlp_v.beta[tid - TD_H];
     }
     float offk[NOFF];
 #pragma unroll
@@ -870,8 +826,8 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         Edge2 ed;
         td_row_index16(a, i, i, lane, rin);
         td_row_gather16<true>(a, i, i, lane, rin, acc);
-        if constexpr (SPLIT) td_first_layer_split16<true, true, false>(a, reinterpret_cast<const uint4 *>(Rk), GAMk, BETk, offk, rin, i, lane, acc, ed);
-        else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), GAMk, BETk, offk, rin, lane, acc, ed);
+        if constexpr (SPLIT) td_first_layer_split16<true, true, false>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+        else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), KBk, offk, rin, lane, acc, ed);
         // the value half's gathers (its own accumulators) fly while the logits and the softmax run.  The query is fetched BEFORE they are
         // issued: vmcnt counts in order, so a load issued after the gathers could only be waited for together with them -- and the
         // logits, which need the query first, would start when the gathers have landed instead of while they fly
@@ -905,8 +861,8 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
-        if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), GAMv, BETv, offk, rv, i, lane, accv, ev);
-        else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), GAMv, BETv, offk, rv, lane, accv, ev);
+        if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
+        else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), KBv, offk, rv, lane, accv, ev);
         floatx4_t xv[2];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -959,9 +915,9 @@ __device__ __forceinline__ int td_tile_row16(int e) { return e * V16_TB_STRIDE +
 constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // 1408 >= 8 * 132: two transpose tiles, later the Zbar half
 constexpr int V16_SB_FLOATS = 48;                         // per wave: S[16 heads] + the 32 edges' 1 / sigma (td_ln_relu16) on their way to the A operand
 constexpr size_t V16_LDS_BYTES =
-    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 3 * TD_H + 4) * sizeof(float);
+    (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
-    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 3 * TD_H + 4 + 32) * sizeof(float);
+    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
 // (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
@@ -997,7 +953,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         const float4 r0 = *reinterpret_cast<const float4 *>(RS + 8 * g), r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
         alx[0] *= r0.x; alx[1] *= r0.y; alx[2] *= r0.z; alx[3] *= r0.w; alx[4] *= r1.x; alx[5] *= r1.y; alx[6] *= r1.z; alx[7] *= r1.w;
     };
-    const float *GAM = B2 + TD_H, *BET = GAM + TD_H;
+    const float *KB = B2 + TD_H;                          // beta / |gamma| of the folded LayerNorm (td_ln_relu16)
     // SPLIT: workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0)
     int my_cls = 1, GL = 0;
     int64_t n_rows = 0;
@@ -1025,12 +981,11 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid,
                        V16_WAVES * 64);
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
-        else if (tid < 2 * TD_H) B2[tid] = a.mlp.gamma[tid - TD_H];
-        else if (tid < 3 * TD_H) B2[tid] = a.mlp.beta[tid - 2 * TD_H];
-        else if (tid == 3 * TD_H) *reinterpret_cast<int *>(B2 + 3 * TD_H) = 0;
-        else if (SPLIT && tid >= 3 * TD_H + 32 && tid < 3 * TD_H + 64) {           // Gaussian centres, read per row (see edge_key16_kernel)
-            const int k = tid - (3 * TD_H + 32);
-            B2[3 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
+        else if (tid < 2 * TD_H) B2[tid] = a.mlp.beta[tid - TD_H];
+        else if (tid == 2 * TD_H) *reinterpret_cast<int *>(B2 + 2 * TD_H) = 0;
+        else if (SPLIT && tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {           // Gaussian centres, read per row (see edge_key16_kernel)
+            const int k = tid - (2 * TD_H + 32);
+            B2[2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];
@@ -1073,7 +1028,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     const bool dyn = a.deal == 2 && (!SPLIT || my_cls == 1);
     const int64_t first = scan;
     if (!dyn) scan += wid;
-    int *row_ctr = reinterpret_cast<int *>(B2 + 3 * TD_H);
+    int *row_ctr = reinterpret_cast<int *>(B2 + 2 * TD_H);
     auto row_id = [&](int64_t itx) -> int64_t { return list ? (int64_t)list[itx] : itx; };
     int cand = 0;                      // SPLIT: lane t = row id of candidate t of the current window
     unsigned long long todo = 0ull;    // SPLIT: candidates of the window still to do
@@ -1164,9 +1119,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         }
                     }
                     if constexpr (SPLIT)
-                        td_first_layer_split16<false, true, false, FULL ? 2 : 1>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offk, rcur, i, lane, acc, ed);
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
                     else
-                        td_first_layer_compute16<false, true>(a, Rt, GAM, BET, offk, rcur, lane, acc, ed);
+                        td_first_layer_compute16<false, true>(a, Rt, KB, offk, rcur, lane, acc, ed);
                     float part = (al[0] + al[1]) + (al[2] + al[3]);
                     if constexpr (FULL) part += (al[4] + al[5]) + (al[6] + al[7]);
                     asum += part;
@@ -1279,14 +1234,14 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             {
                 int dep = 0;
                 asm volatile("" : "+v"(dep));
-                const float4 *op = reinterpret_cast<const float4 *>(B2 + 3 * TD_H + 4 + 8 * g + dep);
+                const float4 *op = reinterpret_cast<const float4 *>(B2 + 2 * TD_H + 4 + 8 * g + dep);
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
-            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), GAM, BET, offr, rin, i, lane, acc, ed);
+            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
-            td_first_layer_compute16<false>(a, Rt, GAM, BET, offk, rin, lane, acc, ed);
+            td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
 
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
@@ -1379,7 +1334,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 // dots its 32 hidden units of an edge with w3 and the four lane groups add up.
 constexpr int G16_WAVES = 4;        // 162 VGPRs: three 4-wave workgroups per CU
 constexpr int G16P_U4 = 3 * 8 * 48;                                     // uint4 entries of the gate's piece table
-constexpr size_t G16_LDS_BYTES = (size_t)G16P_U4 * 16 + (size_t)4 * TD_H * sizeof(float);
+constexpr size_t G16_LDS_BYTES = (size_t)G16P_U4 * 16 + (size_t)3 * TD_H * sizeof(float);
 
 __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, const float4 *__restrict__ x4,
                                                                      const int32_t *__restrict__ nbr, int64_t N,
@@ -1388,14 +1343,14 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
                                                                      const int32_t *__restrict__ chunk_node, float *__restrict__ ew) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint4 *Rp = reinterpret_cast<const uint4 *>(lds);              // [piece][hb][48]
-    float *B0 = lds + G16P_U4 * 4, *GAM = B0 + TD_H, *BET = GAM + TD_H, *W3 = BET + TD_H;
+    float *B0 = lds + G16P_U4 * 4, *BET = B0 + TD_H, *W3 = BET + TD_H;      // bias, beta / |gamma| (folded LayerNorm), output weights
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
         td_stage_lds16(reinterpret_cast<const float4 *>(gt.R16p), reinterpret_cast<float4 *>(lds), G16P_U4, tid, G16_WAVES * 64);
-        for (int t = tid; t < 4 * TD_H; t += G16_WAVES * 64) {
+        for (int t = tid; t < 3 * TD_H; t += G16_WAVES * 64) {
             const int n = t & (TD_H - 1);
-            B0[t] = t < TD_H ? gt.b0[n] : (t < 2 * TD_H ? gt.gamma[n] : (t < 3 * TD_H ? gt.beta[n] : gt.w3[n]));
+            B0[t] = t < TD_H ? gt.b0[n] : (t < 2 * TD_H ? gt.beta[n] : gt.w3[n]);
         }
     }
     float offj[8];
@@ -1451,7 +1406,8 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
         }
-        td_ln_affine_relu16(GAM, BET, g, acc);
+        float rstd[2];
+        td_ln_relu16<2>(BET, g, acc, rstd);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
             float part = 0.f;
@@ -1461,7 +1417,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
                 part = fmaf(acc[eb][hb][0], w.x, part); part = fmaf(acc[eb][hb][1], w.y, part);
                 part = fmaf(acc[eb][hb][2], w.z, part); part = fmaf(acc[eb][hb][3], w.w, part);
             }
-            const float logit = td_sum_groups(part) + gt.b3;
+            const float logit = fmaf(td_sum_groups(part), rstd[eb], gt.b3);
             if (g == 0) ew[row * TD_K + 16 * eb + lo] = valid[eb] ? 1.0f / (1.0f + expf(-logit)) : 0.f;
         }
     }

@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
     const float4 *Rp = reinterpret_cast<const float4 *>(g.R);
 #pragma unroll
     for (int s = 0; s < TD_SLOT_STEPS; ++s) R[s] = Rp[s * 64 + lane];
-    float b0[4], gam[4], bet[4], w3[4];
+    float b0[4], bet[4], w3[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        b0[t] = g.b0[32 * t + c]; gam[t] = g.gamma[32 * t + c]; bet[t] = g.beta[32 * t + c]; w3[t] = g.w3[32 * t + c];
+        b0[t] = g.b0[32 * t + c]; bet[t] = g.beta[32 * t + c]; w3[t] = g.w3[32 * t + c];
     }
     float offk[TD_SLOT_STEPS];
 #pragma unroll
@@ -60,19 +60,19 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
             acc[2] = td_mfma(av, R[s].z, acc[2]);
             acc[3] = td_mfma(av, R[s].w, acc[3]);
         }
+        // LayerNorm in the folded form the gate's weights are packed for (FoldedMlp, api.cpp): the accumulators hold the centred
+        // pre-activation times the sign of the LayerNorm weight, bet = beta / |gamma|, w3 carries |gamma|, 1 / sigma multiplies the dot product
         float outv = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s1 = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-            const float mean = td_sum32(s1) * (1.0f / TD_H);
-            const float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
-            const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H);
-            const float rstd = 1.0f / sqrtf(var + 1e-5f);
-            float part = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f) * w3[0];
-            part += fmaxf(d1 * rstd * gam[1] + bet[1], 0.f) * w3[1];
-            part += fmaxf(d2 * rstd * gam[2] + bet[2], 0.f) * w3[2];
-            part += fmaxf(d3 * rstd * gam[3] + bet[3], 0.f) * w3[3];
-            const float logit = td_sum32(part) + g.b3;
+            const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r];
+            const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H) + 1e-5f;
+            const float rstd = __frsqrt_rn(var), sig = var * rstd;
+            float part = fmaxf(fmaf(sig, bet[0], d0), 0.f) * w3[0];
+            part = fmaf(fmaxf(fmaf(sig, bet[1], d1), 0.f), w3[1], part);
+            part = fmaf(fmaxf(fmaf(sig, bet[2], d2), 0.f), w3[2], part);
+            part = fmaf(fmaxf(fmaf(sig, bet[3], d3), 0.f), w3[3], part);
+            const float logit = fmaf(td_sum32(part), rstd, g.b3);
             if (c == r) outv = 1.0f / (1.0f + expf(-logit));
         }
         // lane (c < 16, hi) holds the gate of edge row erow(c, hi)

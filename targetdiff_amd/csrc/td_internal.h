@@ -52,8 +52,9 @@ inline int td_set_lds(TdLdsOnce &once, const void *fn, size_t bytes) {
 //    radial/type table R and a bias;  * the second Linear is stored as per-wave MFMA B fragments.
 struct TdEdgeMlp {
     const float *R;        // [2 dst class][2 slot][12 kstep][64 lane][4 ntile]  first-layer radial+type B fragments
-    const float *gamma;    // [128] LayerNorm weight
-    const float *beta;     // [128] LayerNorm bias
+    // (every table below comes from the MLP with its LayerNorm folded into the two Linears: FoldedMlp, api.cpp)
+    const float *gamma;    // [128] |LayerNorm weight| (already inside the second Linear's columns; not read by the kernels)
+    const float *beta;     // [128] LayerNorm bias / |LayerNorm weight|: z' = relu(centred pre-activation + sigma * beta)
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]
     const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
@@ -89,7 +90,7 @@ struct TdLayer {
 
 struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_transformer.py:236-237,312-316)
     const float *R;        // [12 kstep][64 lane][4 ntile]
-    const float *b0, *gamma, *beta, *w3;   // [128] each
+    const float *b0, *gamma, *beta, *w3;   // [128] each, LayerNorm folded like the edge MLPs' (FoldedMlp): beta = bias / |weight|, w3 carries |weight|
     float b3;
     const float *offsets;  // [20]
     float coeff;
