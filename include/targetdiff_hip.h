@@ -287,7 +287,9 @@ int td_session_step_graph(const td_session *s);
  * (the others keep the protein-only graph's cached layer-1 output), -1 when off; synchronises */
 int td_session_row_counts(td_session *s, int32_t *host_counts, int32_t n_counts, void *stream);
 
-/* ---- kernel timers (measurement only; process-global, not thread-safe).  td_profile_begin arms HIP-event
+/* ---- kernel timers (measurement only; process-global: one set of timers for all models and streams of the process.  Launches from
+ *      several host threads may record concurrently -- every start / stop pair enters the lists under a lock -- but begin / end
+ *      themselves are meant for one controlling thread).  td_profile_begin arms HIP-event
  *      timers around the kernel classes selected by `class_mask` (bit c = class c) on the launch stream;
  *      td_profile_end synchronises the device and returns per-class summed milliseconds and launch counts.
  *      Classes: 0 knn, 1 edge gate, 2 node projections, 3 x2h key pass, 4 x2h value pass, 5 h2x key pass,

@@ -1,10 +1,12 @@
 // C ABI of libtargetdiff_hip.so: weight re-packing, workspace carving and the per-step launch sequence.
 // See include/targetdiff_hip.h for the contract of every entry point and the reference seam it replaces.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -34,11 +36,15 @@ extern "C" const char *td_build_tag(void) { return TD_BUILD_TAG; }
 namespace {
 enum { PC_KNN = 0, PC_GATE, PC_NODE, PC_X2H_K, PC_X2H_V, PC_H2X_K, PC_H2X_V, PC_COMPOSE, PC_HEAD, PC_POST, PC_COUNT };
 struct Profiler {
-    unsigned mask = 0;
+    std::atomic<unsigned> mask{0};
+    std::mutex mu;                            // the event lists: launches may come from several host threads (one stream each)
     std::vector<hipEvent_t> ev[PC_COUNT];     // start/stop pairs
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        }
         hipEvent_t e = nullptr;
         (void)hipEventCreate(&e);
         return e;
@@ -46,17 +52,24 @@ struct Profiler {
 };
 Profiler g_prof;
 struct ProfScope {
-    int cls; hipStream_t s; bool on;
-    ProfScope(int c, hipStream_t st) : cls(c), s(st), on((g_prof.mask >> c) & 1u) {
-        if (on) { hipEvent_t e = g_prof.get(); (void)hipEventRecord(e, s); g_prof.ev[cls].push_back(e); }
+    int cls; hipStream_t s; bool on; hipEvent_t e0 = nullptr;
+    ProfScope(int c, hipStream_t st) : cls(c), s(st), on((g_prof.mask.load(std::memory_order_relaxed) >> c) & 1u) {
+        if (on) { e0 = g_prof.get(); (void)hipEventRecord(e0, s); }
     }
     ~ProfScope() {
-        if (on) { hipEvent_t e = g_prof.get(); (void)hipEventRecord(e, s); g_prof.ev[cls].push_back(e); }
+        if (on) {
+            hipEvent_t e1 = g_prof.get();
+            (void)hipEventRecord(e1, s);
+            std::lock_guard<std::mutex> lk(g_prof.mu);       // the pair enters the list together, whatever other threads record meanwhile
+            g_prof.ev[cls].push_back(e0);
+            g_prof.ev[cls].push_back(e1);
+        }
     }
 };
 }  // namespace
 
 extern "C" int td_profile_begin(uint32_t class_mask) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (int c = 0; c < PC_COUNT; ++c) {
         for (hipEvent_t e : g_prof.ev[c]) g_prof.pool.push_back(e);
         g_prof.ev[c].clear();
@@ -68,6 +81,7 @@ extern "C" int td_profile_begin(uint32_t class_mask) {
 extern "C" int td_profile_end(float *ms_out, int32_t *count_out, int32_t num_classes) {
     g_prof.mask = 0;
     TD_CHECK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     for (int c = 0; c < PC_COUNT; ++c) {
         float total = 0.f;
         int n = 0;
