@@ -576,11 +576,11 @@ def main():
                 'share_of_step': (p['ms'] / prof_steps) / (sec_per_step * 1e3), 'profiled_steps': prof_steps}
 
     if default_graph:
-        vk, kk = (('edge_value16_kernel<true>', 'edge_key16_kernel<false, 12, 0, false, true>') if split
-                  else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, false, false>'))
+        vk, kk = (('edge_value16_kernel<true>', 'edge_key16_kernel<false, 12, 0, 0, true>') if split
+                  else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, 0, false>'))
     else:
         vk = 'edge_value16_ragged_kernel'
-        kk = 'edge_key16_kernel<false, 12, 0, true, true>' if split else 'edge_key16_kernel<false, 16, 0, true, false>'
+        kk = 'edge_key16_kernel<false, 12, 0, 1, true>' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
