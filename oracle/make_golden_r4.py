@@ -12,7 +12,11 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
       edge gate rebuilt from the moved coordinates in between): forward on the small batch, 4 reverse steps.
   forward_ln_signs.npz       the default architecture with LayerNorm weights of every sign (oracle.weights.ln_signs_state_dict: negative,
       zero and tiny entries in every MLP): forward (return_all) on the small batch.  Pins the LayerNorm fold of the packed edge MLPs.
-Weights: oracle.weights.time_emb_state_dict / make_state_dict (seeded per key; the fixtures hold outputs only)."""
+  forward_ew_r_out_fc.npz / forward_ew_none.npz / forward_out_fc.npz / sample_ew_r_out_fc_4.npz   the gate and output options of the
+      attention layers outside configs/training.yml: ew_net_type = 'r' (every stage's own Linear(80, 1) + sigmoid on the layer's radial
+      features, models/uni_transformer.py:34-35, 60-61, 102-103, 124-125), anything else but 'global' / 'm' (e_w = 1, :64-67), and
+      x2h_out_fc = True (node_output([attention output | h]) + h, :39-40, 81-84).  'r' + out_fc are the reference CLASS's defaults.
+Weights: oracle.weights.time_emb_state_dict / make_state_dict(seed, cfg) (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
 
 import os
@@ -36,7 +40,7 @@ def build(ref, **over):
     if cfg.get('time_emb_dim', 0) > 0 and cfg['time_emb_mode'] == 'simple':
         sd = weights.time_emb_state_dict(SEED)
     else:
-        sd = weights.make_state_dict(SEED)
+        sd = weights.make_state_dict(SEED, cfg)
     res = model.load_state_dict(sd, strict=False)
     assert not res.unexpected_keys, res.unexpected_keys
     learnable = {k for k, p in model.named_parameters() if p.requires_grad}
@@ -75,6 +79,19 @@ def gen_forward_ln_signs(ref):
           layer0_pred_ligand_v=p['layer_pred_ligand_v'][0].numpy(), layer0_pred_ligand_pos=p['layer_pred_ligand_pos'][0].numpy())
     print('forward_ln_signs: |pred_v| max', float(p['pred_ligand_v'].abs().max()), '|dx| max',
           float((p['pred_ligand_pos'] - lposc).abs().max()))
+
+
+def gen_forward_options(ref, name, **over):
+    model = build(ref, **over)
+    b, lpos, lv = small_batch()
+    ppos, lposc, _ = ref.center_pos(b.protein_pos, lpos, b.protein_element_batch, b.ligand_element_batch, mode='protein')
+    with torch.no_grad():
+        p = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch)
+        f = model(ppos, b.protein_atom_feature.float(), b.protein_element_batch, lposc, lv, b.ligand_element_batch, fix_x=True)
+    _save(os.path.join(GOLDEN_DIR, name), protein_pos=ppos.numpy(), ligand_pos=lposc.numpy(), ligand_v=lv.numpy(),
+          pred_ligand_pos=p['pred_ligand_pos'].numpy(), pred_ligand_v=p['pred_ligand_v'].numpy(),
+          final_ligand_h=p['final_ligand_h'].numpy(), final_h=p['final_h'].numpy(), fix_x_final_ligand_h=f['final_ligand_h'].numpy())
+    print(name, over, '|pred_v| max', float(p['pred_ligand_v'].abs().max()), '|dx| max', float((p['pred_ligand_pos'] - lposc).abs().max()))
 
 
 def gen_forward_blocks(ref):
@@ -125,6 +142,10 @@ def main():
     global STEPS
     STEPS = 4
     gen_sample(ref, 'sample_blocks2_4.npz', 4500, num_blocks=2)
+    gen_forward_options(ref, 'forward_ew_r_out_fc.npz', ew_net_type='r', x2h_out_fc=True)
+    gen_forward_options(ref, 'forward_ew_none.npz', ew_net_type='none')
+    gen_forward_options(ref, 'forward_out_fc.npz', x2h_out_fc=True)
+    gen_sample(ref, 'sample_ew_r_out_fc_4.npz', 4600, ew_net_type='r', x2h_out_fc=True)
 
 
 if __name__ == '__main__':

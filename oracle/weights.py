@@ -46,24 +46,33 @@ def _att_layer_spec(prefix, cfg, num_x2h, num_h2x):
     H, heads = cfg['hidden_dim'], cfg['n_heads']
     kv_in = 2 * H + cfg['edge_feat_dim'] + 4 * cfg['num_r_gaussian']
     spec = [(f'{prefix}.distance_expansion.offset', (cfg['num_r_gaussian'],), 'offset', 0)]
+    r_feat = 4 * cfg['num_r_gaussian']
+    ew = cfg.get('ew_net_type', 'global')
     for i in range(num_x2h):
         p = f'{prefix}.x2h_layers.{i}'
         spec += _mlp_spec(f'{p}.hk_func', kv_in, H, H)
         spec += _mlp_spec(f'{p}.hv_func', kv_in, H, H)
         spec += _mlp_spec(f'{p}.hq_func', H, H, H)
+        if ew == 'r':                                   # models/uni_transformer.py:34-35
+            spec += [(f'{p}.ew_net.0.weight', (1, r_feat), 'linear', r_feat), (f'{p}.ew_net.0.bias', (1,), 'bias', r_feat)]
+        elif ew == 'm':                                 # :36-37
+            spec += [(f'{p}.ew_net.0.weight', (1, H), 'linear', H), (f'{p}.ew_net.0.bias', (1,), 'bias', H)]
+        if cfg.get('x2h_out_fc', False):                # :39-40
+            spec += _mlp_spec(f'{p}.node_output', 2 * H, H, H)
     for i in range(num_h2x):
         p = f'{prefix}.h2x_layers.{i}'
         spec += _mlp_spec(f'{p}.xk_func', kv_in, H, H)
         spec += _mlp_spec(f'{p}.xv_func', kv_in, H, heads)
         spec += _mlp_spec(f'{p}.xq_func', H, H, H)
+        if ew == 'r':                                   # :102-103
+            spec += [(f'{p}.ew_net.0.weight', (1, r_feat), 'linear', r_feat), (f'{p}.ew_net.0.bias', (1,), 'bias', r_feat)]
     return spec
 
 
 def parameter_spec(cfg=None, protein_dim=PROTEIN_FEATURE_DIM, ligand_dim=LIGAND_FEATURE_DIM):
     """[(key, shape, kind, fan_in)] for every learnable tensor / fixed offset of the default model."""
     cfg = dict(DEFAULT_MODEL_CONFIG if cfg is None else cfg)
-    assert cfg['model_type'] == 'uni_o2' and cfg['time_emb_dim'] == 0 and cfg['ew_net_type'] == 'global'
-    assert not cfg['x2h_out_fc']
+    assert cfg['model_type'] == 'uni_o2' and cfg['time_emb_dim'] == 0
     H = cfg['hidden_dim']
     emb = H - 1 if cfg['node_indicator'] else H
     spec = [
@@ -73,7 +82,8 @@ def parameter_spec(cfg=None, protein_dim=PROTEIN_FEATURE_DIM, ligand_dim=LIGAND_
         ('ligand_atom_emb.bias', (emb,), 'bias', ligand_dim),
         ('refine_net.distance_expansion.offset', (cfg['num_r_gaussian'],), 'offset', 0),
     ]
-    spec += _mlp_spec('refine_net.edge_pred_layer', cfg['num_r_gaussian'], H, 1)
+    if cfg['ew_net_type'] == 'global':                   # models/uni_transformer.py:241-242
+        spec += _mlp_spec('refine_net.edge_pred_layer', cfg['num_r_gaussian'], H, 1)
     # init_h_emb_layer: built with num_init_x2h=1, num_init_h2x=0 and never called
     # (models/uni_transformer.py:245,255-261 vs :301-328); present in checkpoints.
     spec += _att_layer_spec('refine_net.init_h_emb_layer', cfg, 1, 0)

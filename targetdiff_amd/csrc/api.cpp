@@ -420,9 +420,11 @@ extern "C" size_t td_model_num_weights(const td_config *cfg) {
     const td_config &c = *cfg;
     const int H = c.hidden_dim, E = H - 1, KV = kv_in(c);
     size_t n = (size_t)E * c.protein_feat_dim + E + (size_t)E * c.ligand_num_classes + E;
-    n += c.num_r_gaussian + mlp_floats(c.num_r_gaussian, H, 1);
+    n += c.num_r_gaussian + (c.ew_net_type == 0 ? mlp_floats(c.num_r_gaussian, H, 1) : 0);
     n += (size_t)c.num_layers * (c.num_r_gaussian + 2 * mlp_floats(KV, H, H) + 2 * mlp_floats(H, H, H) +
                                  mlp_floats(KV, H, H) + mlp_floats(KV, H, c.n_heads));
+    if (c.ew_net_type == 1) n += (size_t)c.num_layers * 2 * (4 * c.num_r_gaussian + 1);       // the two stages' ew_net
+    if (c.x2h_out_fc) n += (size_t)c.num_layers * mlp_floats(2 * H, H, H);                     // node_output
     n += (size_t)H * H + H + (size_t)c.ligand_num_classes * H + c.ligand_num_classes;
     return n;
 }
@@ -454,6 +456,15 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         td_set_error("td_model_create: num_blocks must be 1 .. 8 (0 = 1), got %d", c.num_blocks);
         return TD_EINVAL;
     }
+    if (c.ew_net_type < 0 || c.ew_net_type > 2 || (c.x2h_out_fc != 0 && c.x2h_out_fc != 1)) {
+        td_set_error("td_model_create: ew_net_type must be 0 ('global'), 1 ('r') or 2 (none), x2h_out_fc 0 or 1; got %d / %d",
+                     c.ew_net_type, c.x2h_out_fc);
+        return TD_EINVAL;
+    }
+    if (c.ew_net_type != 0 && !default_graph(c)) {
+        td_set_error("td_model_create: ew_net_type 'r' / none runs on the 32-slot graphs only (knn <= 32, or radius with a cap <= 32)");
+        return TD_EINVAL;
+    }
     if (c.model_mean_type != 0 && c.model_mean_type != 1) {
         td_set_error("td_model_create: model_mean_type must be 0 ('C0') or 1 ('noise'), got %d", c.model_mean_type);
         return TD_EINVAL;
@@ -467,7 +478,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     const float *Wp = cur.take((size_t)E * F), *bp = cur.take(E);
     const float *Wl = cur.take((size_t)E * C), *bl = cur.take(E);
     const float *goff = cur.take(TD_NG);
-    MlpSrc gate = cur.mlp(TD_NG, H, 1);
+    // (without the global gate -- ew_net_type 'r' / none -- the blob has no edge_pred_layer; a zero MLP stands in for the packer)
+    static const std::vector<float> zero_mlp(mlp_floats(TD_NG, TD_H, 1), 0.f);
+    Cursor zc{zero_mlp.data(), zero_mlp.size()};
+    MlpSrc gate = c.ew_net_type == 0 ? cur.mlp(TD_NG, H, 1) : zc.mlp(TD_NG, H, 1);
     const FoldedMlp fgate(gate, TD_NG, H, 1);          // LayerNorm folded into the two Linears, like the edge MLPs'
     gate = fgate.src();
 
@@ -514,13 +528,38 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             }
     }
     // ---- layers
-    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; };
+    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; size_t ew_x2h = 0, ew_h2x = 0, noB = 0, nob1 = 0, nog = 0, nobeta = 0, nob2 = 0; };
     std::vector<LayerOff> lo(L);
     for (int l = 0; l < L; ++l) {
         const float *off = cur.take(TD_NG);
+        // blob order per layer: offsets, hk, hv, hq, [node_output], [x2h ew_net], xk, xv, xq, [h2x ew_net]
         MlpSrc hk = cur.mlp(KV, H, H), hv = cur.mlp(KV, H, H), hq = cur.mlp(H, H, H);
+        MlpSrc nout{};
+        if (c.x2h_out_fc) nout = cur.mlp(2 * H, H, H);
+        const float *ewx = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
         MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
+        const float *ewh = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
         if (!cur.ok) break;
+        if (c.ew_net_type != 0) {            // [4 types][20] + bias per stage; none: sigmoid(40) = 1.0f
+            lo[l].ew_x2h = pk.alloc(4 * TD_NG + 1);
+            lo[l].ew_h2x = pk.alloc(4 * TD_NG + 1);
+            if (c.ew_net_type == 1) {
+                memcpy(pk.data.data() + lo[l].ew_x2h, ewx, (4 * TD_NG + 1) * sizeof(float));
+                memcpy(pk.data.data() + lo[l].ew_h2x, ewh, (4 * TD_NG + 1) * sizeof(float));
+            } else {
+                pk.data[lo[l].ew_x2h + 4 * TD_NG] = 40.f;
+                pk.data[lo[l].ew_h2x + 4 * TD_NG] = 40.f;
+            }
+        }
+        if (c.x2h_out_fc) {
+            lo[l].noB = pack_B128(pk, nout.w0, 2 * TD_H, 0);           // the attention-output half of net.0 (cat([output, h]), :83)
+            pack_B128(pk, nout.w0, 2 * TD_H, TD_H);                    // the h half (consecutive blocks)
+            pack_B128(pk, nout.w3, TD_H, 0);
+            lo[l].nob1 = pack_vec(pk, nout.b0, TD_H);
+            lo[l].nog = pack_vec(pk, nout.g, TD_H);
+            lo[l].nobeta = pack_vec(pk, nout.b, TD_H);
+            lo[l].nob2 = pack_vec(pk, nout.b3, TD_H);
+        }
         // the four edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
         const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H), fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
         hk = fhk.src(); hv = fhv.src(); xk = fxk.src(); xv = fxv.src();
@@ -577,6 +616,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         Ly.nodeX2h = node(lo[l].nx); Ly.nodeH2x = node(lo[l].nh);
         Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true); Ly.xk = edge(lo[l].xk, true); Ly.xv = edge(lo[l].xv, true);
         Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
+        Ly.ew_x2h = c.ew_net_type != 0 ? D + lo[l].ew_x2h : nullptr;
+        Ly.ew_h2x = c.ew_net_type != 0 ? D + lo[l].ew_h2x : nullptr;
+        Ly.nodeOut = c.x2h_out_fc ? TdNodeOut{D + lo[l].noB, D + lo[l].nob1, D + lo[l].nog, D + lo[l].nobeta, D + lo[l].nob2}
+                                  : TdNodeOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
     const float *S = D + oS;
@@ -695,9 +738,9 @@ int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const Gra
 // lig / Nl: the ligand rows of the batch (all of them are among `rows`: every row list of a step contains the ligand atoms)
 int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const int32_t *nbr, const float *P,
                const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig,
-               int64_t Nl, hipStream_t s) {
+               int64_t Nl, hipStream_t s, float *out = nullptr) {
     return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s, gt.cptr, gt.cpn_p,
-                                  lig ? gt.NCl : 0, gt.mixed);
+                                  lig ? gt.NCl : 0, gt.mixed, out);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the
@@ -767,8 +810,19 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
             proj_done = false;
+            if (L.ew_x2h) {          // ew_net_type 'r' / none: this stage's own gate from the layer's coordinates (no caching: every row)
+                ProfScope ps(PC_GATE, s);
+                if ((rc = td_launch_layer_gate(L.ew_x2h, L.offsets, L.coeff, xc, gt.nbr, N, gt.ew, s)) != TD_OK) return rc;
+            }
             { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, gt, gt.ew, gt.nbr, w.P, w.q, rws, cnt, N, gt.alpha, s, w.lig_node, Nl)) != TD_OK) return rc; }
-            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, gt, gt.nbr, w.P, rws, cnt, N, h, gt.alpha, w.lig_node, Nl, s)) != TD_OK) return rc; }
+            // x2h_out_fc: the attention output goes to w.q (the queries are spent once the key pass is done) without the residual, and
+            // node_output([output | h]) + h follows on every row
+            float *att_out = L.nodeOut.B ? w.q : nullptr;
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, gt, gt.nbr, w.P, rws, cnt, N, h, gt.alpha, w.lig_node, Nl, s, att_out)) != TD_OK) return rc; }
+            if (att_out) {
+                ProfScope ps(PC_NODE, s);
+                if ((rc = td_launch_node_output(L.nodeOut, att_out, h, N, s)) != TD_OK) return rc;
+            }
             if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
@@ -781,6 +835,10 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
             proj_done = true;
         } else {
             if ((rc = h2x_project(L, w, h, N, Nl, w.Px, w.qx, level_rows(1), level_count(1), s)) != TD_OK) return rc;
+        }
+        if (L.ew_h2x) {              // the h2x stage's own gate, from the same (not yet updated) coordinates
+            ProfScope ps(PC_GATE, s);
+            if ((rc = td_launch_layer_gate(L.ew_h2x, L.offsets, L.coeff, xc, gt.nbr, N, gt.ew, s)) != TD_OK) return rc;
         }
         if ((rc = h2x_attend(m, L, w, gt, Nl, xc, xn, w.Px, w.qx, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
@@ -802,6 +860,7 @@ int build_default_graph(const td_model *m, Workspace &w, int64_t N, int max_grap
             rc = td_launch_knn(w.x4a, w.node_ptr, w.gid, N, max_graph_nodes, w.nbr, s, m->cfg.knn);
         if (rc != TD_OK) return rc;
     }
+    if (m->cfg.ew_net_type != 0) return TD_OK;          // 'r' / none: every stage computes its own gate (run_backbone)
     ProfScope ps(PC_GATE, s);
     return td_launch_gate(m->gate, w.x4a, w.nbr, N, nullptr, nullptr, w.ew, s);
 }
@@ -1549,7 +1608,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     for (int64_t g = 0; g < B; ++g) gmax = std::max(gmax, (hp[g + 1] - hp[g]) + (hl[g + 1] - hl[g]));
     S->graph_nodes_max = gmax;
     const bool knn_like = m->cfg.cutoff_mode == TD_CUTOFF_KNN || m->cfg.cutoff_mode == TD_CUTOFF_HYBRID;
-    S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES) && num_blocks(m->cfg) == 1;
+    S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES) && num_blocks(m->cfg) == 1 && m->cfg.ew_net_type == 0 &&
+                 !m->cfg.x2h_out_fc;      // (the static-protein tables hold the global gate's rows and plain x2h outputs)
     if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
     const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table
     const int KS = S->chunked ? 64 : TD_K;                   // static keys kept per protein row

@@ -39,6 +39,7 @@ struct Args16 {
     const int32_t *rows;
     const int32_t *count_ptr;
     float *h;
+    float *out;                // value pass, x2h_out_fc: the attention output goes here WITHOUT the residual (nullptr: h += output)
     float *alpha;
     float4 *x4_out;            // XV mode: updated coordinates of the dst (ligand) nodes
     int64_t count;
@@ -1190,7 +1191,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
                     o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
                 }
-                a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+                if (a.out) a.out[(size_t)i * TD_H + n] = o;
+                else a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
             }
         }
         trace_end();
@@ -1320,7 +1322,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
                 o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
             }
-            a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
+            if (a.out) a.out[(size_t)icur * TD_H + n] = o;
+            else a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
     }
     trace_end();
@@ -1516,13 +1519,14 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            const int32_t *lig_rows, int64_t lig_count, hipStream_t s, const int32_t *cptr, int cpn_p,
-                           int64_t lig_chunks, const int32_t *mixed_count) {
+                           int64_t lig_chunks, const int32_t *mixed_count, float *out) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
     a.alpha = const_cast<float *>(alpha); a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets;
     a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr; a.cpn_p = cpn_p > 0 ? cpn_p : 1; a.lig_chunks = lig_chunks;
     a.mixed_count = mixed_count;
+    a.out = out;
     int G = grid16(count, V16_WAVES);
     const dim3 block(V16_WAVES * 64);
     a.trace = wg_trace_slot(1);

@@ -93,3 +93,39 @@ int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_
     return TD_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------ per-layer gate (ew_net_type 'r')
+// e_w = sigmoid(Linear(4 x 20 -> 1)(outer_product(edge type, GaussianSmearing(dist))))  (models/uni_transformer.py:34-35, 60-61, 102-103,
+// 124-125): with a one-hot edge type the 80-wide dot product is the 20 Gaussians against the weights of the edge's type.  One thread per
+// slot of the 32-slot neighbour table; w = [4 types][20] + bias.  ew_net_type 'none' (e_w = 1) runs the same kernel with zero weights and a
+// bias of 40 (sigmoid = 1.0f exactly).  A non-default configuration: nothing here is tuned.
+__global__ void layer_gate_kernel(const float *__restrict__ w, const float *__restrict__ offsets, float coeff,
+                                  const float4 *__restrict__ x4, const int32_t *__restrict__ nbr, int64_t N, float *__restrict__ ew) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * TD_K) return;
+    const int64_t i = t / TD_K;
+    const int j = nbr[t];
+    if (j < 0) { ew[t] = 0.f; return; }
+    const float4 xi = x4[i], xj = x4[j];
+    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    // edge type (models/uni_transformer.py:292-297): 0 l<-l, 1 src lig/dst prot, 2 src prot/dst lig, 3 p<-p
+    const bool dl = xi.w > 0.5f, sl = xj.w > 0.5f;
+    const int type = dl ? (sl ? 0 : 2) : (sl ? 1 : 3);
+    float logit = w[4 * TD_NG];
+#pragma unroll
+    for (int k = 0; k < TD_NG; ++k) {
+        const float u = d - offsets[k];
+        logit = fmaf(w[type * TD_NG + k], expf(coeff * u * u), logit);
+    }
+    ew[t] = 1.0f / (1.0f + expf(-logit));
+}
+
+int td_launch_layer_gate(const float *w, const float *offsets, float coeff, const float4 *x4, const int32_t *nbr, int64_t N, float *ew,
+                         hipStream_t s) {
+    if (N == 0) return TD_OK;
+    const int64_t total = N * TD_K;
+    layer_gate_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(w, offsets, coeff, x4, nbr, N, ew);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}

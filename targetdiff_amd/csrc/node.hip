@@ -537,9 +537,13 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
 // h_i += W2 SiLU(W1 [mi | h_i] + b1) + b2   (models/egnn.py:56, node_mlp = Linear(256,128) -> SiLU -> Linear(128,128)).
 // Same decomposition as node_proj_kernel: 32 rows per wave, A tiles in registers, B staged through LDS; the 256-deep first
 // Linear is two 128-deep GEMMs into one accumulator (mi tile, then h tile).
+// LN = true: node_output of BaseX2HAttLayer with out_fc (models/uni_transformer.py:39-40, 81-84): h_i += W2 relu(LayerNorm(W1 [out_i | h_i]
+// + b1)) + b2, `mi` = the attention output of the row, gamma / beta = the MLP's LayerNorm affine.
+template <bool LN>
 __global__ __launch_bounds__(256, 2) void egnn_node_kernel(const float4 *__restrict__ B, const float *__restrict__ b1,
                                                            const float *__restrict__ b2, const float *__restrict__ mi,
-                                                           float *__restrict__ h, int64_t N) {
+                                                           float *__restrict__ h, int64_t N, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float4 *bufs = reinterpret_cast<float4 *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -567,13 +571,28 @@ __global__ __launch_bounds__(256, 2) void egnn_node_kernel(const float4 *__restr
     for (int m = 0; m < 16; ++m)
         a[m] = arow >= 0 ? *reinterpret_cast<const float4 *>(h + arow * TD_H + 8 * m + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
     gemm128_lds(a, B1, B2, bufs, cur, tid, lane, acc);
-    // SiLU, then C layout -> A layout through the wave-private tile
+    if constexpr (LN) {          // LayerNorm over the row's 128 columns (4 tiles x the 32 lanes of a half-wave) + ReLU, in place
+        float gam[4], bet[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { gam[t] = gamma[32 * t + c]; bet[t] = beta[32 * t + c]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float mean = td_sum32((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) * (1.0f / TD_H);
+            const float d0 = acc[0][r] - mean, d1 = acc[1][r] - mean, d2 = acc[2][r] - mean, d3 = acc[3][r] - mean;
+            const float rstd = __frsqrt_rn(td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H) + 1e-5f);
+            acc[0][r] = fmaxf(d0 * rstd * gam[0] + bet[0], 0.f);
+            acc[1][r] = fmaxf(d1 * rstd * gam[1] + bet[1], 0.f);
+            acc[2][r] = fmaxf(d2 * rstd * gam[2] + bet[2], 0.f);
+            acc[3][r] = fmaxf(d3 * rstd * gam[3] + bet[3], 0.f);
+        }
+    }
+    // SiLU (EGNN), then C layout -> A layout through the wave-private tile
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = acc[t][r];
-            tb[td_erow(r, hi) * NP_TSTRIDE + c] = v * __frcp_rn(1.0f + __expf(-v));
+            tb[td_erow(r, hi) * NP_TSTRIDE + c] = LN ? v : v * __frcp_rn(1.0f + __expf(-v));
         }
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) a[4 * t + mm] = *reinterpret_cast<const float4 *>(tb + c * NP_TSTRIDE + 8 * mm + 4 * hi);
@@ -599,9 +618,21 @@ __global__ __launch_bounds__(256, 2) void egnn_node_kernel(const float4 *__restr
 int td_launch_egnn_node(const TdEgnnLayer &L, const float *mi, float *h, int64_t N, hipStream_t s) {
     if (N == 0) return TD_OK;
     int rc;
-    if ((rc = td_set_lds(g_egnn_node_lds, reinterpret_cast<const void *>(egnn_node_kernel), NP_LDS_BYTES)) != TD_OK) return rc;
-    egnn_node_kernel<<<dim3((unsigned)((N + 127) / 128)), dim3(256), NP_LDS_BYTES, s>>>(
-        reinterpret_cast<const float4 *>(L.nodeB), L.nb1, L.nb2, mi, h, N);
+    if ((rc = td_set_lds(g_egnn_node_lds, reinterpret_cast<const void *>(egnn_node_kernel<false>), NP_LDS_BYTES)) != TD_OK) return rc;
+    egnn_node_kernel<false><<<dim3((unsigned)((N + 127) / 128)), dim3(256), NP_LDS_BYTES, s>>>(
+        reinterpret_cast<const float4 *>(L.nodeB), L.nb1, L.nb2, mi, h, N, nullptr, nullptr);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// node_output of an x2h stage with out_fc: h += MLP([out | h]) on every row (fp32 MFMA; a non-default configuration)
+int td_launch_node_output(const TdNodeOut &no, const float *out, float *h, int64_t N, hipStream_t s) {
+    if (N == 0) return TD_OK;
+    static TdLdsOnce once;
+    int rc;
+    if ((rc = td_set_lds(once, reinterpret_cast<const void *>(egnn_node_kernel<true>), NP_LDS_BYTES)) != TD_OK) return rc;
+    egnn_node_kernel<true><<<dim3((unsigned)((N + 127) / 128)), dim3(256), NP_LDS_BYTES, s>>>(
+        reinterpret_cast<const float4 *>(no.B), no.b1, no.b2, out, h, N, no.gamma, no.beta);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

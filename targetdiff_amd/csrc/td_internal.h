@@ -81,9 +81,17 @@ struct TdNodeStage {
     bool async_copy;         // split kernel: B chunks by inline-asm global_load_lds + explicit wait (model option "node_proj_async", default)
 };
 
+// node_output MLP of an x2h stage with out_fc (models/uni_transformer.py:39-40): Linear(256, 128) -> LayerNorm -> ReLU -> Linear(128, 128)
+struct TdNodeOut {
+    const float *B;        // 3 x B fragments (pack_B128): net.0[:, 0:128] (attention output), net.0[:, 128:256] (h), net.3
+    const float *b1, *gamma, *beta, *b2;
+};
+
 struct TdLayer {
     TdNodeStage nodeX2h, nodeH2x;
     TdEdgeMlp hk, hv, xk, xv;
+    const float *ew_x2h, *ew_h2x;   // ew_net_type 'r' / 'none': [4 types][20] + bias of the stage's gate (nullptr: the global gate)
+    TdNodeOut nodeOut;              // x2h_out_fc (B == nullptr: off)
     const float *offsets;  // [20] Gaussian centres of this layer (models/common.py:15)
     float coeff;           // -0.5 / (offset[1]-offset[0])^2
 };
@@ -222,6 +230,9 @@ int td_launch_node_proj_pair(const TdNodeStage &hx, const int32_t *hop_rows, con
                              const int32_t *lig_rows, int64_t Nl, float *Px, float *qx, const TdNodeStage &nx,
                              const int32_t *rows, const int32_t *count_ptr, float *P, float *q, const float *h, int64_t N,
                              hipStream_t s);
+int td_launch_node_output(const TdNodeOut &no, const float *out, float *h, int64_t N, hipStream_t s);
+int td_launch_layer_gate(const float *w, const float *offsets, float coeff, const float4 *x4, const int32_t *nbr, int64_t N, float *ew,
+                         hipStream_t s);
 // gate.hip -- rows: optional row list; chunk_node: dst node of every row of nbr / ew on general graphs (nullptr: row == node)
 int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_t N, const int32_t *rows,
                    const int32_t *count_ptr, float *ew, hipStream_t s, const int32_t *chunk_node = nullptr);
@@ -240,7 +251,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig_rows, int64_t lig_count,
                            hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0,
-                           const int32_t *mixed_count = nullptr);
+                           const int32_t *mixed_count = nullptr, float *out = nullptr);
 int td_set_wg_trace(unsigned long long *buf, int slots);
 bool td_wg_trace_armed();
 // graph.hip, general graphs

@@ -95,29 +95,45 @@ class _MLPParams(nn.Module):
         raise RuntimeError('parameter holder: the arithmetic runs in libtargetdiff_hip.so')
 
 
+class _GateParams(nn.Sequential):
+    """``ew_net`` of a stage with ew_net_type 'r': Linear(4 * num_r_gaussian, 1) + Sigmoid (models/uni_transformer.py:34-35, 102-103)."""
+
+    def __init__(self, r_feat_dim):
+        super().__init__(nn.Linear(r_feat_dim, 1), nn.Sigmoid())
+
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter holder: the arithmetic runs in libtargetdiff_hip.so')
+
+
 class _X2HParams(nn.Module):
-    def __init__(self, hidden, heads, kv_in):
+    def __init__(self, hidden, heads, kv_in, r_feat_dim=80, ew_net_type='global', out_fc=False):
         super().__init__()
         self.hk_func = _MLPParams(kv_in, hidden, hidden)
         self.hv_func = _MLPParams(kv_in, hidden, hidden)
         self.hq_func = _MLPParams(hidden, hidden, hidden)
+        if ew_net_type == 'r':
+            self.ew_net = _GateParams(r_feat_dim)
+        if out_fc:
+            self.node_output = _MLPParams(2 * hidden, hidden, hidden)
 
 
 class _H2XParams(nn.Module):
-    def __init__(self, hidden, heads, kv_in):
+    def __init__(self, hidden, heads, kv_in, r_feat_dim=80, ew_net_type='global'):
         super().__init__()
         self.xk_func = _MLPParams(kv_in, hidden, hidden)
         self.xv_func = _MLPParams(kv_in, heads, hidden)
         self.xq_func = _MLPParams(hidden, hidden, hidden)
+        if ew_net_type == 'r':
+            self.ew_net = _GateParams(r_feat_dim)
 
 
 class _AttLayerParams(nn.Module):
-    def __init__(self, hidden, heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x):
+    def __init__(self, hidden, heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x, ew_net_type='global', out_fc=False):
         super().__init__()
         kv_in = 2 * hidden + edge_feat_dim + 4 * num_r_gaussian
         self.distance_expansion = _Offsets(num_r_gaussian)
-        self.x2h_layers = nn.ModuleList([_X2HParams(hidden, heads, kv_in) for _ in range(num_x2h)])
-        self.h2x_layers = nn.ModuleList([_H2XParams(hidden, heads, kv_in) for _ in range(num_h2x)])
+        self.x2h_layers = nn.ModuleList([_X2HParams(hidden, heads, kv_in, 4 * num_r_gaussian, ew_net_type, out_fc) for _ in range(num_x2h)])
+        self.h2x_layers = nn.ModuleList([_H2XParams(hidden, heads, kv_in, 4 * num_r_gaussian, ew_net_type) for _ in range(num_h2x)])
 
 
 class UniTransformerO2TwoUpdateGeneral(nn.Module):
@@ -131,10 +147,13 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         unsupported = []
         if not 1 <= int(num_blocks) <= 8: unsupported.append(f'num_blocks={num_blocks} (1..8)')
         if cutoff_mode not in capi.CUTOFF_MODES: unsupported.append(f'cutoff_mode={cutoff_mode!r}')
-        if ew_net_type != 'global': unsupported.append(f'ew_net_type={ew_net_type!r}')
+        if ew_net_type == 'm': unsupported.append("ew_net_type='m' (the gate from the value vectors)")
+        if ew_net_type != 'global' and (cutoff_mode not in ('knn', 'radius') or (cutoff_mode == 'knn' and k > 32) or
+                                        (cutoff_mode == 'radius' and max_num_neighbors > 32)):
+            unsupported.append(f'ew_net_type={ew_net_type!r} on a graph wider than 32 slots per node')
         if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
         if num_x2h != 1 or num_h2x != 1: unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x}')
-        if x2h_out_fc or sync_twoup: unsupported.append(f'x2h_out_fc={x2h_out_fc}/sync_twoup={sync_twoup}')
+        if sync_twoup: unsupported.append(f'sync_twoup={sync_twoup}')
         if (hidden_dim, n_heads, num_r_gaussian, edge_feat_dim) != (128, 16, 20, 4):
             unsupported.append(f'shape {(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim)}')
         if not 1 <= k <= capi.MAX_FANIN: unsupported.append(f'knn={k} (1..{capi.MAX_FANIN})')
@@ -154,15 +173,16 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
                           'oracle/shims.py only, not to torch_cluster.radius_graph.', stacklevel=3)
         self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
         self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
-        self.cutoff_mode, self.ew_net_type = cutoff_mode, ew_net_type
+        self.cutoff_mode, self.ew_net_type, self.x2h_out_fc = cutoff_mode, ew_net_type, bool(x2h_out_fc)
         self.distance_expansion = _Offsets(num_r_gaussian)
-        self.edge_pred_layer = _MLPParams(num_r_gaussian, 1, hidden_dim)
+        if ew_net_type == 'global':                                  # :241-242 (the per-stage gates of 'r' live in the layers)
+            self.edge_pred_layer = _MLPParams(num_r_gaussian, 1, hidden_dim)
         # built by the reference with (num_init_x2h, num_init_h2x) and never called (uni_transformer.py:245 vs
         # :301-328); kept so that checkpoints load with strict=True.
         self.init_h_emb_layer = _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim,
-                                                num_init_x2h, num_init_h2x)
+                                                num_init_x2h, num_init_h2x, ew_net_type, bool(x2h_out_fc))
         self.base_block = nn.ModuleList([
-            _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x)
+            _AttLayerParams(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim, num_x2h, num_h2x, ew_net_type, bool(x2h_out_fc))
             for _ in range(num_layers)])
         self._owner = None       # set by ScorePosNet3D: the module that owns the packed native weights
 
@@ -375,6 +395,7 @@ class ScorePosNet3D(nn.Module):
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             cfg['model_mean_type'] = self.model_mean_type
             cfg['num_blocks'] = int(rn.num_blocks)
+            cfg['ew_net_type'], cfg['x2h_out_fc'] = rn.ew_net_type, rn.x2h_out_fc
             sd = self.state_dict()
             if self.time_emb_dim > 0:         # the kernels embed the one-hot part; the time columns go through _time_bias
                 sd = dict(sd)

@@ -159,3 +159,63 @@ def test_layernorm_weights_of_every_sign_vs_reference():
     # the all-positive weights give something else
     one = _model(weights.make_state_dict(SEED))(*args)
     assert _maxdiff(one['pred_ligand_v'], g['pred_ligand_v']) > 1e-3
+
+
+@pytest.mark.parametrize('name,over', [('forward_ew_r_out_fc.npz', dict(ew_net_type='r', x2h_out_fc=True)),
+                                       ('forward_ew_none.npz', dict(ew_net_type='none')),
+                                       ('forward_out_fc.npz', dict(x2h_out_fc=True))])
+def test_gate_and_output_options_vs_reference(name, over):
+    """ew_net_type = 'r' (every stage's own gate on the layer's radial features), any value that means e_w = 1, and x2h_out_fc = True
+    (node_output([attention output | h]) + h) -- 'r' + out_fc are the reference CLASS's defaults (models/uni_transformer.py:146-148,
+    212-214), configs/training.yml uses 'global' / False.  Forward and fix_x against fixtures of the real reference; strict state_dict."""
+    from oracle import weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    g = load_golden(name)
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    cfg.update(over)
+    sd = weights.make_state_dict(SEED, cfg)
+    model = _model(sd, **over)
+    learnable = {k for k, p in model.named_parameters() if p.requires_grad and not k.startswith('refine_net.init_h_emb_layer')}
+    assert learnable <= set(sd), sorted(learnable - set(sd))[:4]          # every parameter of the mirror came from the reference's keys
+    assert ('refine_net.edge_pred_layer.net.0.weight' in dict(model.named_parameters())) == (over.get('ew_net_type', 'global') == 'global')
+    b = small_batch()[0].to(dev)
+    args = (torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
+            torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch)
+    p = model(*args)
+    d = {k: _maxdiff(p[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h', 'final_h')}
+    print(name, d)
+    assert d['pred_ligand_pos'] <= TOL_X and d['pred_ligand_v'] <= TOL_H and d['final_ligand_h'] <= TOL_H and d['final_h'] <= TOL_H
+    f = model(*args, fix_x=True)
+    assert _maxdiff(f['final_ligand_h'], g['fix_x_final_ligand_h']) <= TOL_H
+    assert torch.equal(f['pred_ligand_pos'].cpu(), torch.from_numpy(g['ligand_pos']))
+    base = _model(weights.make_state_dict(SEED))(*args)            # configs/training.yml's options give something else
+    assert _maxdiff(base['pred_ligand_v'], g['pred_ligand_v']) > 1e-3
+
+
+def test_gate_and_output_options_sampling_vs_reference():
+    """4 reverse steps of the reference's loop with ew_net_type = 'r' and x2h_out_fc = True: the session (which does not cache with these
+    options), launch by launch, and the stateless forward -- same trajectory, and the reference's."""
+    from oracle import draws, weights
+    from oracle.make_golden import SEED, small_batch
+    dev = _dev()
+    over = dict(ew_net_type='r', x2h_out_fc=True)
+    cfg = dict(weights.DEFAULT_MODEL_CONFIG)
+    cfg.update(over)
+    model = _model(weights.make_state_dict(SEED, cfg), **over)
+    gs = load_golden('sample_ew_r_out_fc_4.npz')
+    b = small_batch()[0].to(dev)
+    outs = []
+    for kw in (dict(), dict(use_graph=False), dict(use_session=False)):
+        r = model.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                                   torch.from_numpy(gs['init_ligand_pos']).to(dev), torch.from_numpy(gs['init_ligand_v']).to(dev),
+                                   b.ligand_element_batch, num_steps=int(gs['steps']), center_pos_mode='protein',
+                                   noise_source=draws.Source(int(gs['draws_base']), dev), **kw)
+        assert np.array_equal(torch.stack(r['v_traj']).numpy(), gs['v_traj'].astype(np.int64)), kw
+        assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
+        outs.append(r)
+    assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[2]['pos_traj']))
+    with pytest.raises(NotImplementedError, match="'m'"):
+        _model(weights.make_state_dict(SEED), ew_net_type='m')
+    with pytest.raises(NotImplementedError, match='32 slots'):
+        _model(weights.make_state_dict(SEED), ew_net_type='r', knn=48)
