@@ -80,7 +80,8 @@ typedef struct td_config {
     int32_t ew_net_type;         /* 0 = 'global' (configs/training.yml: one gate MLP on the step-start distances), 1 = 'r' (every x2h / h2x
                                     stage has its own Linear(4 x 20 -> 1) + sigmoid on the layer's radial features,
                                     models/uni_transformer.py:34-35, 60-61, 102-103, 124-125), 2 = none (any other value of the
-                                    reference's option except 'm': e_w = 1).  'r' / none: default graph only, sessions do not cache */
+                                    reference's option: e_w = 1), 3 = 'm' (x2h: sigmoid(Linear(128 -> 1)) of the edge's value vector,
+                                    :36-37, 62-63; h2x: e_w = 1, :126-127).  Other than 'global': default graph only, sessions do not cache */
     int32_t x2h_out_fc;          /* 1: h += node_output([attention output | h]) after every x2h stage (models/uni_transformer.py:39-40,
                                     81-84; the reference class's default, False in configs/training.yml); sessions do not cache */
 } td_config;                     /* (the last two fields were `reserved[2]`, to be zero, until round 4: same size, same defaults) */

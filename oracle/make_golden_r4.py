@@ -12,9 +12,10 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
       edge gate rebuilt from the moved coordinates in between): forward on the small batch, 4 reverse steps.
   forward_ln_signs.npz       the default architecture with LayerNorm weights of every sign (oracle.weights.ln_signs_state_dict: negative,
       zero and tiny entries in every MLP): forward (return_all) on the small batch.  Pins the LayerNorm fold of the packed edge MLPs.
-  forward_ew_r_out_fc.npz / forward_ew_none.npz / forward_out_fc.npz / sample_ew_r_out_fc_4.npz   the gate and output options of the
+  forward_ew_r_out_fc.npz / forward_ew_none.npz / forward_out_fc.npz / forward_ew_m.npz / sample_ew_r_out_fc_4.npz   the gate and output options of the
       attention layers outside configs/training.yml: ew_net_type = 'r' (every stage's own Linear(80, 1) + sigmoid on the layer's radial
-      features, models/uni_transformer.py:34-35, 60-61, 102-103, 124-125), anything else but 'global' / 'm' (e_w = 1, :64-67), and
+      features, models/uni_transformer.py:34-35, 60-61, 102-103, 124-125), 'm' (the x2h gate from the edge's value vector, :36-37, 62-63),
+      anything else but 'global' (e_w = 1, :64-67), and
       x2h_out_fc = True (node_output([attention output | h]) + h, :39-40, 81-84).  'r' + out_fc are the reference CLASS's defaults.
 Weights: oracle.weights.time_emb_state_dict / make_state_dict(seed, cfg) (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
@@ -145,6 +146,7 @@ def main():
     gen_forward_options(ref, 'forward_ew_r_out_fc.npz', ew_net_type='r', x2h_out_fc=True)
     gen_forward_options(ref, 'forward_ew_none.npz', ew_net_type='none')
     gen_forward_options(ref, 'forward_out_fc.npz', x2h_out_fc=True)
+    gen_forward_options(ref, 'forward_ew_m.npz', ew_net_type='m')
     gen_sample(ref, 'sample_ew_r_out_fc_4.npz', 4600, ew_net_type='r', x2h_out_fc=True)
 
 

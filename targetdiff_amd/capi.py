@@ -184,19 +184,17 @@ def _on(device):
 MLP_KEYS = ('net.0.weight', 'net.0.bias', 'net.1.weight', 'net.1.bias', 'net.3.weight', 'net.3.bias')
 
 
-EW_NET_TYPES = {'global': 0, 'r': 1}                      # td_config.ew_net_type; anything else but 'm' = 2 (e_w = 1)
+EW_NET_TYPES = {'global': 0, 'r': 1, 'm': 3}              # td_config.ew_net_type; anything else = 2 (e_w = 1)
 
 
 def ew_net_code(ew_net_type) -> int:
-    if ew_net_type == 'm':
-        raise NotImplementedError("ew_net_type='m' (the gate from the value vectors, models/uni_transformer.py:36-37, 62-63) is not built")
     return EW_NET_TYPES.get(ew_net_type, 2)
 
 
 def flat_key_order(num_layers: int, ew_net_type='global', x2h_out_fc=False):
     """Order of the reference state_dict tensors inside the flat blob td_model_create consumes
     (key names: SURVEY.md Appendix C; init_h_emb_layer and the schedule constants are not part of it).  Per layer: offsets, hk, hv, hq,
-    [node_output (x2h_out_fc)], [x2h ew_net ('r')], xk, xv, xq, [h2x ew_net ('r')]; the global gate MLP only with ew_net_type 'global'."""
+    [node_output (x2h_out_fc)], [x2h ew_net ('r': 80 + 1, 'm': 128 + 1)], xk, xv, xq, [h2x ew_net ('r')]; the global gate MLP only with ew_net_type 'global'."""
     keys = ['protein_atom_emb.weight', 'protein_atom_emb.bias', 'ligand_atom_emb.weight', 'ligand_atom_emb.bias',
             'refine_net.distance_expansion.offset']
     if ew_net_type == 'global':
@@ -208,7 +206,7 @@ def flat_key_order(num_layers: int, ew_net_type='global', x2h_out_fc=False):
             keys += [f'{p}.{f}.{k}' for k in MLP_KEYS]
         if x2h_out_fc:
             keys += [f'{p}.x2h_layers.0.node_output.{k}' for k in MLP_KEYS]
-        if ew_net_type == 'r':
+        if ew_net_type in ('r', 'm'):
             keys += [f'{p}.x2h_layers.0.ew_net.0.weight', f'{p}.x2h_layers.0.ew_net.0.bias']
         for f in ('h2x_layers.0.xk_func', 'h2x_layers.0.xv_func', 'h2x_layers.0.xq_func'):
             keys += [f'{p}.{f}.{k}' for k in MLP_KEYS]

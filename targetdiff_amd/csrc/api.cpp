@@ -424,6 +424,7 @@ extern "C" size_t td_model_num_weights(const td_config *cfg) {
     n += (size_t)c.num_layers * (c.num_r_gaussian + 2 * mlp_floats(KV, H, H) + 2 * mlp_floats(H, H, H) +
                                  mlp_floats(KV, H, H) + mlp_floats(KV, H, c.n_heads));
     if (c.ew_net_type == 1) n += (size_t)c.num_layers * 2 * (4 * c.num_r_gaussian + 1);       // the two stages' ew_net
+    if (c.ew_net_type == 3) n += (size_t)c.num_layers * (H + 1);                                // 'm': the x2h stage's ew_net
     if (c.x2h_out_fc) n += (size_t)c.num_layers * mlp_floats(2 * H, H, H);                     // node_output
     n += (size_t)H * H + H + (size_t)c.ligand_num_classes * H + c.ligand_num_classes;
     return n;
@@ -456,13 +457,13 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         td_set_error("td_model_create: num_blocks must be 1 .. 8 (0 = 1), got %d", c.num_blocks);
         return TD_EINVAL;
     }
-    if (c.ew_net_type < 0 || c.ew_net_type > 2 || (c.x2h_out_fc != 0 && c.x2h_out_fc != 1)) {
-        td_set_error("td_model_create: ew_net_type must be 0 ('global'), 1 ('r') or 2 (none), x2h_out_fc 0 or 1; got %d / %d",
+    if (c.ew_net_type < 0 || c.ew_net_type > 3 || (c.x2h_out_fc != 0 && c.x2h_out_fc != 1)) {
+        td_set_error("td_model_create: ew_net_type must be 0 ('global'), 1 ('r'), 2 (none) or 3 ('m'), x2h_out_fc 0 or 1; got %d / %d",
                      c.ew_net_type, c.x2h_out_fc);
         return TD_EINVAL;
     }
     if (c.ew_net_type != 0 && !default_graph(c)) {
-        td_set_error("td_model_create: ew_net_type 'r' / none runs on the 32-slot graphs only (knn <= 32, or radius with a cap <= 32)");
+        td_set_error("td_model_create: ew_net_type 'r' / 'm' / none runs on the 32-slot graphs only (knn <= 32, or radius with a cap <= 32)");
         return TD_EINVAL;
     }
     if (c.model_mean_type != 0 && c.model_mean_type != 1) {
@@ -528,7 +529,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             }
     }
     // ---- layers
-    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; size_t ew_x2h = 0, ew_h2x = 0, noB = 0, nob1 = 0, nog = 0, nobeta = 0, nob2 = 0; };
+    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; size_t ew_x2h = 0, ew_h2x = 0, gate_m = 0, noB = 0, nob1 = 0, nog = 0, nobeta = 0, nob2 = 0; };
     std::vector<LayerOff> lo(L);
     for (int l = 0; l < L; ++l) {
         const float *off = cur.take(TD_NG);
@@ -537,10 +538,14 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         MlpSrc nout{};
         if (c.x2h_out_fc) nout = cur.mlp(2 * H, H, H);
         const float *ewx = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
+        const float *ewm = c.ew_net_type == 3 ? cur.take(H + 1) : nullptr;
         MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
         const float *ewh = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
         if (!cur.ok) break;
-        if (c.ew_net_type != 0) {            // [4 types][20] + bias per stage; none: sigmoid(40) = 1.0f
+        // the four edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
+        const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H), fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
+        hk = fhk.src(); hv = fhv.src(); xk = fxk.src(); xv = fxv.src();
+        if (c.ew_net_type != 0) {            // [4 types][20] + bias per stage; 'm' and none: sigmoid(40) = 1.0f
             lo[l].ew_x2h = pk.alloc(4 * TD_NG + 1);
             lo[l].ew_h2x = pk.alloc(4 * TD_NG + 1);
             if (c.ew_net_type == 1) {
@@ -551,6 +556,17 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
                 pk.data[lo[l].ew_h2x + 4 * TD_NG] = 40.f;
             }
         }
+        if (ewm) {          // u'_n = sum_o w_m[o] W2v'[o][n] on the FOLDED second Linear (its columns carry |gamma_n|), c = w_m . b2v + b_m
+            lo[l].gate_m = pk.alloc(TD_H + 1);
+            double cc = ewm[H];
+            for (int o = 0; o < H; ++o) cc += (double)ewm[o] * (double)fhv.b3[o];
+            for (int n = 0; n < H; ++n) {
+                double u = 0.0;
+                for (int o = 0; o < H; ++o) u += (double)ewm[o] * (double)fhv.w3[(size_t)o * H + n];
+                pk.data[lo[l].gate_m + n] = (float)u;
+            }
+            pk.data[lo[l].gate_m + H] = (float)cc;
+        }
         if (c.x2h_out_fc) {
             lo[l].noB = pack_B128(pk, nout.w0, 2 * TD_H, 0);           // the attention-output half of net.0 (cat([output, h]), :83)
             pack_B128(pk, nout.w0, 2 * TD_H, TD_H);                    // the h half (consecutive blocks)
@@ -560,9 +576,6 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             lo[l].nobeta = pack_vec(pk, nout.b, TD_H);
             lo[l].nob2 = pack_vec(pk, nout.b3, TD_H);
         }
-        // the four edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
-        const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H), fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
-        hk = fhk.src(); hv = fhv.src(); xk = fxk.src(); xv = fxv.src();
         lo[l].off = pack_vec(pk, off, TD_NG);
         lo[l].coeff = gaussian_coeff(off);
         lo[l].nx = pack_node_stage(pk, hk, hv, hq, KV);
@@ -618,6 +631,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
         Ly.ew_x2h = c.ew_net_type != 0 ? D + lo[l].ew_x2h : nullptr;
         Ly.ew_h2x = c.ew_net_type != 0 ? D + lo[l].ew_h2x : nullptr;
+        Ly.gate_m = c.ew_net_type == 3 ? D + lo[l].gate_m : nullptr;
         Ly.nodeOut = c.x2h_out_fc ? TdNodeOut{D + lo[l].noB, D + lo[l].nob1, D + lo[l].nog, D + lo[l].nobeta, D + lo[l].nob2}
                                   : TdNodeOut{nullptr, nullptr, nullptr, nullptr, nullptr};
     }
@@ -740,7 +754,7 @@ int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const G
                const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig,
                int64_t Nl, hipStream_t s, float *out = nullptr) {
     return td_launch_edge_value16(mlp, L, x4, nbr, P, rows, count_ptr, count, h, alpha, lig, Nl, s, gt.cptr, gt.cpn_p,
-                                  lig ? gt.NCl : 0, gt.mixed, out);
+                                  lig ? gt.NCl : 0, gt.mixed, out, L.gate_m);
 }
 
 // h2x stage, projections in one launch: src-side (k_j, v_j) of the nodes a ligand atom can see -- `hop_rows` (the

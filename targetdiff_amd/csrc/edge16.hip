@@ -39,6 +39,7 @@ struct Args16 {
     const int32_t *rows;
     const int32_t *count_ptr;
     float *h;
+    const float *gate_m;       // value pass, ew_net_type 'm': u' [128] = folded W2v^T w_m, then c = w_m . b2v + b_m (the gate from the value vector)
     float *out;                // value pass, x2h_out_fc: the attention output goes here WITHOUT the residual (nullptr: h += output)
     float *alpha;
     float4 *x4_out;            // XV mode: updated coordinates of the dst (ligand) nodes
@@ -935,7 +936,11 @@ constexpr size_t V16S_LDS_BYTES =
 constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // CHUNKED = true (general graphs): a dst node's in-edges are the chunks cptr[i] .. cptr[i+1]-1; alpha (already normalised over
 // the whole node and gated by the key pass) is indexed by chunk; Zbar accumulates over the chunks, then one output product.
-template <bool SPLIT, bool CHUNKED = false>
+// GATE_M (ew_net_type 'm', default graph only): the edge gate is e_w = sigmoid(Linear(128 -> 1)(v_e)) of the edge's VALUE vector
+// (models/uni_transformer.py:36-37, 62-63).  v_e = W2v z_e + b2v is never formed here; the gate's logit is linear in it, so it is
+// (W2v^T w) . z_e + (w . b2v + b) -- one 128-wide dot product with a vector packed at model creation --, and since the gate multiplies v_e,
+// which enters the output linearly, it multiplies the attention weight instead: alpha_e e_w_e feeds both the aggregation and S.
+template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
@@ -949,11 +954,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS;
     // the attention weights of the aggregation product (A operand: edge 8g + s, head lo) times the edges' 1 / sigma, which the first
     // layer leaves in the lanes of the z^T layout (edge 16eb + lo): 32 floats through the wave's own LDS
-    auto scale_alpha = [&](float (&alx)[8], const Edge2 &ed) {
-        if (g < 2) RS[16 * g + lo] = g == 0 ? ed.rstd[0] : ed.rstd[1];
+    auto scale_edges = [&](float (&alx)[8], float v0, float v1) {          // alx[s] *= v of edge 8g + s (v0 / v1: the lane's two edges)
+        if (g < 2) RS[16 * g + lo] = g == 0 ? v0 : v1;
         const float4 r0 = *reinterpret_cast<const float4 *>(RS + 8 * g), r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
         alx[0] *= r0.x; alx[1] *= r0.y; alx[2] *= r0.z; alx[3] *= r0.w; alx[4] *= r1.x; alx[5] *= r1.y; alx[6] *= r1.z; alx[7] *= r1.w;
     };
+    auto scale_alpha = [&](float (&alx)[8], const Edge2 &ed) { scale_edges(alx, ed.rstd[0], ed.rstd[1]); };
     const float *KB = B2 + TD_H;                          // beta / |gamma| of the folded LayerNorm (td_ln_relu16)
     // SPLIT: workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0)
     int my_cls = 1, GL = 0;
@@ -1245,6 +1251,23 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
 
+        if constexpr (GATE_M) {          // e_w = sigmoid((u' . z'_e) / sigma_e + c), multiplied into alpha before S is taken
+            float part[2] = {0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                const float4 u4 = *reinterpret_cast<const float4 *>(a.gate_m + 16 * hb + 4 * g);
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    part[eb] = fmaf(acc[eb][hb][0], u4.x, part[eb]); part[eb] = fmaf(acc[eb][hb][1], u4.y, part[eb]);
+                    part[eb] = fmaf(acc[eb][hb][2], u4.z, part[eb]); part[eb] = fmaf(acc[eb][hb][3], u4.w, part[eb]);
+                }
+            }
+            const float cm = a.gate_m[TD_H];
+            float gm[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) gm[eb] = 1.0f / (1.0f + expf(-fmaf(td_sum_groups(part[eb]), ed.rstd[eb], cm)));
+            scale_edges(al, gm[0], gm[1]);
+        }
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
         if (lane < TD_HEADS) SB[lane] = ssum;
@@ -1519,7 +1542,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha,
                            const int32_t *lig_rows, int64_t lig_count, hipStream_t s, const int32_t *cptr, int cpn_p,
-                           int64_t lig_chunks, const int32_t *mixed_count, float *out) {
+                           int64_t lig_chunks, const int32_t *mixed_count, float *out, const float *gate_m) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = nullptr; a.P = P; a.q = nullptr; a.rows = rows; a.count_ptr = count_ptr; a.h = h;
@@ -1527,6 +1550,7 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     a.coeff = L.coeff; a.p_off = 2 * TD_H; a.cptr = cptr; a.cpn_p = cpn_p > 0 ? cpn_p : 1; a.lig_chunks = lig_chunks;
     a.mixed_count = mixed_count;
     a.out = out;
+    a.gate_m = cptr ? nullptr : gate_m;          // (ew_net_type 'm' is accepted on the default graph only)
     int G = grid16(count, V16_WAVES);
     const dim3 block(V16_WAVES * 64);
     a.trace = wg_trace_slot(1);
@@ -1537,6 +1561,9 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
         if (cptr) {
             TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
             edge_value16_kernel<true, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+        } else if (gate_m) {
+            TD_LDS_ONCE((edge_value16_kernel<true, false, true>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
         } else {
             TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
@@ -1544,6 +1571,9 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     } else if (cptr) {
         TD_LDS_ONCE((edge_value16_kernel<false, true>), V16_LDS_BYTES);
         edge_value16_kernel<false, true><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);
+    } else if (gate_m) {
+        TD_LDS_ONCE((edge_value16_kernel<false, false, true>), V16_LDS_BYTES);
+        edge_value16_kernel<false, false, true><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);
     } else {
         TD_LDS_ONCE((edge_value16_kernel<false, false>), V16_LDS_BYTES);
         edge_value16_kernel<false, false><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);

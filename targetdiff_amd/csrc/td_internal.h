@@ -90,7 +90,9 @@ struct TdNodeOut {
 struct TdLayer {
     TdNodeStage nodeX2h, nodeH2x;
     TdEdgeMlp hk, hv, xk, xv;
-    const float *ew_x2h, *ew_h2x;   // ew_net_type 'r' / 'none': [4 types][20] + bias of the stage's gate (nullptr: the global gate)
+    const float *ew_x2h, *ew_h2x;   // ew_net_type 'r' / 'm' / none: [4 types][20] + bias of the stage's gate (nullptr: the global gate; 'm' and none:
+                                    // zero weights and a bias of 40, i.e. e_w = 1 -- 'm' gates in the value pass instead)
+    const float *gate_m;            // ew_net_type 'm': [128] folded W2v^T w_m, then w_m . b2v + b_m (nullptr: off)
     TdNodeOut nodeOut;              // x2h_out_fc (B == nullptr: off)
     const float *offsets;  // [20] Gaussian centres of this layer (models/common.py:15)
     float coeff;           // -0.5 / (offset[1]-offset[0])^2
@@ -251,7 +253,7 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
 int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *P,
                            const int32_t *rows, const int32_t *count_ptr, int64_t count, float *h, const float *alpha, const int32_t *lig_rows, int64_t lig_count,
                            hipStream_t s, const int32_t *cptr = nullptr, int cpn_p = 1, int64_t lig_chunks = 0,
-                           const int32_t *mixed_count = nullptr, float *out = nullptr);
+                           const int32_t *mixed_count = nullptr, float *out = nullptr, const float *gate_m = nullptr);
 int td_set_wg_trace(unsigned long long *buf, int slots);
 bool td_wg_trace_armed();
 // graph.hip, general graphs

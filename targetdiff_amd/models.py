@@ -113,6 +113,8 @@ class _X2HParams(nn.Module):
         self.hq_func = _MLPParams(hidden, hidden, hidden)
         if ew_net_type == 'r':
             self.ew_net = _GateParams(r_feat_dim)
+        elif ew_net_type == 'm':                                     # the gate from the value vector (:36-37)
+            self.ew_net = _GateParams(hidden)
         if out_fc:
             self.node_output = _MLPParams(2 * hidden, hidden, hidden)
 
@@ -147,7 +149,6 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         unsupported = []
         if not 1 <= int(num_blocks) <= 8: unsupported.append(f'num_blocks={num_blocks} (1..8)')
         if cutoff_mode not in capi.CUTOFF_MODES: unsupported.append(f'cutoff_mode={cutoff_mode!r}')
-        if ew_net_type == 'm': unsupported.append("ew_net_type='m' (the gate from the value vectors)")
         if ew_net_type != 'global' and (cutoff_mode not in ('knn', 'radius') or (cutoff_mode == 'knn' and k > 32) or
                                         (cutoff_mode == 'radius' and max_num_neighbors > 32)):
             unsupported.append(f'ew_net_type={ew_net_type!r} on a graph wider than 32 slots per node')

@@ -163,9 +163,11 @@ def test_layernorm_weights_of_every_sign_vs_reference():
 
 @pytest.mark.parametrize('name,over', [('forward_ew_r_out_fc.npz', dict(ew_net_type='r', x2h_out_fc=True)),
                                        ('forward_ew_none.npz', dict(ew_net_type='none')),
-                                       ('forward_out_fc.npz', dict(x2h_out_fc=True))])
+                                       ('forward_out_fc.npz', dict(x2h_out_fc=True)),
+                                       ('forward_ew_m.npz', dict(ew_net_type='m'))])
 def test_gate_and_output_options_vs_reference(name, over):
-    """ew_net_type = 'r' (every stage's own gate on the layer's radial features), any value that means e_w = 1, and x2h_out_fc = True
+    """ew_net_type = 'r' (every stage's own gate on the layer's radial features), 'm' (the x2h gate from the edge's value vector, which the
+    kernels never form: its logit is a dot product with the hidden activations), any value that means e_w = 1, and x2h_out_fc = True
     (node_output([attention output | h]) + h) -- 'r' + out_fc are the reference CLASS's defaults (models/uni_transformer.py:146-148,
     212-214), configs/training.yml uses 'global' / False.  Forward and fix_x against fixtures of the real reference; strict state_dict."""
     from oracle import weights
@@ -215,7 +217,5 @@ def test_gate_and_output_options_sampling_vs_reference():
         assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
         outs.append(r)
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[2]['pos_traj']))
-    with pytest.raises(NotImplementedError, match="'m'"):
-        _model(weights.make_state_dict(SEED), ew_net_type='m')
     with pytest.raises(NotImplementedError, match='32 slots'):
         _model(weights.make_state_dict(SEED), ew_net_type='r', knn=48)

@@ -56,12 +56,12 @@ def test_unsupported_config_is_rejected_not_emulated():
                          max_num_neighbors=32)
     assert lib.td_model_create(ctypes.byref(cfg3), dummy, 4, None, 0, ctypes.byref(h)) == -1      # radius mode needs r > 0
     from targetdiff_amd.models import ScorePosNet3D
-    for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='m'), dict(ew_net_type='r', knn=48), dict(ew_net_type='r', cutoff_mode='hybrid'),
+    for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='m', knn=48), dict(ew_net_type='r', knn=48), dict(ew_net_type='r', cutoff_mode='hybrid'),
                 dict(num_blocks=9), dict(sync_twoup=True), dict(hidden_dim=256)):
         with pytest.raises(NotImplementedError):
             ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **bad), 27, 13)
     # the gate / output options of the attention layers (round 4): the reference's key sets (oracle.weights mirrors the reference modules)
-    for opt in (dict(ew_net_type='r', x2h_out_fc=True), dict(ew_net_type='none'), dict(x2h_out_fc=True)):
+    for opt in (dict(ew_net_type='r', x2h_out_fc=True), dict(ew_net_type='none'), dict(x2h_out_fc=True), dict(ew_net_type='m')):
         cfgo = dict(weights.DEFAULT_MODEL_CONFIG, **opt)
         m = ScorePosNet3D(cfgo, 27, 13)
         learn = {k for k, p in m.named_parameters() if p.requires_grad}
