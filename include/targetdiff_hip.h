@@ -35,7 +35,7 @@ extern "C" {
 #define TD_ENOMEM (-2)      /* workspace too small or allocation failure */
 #define TD_EHIP (-3)        /* HIP runtime error (message in td_last_error) */
 
-#define TD_ABI_VERSION 4
+#define TD_ABI_VERSION 5
 
 typedef struct td_model td_model;
 
@@ -84,7 +84,10 @@ typedef struct td_config {
                                     :36-37, 62-63; h2x: e_w = 1, :126-127).  Other than 'global': default graph only, sessions do not cache */
     int32_t x2h_out_fc;          /* 1: h += node_output([attention output | h]) after every x2h stage (models/uni_transformer.py:39-40,
                                     81-84; the reference class's default, False in configs/training.yml); sessions do not cache */
-} td_config;                     /* (the last two fields were `reserved[2]`, to be zero, until round 4: same size, same defaults) */
+    int32_t sync_twoup;          /* 1: the h2x stage of a layer reads the layer's INPUT features instead of its x2h output
+                                    (models/uni_transformer.py:198); 0 in configs/training.yml and in the class */
+    int32_t reserved[3];         /* zero */
+} td_config;                     /* (ABI 5: the struct grew by 16 bytes; ew_net_type / x2h_out_fc took the place of ABI 4's reserved[2]) */
 
 /* ---- library ------------------------------------------------------------------------------------ */
 int td_abi_version(void);

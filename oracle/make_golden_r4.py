@@ -17,6 +17,7 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
       features, models/uni_transformer.py:34-35, 60-61, 102-103, 124-125), 'm' (the x2h gate from the edge's value vector, :36-37, 62-63),
       anything else but 'global' (e_w = 1, :64-67), and
       x2h_out_fc = True (node_output([attention output | h]) + h, :39-40, 81-84).  'r' + out_fc are the reference CLASS's defaults.
+  forward_sync_twoup.npz     sync_twoup = True: the h2x stage reads the layer's input features (:198).
 Weights: oracle.weights.time_emb_state_dict / make_state_dict(seed, cfg) (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
 
@@ -147,6 +148,7 @@ def main():
     gen_forward_options(ref, 'forward_ew_none.npz', ew_net_type='none')
     gen_forward_options(ref, 'forward_out_fc.npz', x2h_out_fc=True)
     gen_forward_options(ref, 'forward_ew_m.npz', ew_net_type='m')
+    gen_forward_options(ref, 'forward_sync_twoup.npz', sync_twoup=True)
     gen_sample(ref, 'sample_ew_r_out_fc_4.npz', 4600, ew_net_type='r', x2h_out_fc=True)
 
 

@@ -27,12 +27,12 @@ class TdConfig(ctypes.Structure):
                 ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
                 ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('cutoff_mode', c_int32), ('radius', c_float),
                 ('max_num_neighbors', c_int32), ('model_mean_type', c_int32), ('num_blocks', c_int32), ('ew_net_type', c_int32),
-                ('x2h_out_fc', c_int32)]
+                ('x2h_out_fc', c_int32), ('sync_twoup', c_int32), ('reserved', c_int32 * 3)]
 
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
 MAX_FANIN = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 # every symbol include/targetdiff_hip.h declares: (restype, argtypes)
@@ -261,7 +261,8 @@ class NativeModel:
                             cutoff_mode=CUTOFF_MODES[mode], radius=float(cfg.get('radius', 0.0)),
                             max_num_neighbors=int(cfg.get('max_num_neighbors', 32)),
                             model_mean_type=MEAN_TYPES[cfg.get('model_mean_type', 'C0')], num_blocks=int(cfg.get('num_blocks', 1) or 1),
-                            ew_net_type=ew_net_code(cfg.get('ew_net_type', 'global')), x2h_out_fc=int(bool(cfg.get('x2h_out_fc', False))))
+                            ew_net_type=ew_net_code(cfg.get('ew_net_type', 'global')), x2h_out_fc=int(bool(cfg.get('x2h_out_fc', False))),
+                            sync_twoup=int(bool(cfg.get('sync_twoup', False))))
         self.cutoff_mode, self.k = mode, int(cfg['knn'])
         self.default_graph = mode == 'knn' and self.k <= KNN       # the 32-slot fast path (and the caching session); k < 32
                                                                    # is the 32-NN row with the slots >= k masked

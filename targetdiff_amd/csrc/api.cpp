@@ -462,6 +462,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
                      c.ew_net_type, c.x2h_out_fc);
         return TD_EINVAL;
     }
+    if (c.sync_twoup != 0 && c.sync_twoup != 1) { td_set_error("td_model_create: sync_twoup must be 0 or 1, got %d", c.sync_twoup); return TD_EINVAL; }
     if (c.ew_net_type != 0 && !default_graph(c)) {
         td_set_error("td_model_create: ew_net_type 'r' / 'm' / none runs on the 32-slot graphs only (knn <= 32, or radius with a cap <= 32)");
         return TD_EINVAL;
@@ -812,6 +813,7 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
     auto proj_rows = [&](int l) -> const int32_t * { return l > 0 ? level_rows(Lc - 1 - l + 2) : nullptr; };
     auto proj_count = [&](int l) -> const int32_t * { return l > 0 ? level_count(Lc - 1 - l + 2) : nullptr; };
     bool proj_done = false;        // this layer's x2h-stage projections rode in the previous layer's paired launch
+    const bool sync = m->cfg.sync_twoup != 0;
     for (int l = 0; l < Lc; ++l) {
         const TdLayer &L = m->layers[l];
         if (!(l == 0 && layer0_x2h_done)) {
@@ -819,7 +821,13 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
             const int32_t *rws = l > 0 ? level_rows(e + 1) : nullptr, *cnt = l > 0 ? level_count(e + 1) : nullptr;
             const bool use_fwd = fwd && l == 1 && !rws;
             if (use_fwd) { rws = fwd->rows; cnt = fwd->counts; }
-            if (!proj_done) {
+            if (sync && do_h2x) {
+                // sync_twoup: the h2x stage reads the layer's input features, i.e. the h this stage's projections are taken from: both
+                // stages' projections in one launch, before the value pass overwrites h
+                ProfScope ps(PC_NODE, s);
+                if ((rc = td_launch_node_proj_pair(L.nodeH2x, level_rows(1), level_count(1), w.lig_node, Nl, w.Px, w.qx, L.nodeX2h,
+                                                   proj_rows(l), proj_count(l), w.P, w.q, h, N, s)) != TD_OK) return rc;
+            } else if (!proj_done) {
                 ProfScope ps(PC_NODE, s);
                 if ((rc = td_launch_node_proj(L.nodeX2h, h, N, proj_rows(l), 0x1f, w.P, w.q, s, proj_count(l))) != TD_OK) return rc;
             }
@@ -840,7 +848,9 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
             if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
-        if (l + 1 < Lc) {
+        if (sync) {
+            // (projections taken at the top of the layer)
+        } else if (l + 1 < Lc) {
             // the h2x stage of this layer and the x2h stage of the next project the same h: one launch
             ProfScope ps(PC_NODE, s);
             if ((rc = td_launch_node_proj_pair(L.nodeH2x, level_rows(1), level_count(1), w.lig_node, Nl, w.Px, w.qx,
@@ -1623,7 +1633,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->graph_nodes_max = gmax;
     const bool knn_like = m->cfg.cutoff_mode == TD_CUTOFF_KNN || m->cfg.cutoff_mode == TD_CUTOFF_HYBRID;
     S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES) && num_blocks(m->cfg) == 1 && m->cfg.ew_net_type == 0 &&
-                 !m->cfg.x2h_out_fc;      // (the static-protein tables hold the global gate's rows and plain x2h outputs)
+                 !m->cfg.x2h_out_fc && !m->cfg.sync_twoup;      // (the static-protein tables hold the global gate's rows and plain x2h outputs;
+                                                                 // a cached layer 0 skips the projections sync_twoup takes at its top)
     if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
     const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table
     const int KS = S->chunked ? 64 : TD_K;                   // static keys kept per protein row

@@ -154,7 +154,6 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
             unsupported.append(f'ew_net_type={ew_net_type!r} on a graph wider than 32 slots per node')
         if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
         if num_x2h != 1 or num_h2x != 1: unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x}')
-        if sync_twoup: unsupported.append(f'sync_twoup={sync_twoup}')
         if (hidden_dim, n_heads, num_r_gaussian, edge_feat_dim) != (128, 16, 20, 4):
             unsupported.append(f'shape {(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim)}')
         if not 1 <= k <= capi.MAX_FANIN: unsupported.append(f'knn={k} (1..{capi.MAX_FANIN})')
@@ -174,7 +173,7 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
                           'oracle/shims.py only, not to torch_cluster.radius_graph.', stacklevel=3)
         self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
         self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
-        self.cutoff_mode, self.ew_net_type, self.x2h_out_fc = cutoff_mode, ew_net_type, bool(x2h_out_fc)
+        self.cutoff_mode, self.ew_net_type, self.x2h_out_fc, self.sync_twoup = cutoff_mode, ew_net_type, bool(x2h_out_fc), bool(sync_twoup)
         self.distance_expansion = _Offsets(num_r_gaussian)
         if ew_net_type == 'global':                                  # :241-242 (the per-stage gates of 'r' live in the layers)
             self.edge_pred_layer = _MLPParams(num_r_gaussian, 1, hidden_dim)
@@ -396,7 +395,7 @@ class ScorePosNet3D(nn.Module):
             sched = {k: getattr(self, k).detach().cpu().numpy() for k in capi.SCHEDULE_ORDER + capi.SCHEDULE_OPTIONAL}
             cfg['model_mean_type'] = self.model_mean_type
             cfg['num_blocks'] = int(rn.num_blocks)
-            cfg['ew_net_type'], cfg['x2h_out_fc'] = rn.ew_net_type, rn.x2h_out_fc
+            cfg['ew_net_type'], cfg['x2h_out_fc'], cfg['sync_twoup'] = rn.ew_net_type, rn.x2h_out_fc, rn.sync_twoup
             sd = self.state_dict()
             if self.time_emb_dim > 0:         # the kernels embed the one-hot part; the time columns go through _time_bias
                 sd = dict(sd)

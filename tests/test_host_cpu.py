@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f'{name} declared in targetdiff_hip.h but not exported'
     assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
-    assert lib.td_abi_version() == capi.ABI_VERSION == 4
+    assert lib.td_abi_version() == capi.ABI_VERSION == 5
 
 
 def test_weight_blob_layout_matches_library():
@@ -57,7 +57,7 @@ def test_unsupported_config_is_rejected_not_emulated():
     assert lib.td_model_create(ctypes.byref(cfg3), dummy, 4, None, 0, ctypes.byref(h)) == -1      # radius mode needs r > 0
     from targetdiff_amd.models import ScorePosNet3D
     for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='m', knn=48), dict(ew_net_type='r', knn=48), dict(ew_net_type='r', cutoff_mode='hybrid'),
-                dict(num_blocks=9), dict(sync_twoup=True), dict(hidden_dim=256)):
+                dict(num_blocks=9), dict(num_x2h=2), dict(act_fn='silu'), dict(hidden_dim=256)):
         with pytest.raises(NotImplementedError):
             ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **bad), 27, 13)
     # the gate / output options of the attention layers (round 4): the reference's key sets (oracle.weights mirrors the reference modules)
