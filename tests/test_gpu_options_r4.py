@@ -220,3 +220,14 @@ def test_gate_and_output_options_sampling_vs_reference():
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[2]['pos_traj']))
     with pytest.raises(NotImplementedError, match='32 slots'):
         _model(weights.make_state_dict(SEED), ew_net_type='r', knn=48)
+    # x2h_out_fc and sync_twoup are graph-agnostic: on a hybrid graph (chunk-walking kernels) the session and the stateless forward agree
+    over2 = dict(x2h_out_fc=True, sync_twoup=True, cutoff_mode='hybrid')
+    cfg2 = dict(weights.DEFAULT_MODEL_CONFIG)
+    cfg2.update(over2)
+    hyb = _model(weights.make_state_dict(SEED, cfg2), **over2)
+    rs = [hyb.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
+                               torch.from_numpy(gs['init_ligand_pos']).to(dev), torch.from_numpy(gs['init_ligand_v']).to(dev),
+                               b.ligand_element_batch, num_steps=3, center_pos_mode='protein',
+                               noise_source=draws.Source(4700, dev), use_session=us) for us in (True, False)]
+    assert torch.equal(torch.stack(rs[0]['pos_traj']), torch.stack(rs[1]['pos_traj']))
+    assert torch.isfinite(torch.stack(rs[0]['pos_traj'])).all()
