@@ -86,7 +86,10 @@ typedef struct td_config {
                                     81-84; the reference class's default, False in configs/training.yml); sessions do not cache */
     int32_t sync_twoup;          /* 1: the h2x stage of a layer reads the layer's INPUT features instead of its x2h output
                                     (models/uni_transformer.py:198); 0 in configs/training.yml and in the class */
-    int32_t reserved[3];         /* zero */
+    int32_t num_x2h, num_h2x;    /* stages per layer, 1 .. 4 (0 = 1, as in configs/training.yml): a layer runs num_x2h x2h stages on its
+                                    start coordinates, then num_h2x h2x stages (models/uni_transformer.py:190-206), each stage with its
+                                    own weights.  != 1: sessions do not cache, nothing is fused across stages */
+    int32_t reserved[1];         /* zero */
 } td_config;                     /* (ABI 5: the struct grew by 16 bytes; ew_net_type / x2h_out_fc took the place of ABI 4's reserved[2]) */
 
 /* ---- library ------------------------------------------------------------------------------------ */

@@ -18,6 +18,7 @@ Configurations of ScorePosNet3D outside configs/training.yml that the mirror acc
       anything else but 'global' (e_w = 1, :64-67), and
       x2h_out_fc = True (node_output([attention output | h]) + h, :39-40, 81-84).  'r' + out_fc are the reference CLASS's defaults.
   forward_sync_twoup.npz     sync_twoup = True: the h2x stage reads the layer's input features (:198).
+  forward_stages_2_2.npz / forward_stages_1_3_r.npz   several stages per layer (num_x2h / num_h2x, :190-206).
 Weights: oracle.weights.time_emb_state_dict / make_state_dict(seed, cfg) (seeded per key; the fixtures hold outputs only)."""
 from __future__ import annotations
 
@@ -149,6 +150,8 @@ def main():
     gen_forward_options(ref, 'forward_out_fc.npz', x2h_out_fc=True)
     gen_forward_options(ref, 'forward_ew_m.npz', ew_net_type='m')
     gen_forward_options(ref, 'forward_sync_twoup.npz', sync_twoup=True)
+    gen_forward_options(ref, 'forward_stages_2_2.npz', num_x2h=2, num_h2x=2)
+    gen_forward_options(ref, 'forward_stages_1_3_r.npz', num_x2h=1, num_h2x=3, ew_net_type='r', x2h_out_fc=True)
     gen_sample(ref, 'sample_ew_r_out_fc_4.npz', 4600, ew_net_type='r', x2h_out_fc=True)
 
 

@@ -27,7 +27,7 @@ class TdConfig(ctypes.Structure):
                 ('num_r_gaussian', c_int32), ('edge_feat_dim', c_int32), ('protein_feat_dim', c_int32),
                 ('ligand_num_classes', c_int32), ('num_timesteps', c_int32), ('cutoff_mode', c_int32), ('radius', c_float),
                 ('max_num_neighbors', c_int32), ('model_mean_type', c_int32), ('num_blocks', c_int32), ('ew_net_type', c_int32),
-                ('x2h_out_fc', c_int32), ('sync_twoup', c_int32), ('reserved', c_int32 * 3)]
+                ('x2h_out_fc', c_int32), ('sync_twoup', c_int32), ('num_x2h', c_int32), ('num_h2x', c_int32), ('reserved', c_int32 * 1)]
 
 
 CUTOFF_MODES = {'knn': 0, 'hybrid': 1, 'radius': 2}      # TD_CUTOFF_* (include/targetdiff_hip.h)
@@ -191,9 +191,9 @@ def ew_net_code(ew_net_type) -> int:
     return EW_NET_TYPES.get(ew_net_type, 2)
 
 
-def flat_key_order(num_layers: int, ew_net_type='global', x2h_out_fc=False):
+def flat_key_order(num_layers: int, ew_net_type='global', x2h_out_fc=False, num_x2h=1, num_h2x=1):
     """Order of the reference state_dict tensors inside the flat blob td_model_create consumes
-    (key names: SURVEY.md Appendix C; init_h_emb_layer and the schedule constants are not part of it).  Per layer: offsets, hk, hv, hq,
+    (key names: SURVEY.md Appendix C; init_h_emb_layer and the schedule constants are not part of it).  Per layer: offsets; per x2h stage hk, hv, hq,
     [node_output (x2h_out_fc)], [x2h ew_net ('r': 80 + 1, 'm': 128 + 1)], xk, xv, xq, [h2x ew_net ('r')]; the global gate MLP only with ew_net_type 'global'."""
     keys = ['protein_atom_emb.weight', 'protein_atom_emb.bias', 'ligand_atom_emb.weight', 'ligand_atom_emb.bias',
             'refine_net.distance_expansion.offset']
@@ -202,23 +202,25 @@ def flat_key_order(num_layers: int, ew_net_type='global', x2h_out_fc=False):
     for l in range(num_layers):
         p = f'refine_net.base_block.{l}'
         keys.append(f'{p}.distance_expansion.offset')
-        for f in ('x2h_layers.0.hk_func', 'x2h_layers.0.hv_func', 'x2h_layers.0.hq_func'):
-            keys += [f'{p}.{f}.{k}' for k in MLP_KEYS]
-        if x2h_out_fc:
-            keys += [f'{p}.x2h_layers.0.node_output.{k}' for k in MLP_KEYS]
-        if ew_net_type in ('r', 'm'):
-            keys += [f'{p}.x2h_layers.0.ew_net.0.weight', f'{p}.x2h_layers.0.ew_net.0.bias']
-        for f in ('h2x_layers.0.xk_func', 'h2x_layers.0.xv_func', 'h2x_layers.0.xq_func'):
-            keys += [f'{p}.{f}.{k}' for k in MLP_KEYS]
-        if ew_net_type == 'r':
-            keys += [f'{p}.h2x_layers.0.ew_net.0.weight', f'{p}.h2x_layers.0.ew_net.0.bias']
+        for i in range(num_x2h):
+            for f in ('hk_func', 'hv_func', 'hq_func'):
+                keys += [f'{p}.x2h_layers.{i}.{f}.{k}' for k in MLP_KEYS]
+            if x2h_out_fc:
+                keys += [f'{p}.x2h_layers.{i}.node_output.{k}' for k in MLP_KEYS]
+            if ew_net_type in ('r', 'm'):
+                keys += [f'{p}.x2h_layers.{i}.ew_net.0.weight', f'{p}.x2h_layers.{i}.ew_net.0.bias']
+        for j in range(num_h2x):
+            for f in ('xk_func', 'xv_func', 'xq_func'):
+                keys += [f'{p}.h2x_layers.{j}.{f}.{k}' for k in MLP_KEYS]
+            if ew_net_type == 'r':
+                keys += [f'{p}.h2x_layers.{j}.ew_net.0.weight', f'{p}.h2x_layers.{j}.ew_net.0.bias']
     keys += ['v_inference.0.weight', 'v_inference.0.bias', 'v_inference.2.weight', 'v_inference.2.bias']
     return keys
 
 
-def flatten_state_dict(sd, num_layers: int, ew_net_type='global', x2h_out_fc=False) -> np.ndarray:
+def flatten_state_dict(sd, num_layers: int, ew_net_type='global', x2h_out_fc=False, num_x2h=1, num_h2x=1) -> np.ndarray:
     parts = [sd[k].detach().to('cpu', torch.float32).contiguous().reshape(-1).numpy()
-             for k in flat_key_order(num_layers, ew_net_type, x2h_out_fc)]
+             for k in flat_key_order(num_layers, ew_net_type, x2h_out_fc, num_x2h, num_h2x)]
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.float32)
 
 
@@ -262,12 +264,14 @@ class NativeModel:
                             max_num_neighbors=int(cfg.get('max_num_neighbors', 32)),
                             model_mean_type=MEAN_TYPES[cfg.get('model_mean_type', 'C0')], num_blocks=int(cfg.get('num_blocks', 1) or 1),
                             ew_net_type=ew_net_code(cfg.get('ew_net_type', 'global')), x2h_out_fc=int(bool(cfg.get('x2h_out_fc', False))),
-                            sync_twoup=int(bool(cfg.get('sync_twoup', False))))
+                            sync_twoup=int(bool(cfg.get('sync_twoup', False))), num_x2h=int(cfg.get('num_x2h', 1) or 1),
+                            num_h2x=int(cfg.get('num_h2x', 1) or 1))
         self.cutoff_mode, self.k = mode, int(cfg['knn'])
         self.default_graph = mode == 'knn' and self.k <= KNN       # the 32-slot fast path (and the caching session); k < 32
                                                                    # is the 32-NN row with the slots >= k masked
         self.num_classes = int(cfg['ligand_num_classes'])
-        blob = flatten_state_dict(state_dict, cfg['num_layers'], cfg.get('ew_net_type', 'global'), bool(cfg.get('x2h_out_fc', False)))
+        blob = flatten_state_dict(state_dict, cfg['num_layers'], cfg.get('ew_net_type', 'global'), bool(cfg.get('x2h_out_fc', False)),
+                                  int(cfg.get('num_x2h', 1) or 1), int(cfg.get('num_h2x', 1) or 1))
         expect = self.lib.td_model_num_weights(ctypes.byref(self.cfg))
         if blob.size != expect:
             raise ValueError(f'weight blob has {blob.size} floats, library expects {expect}')

@@ -163,6 +163,11 @@ struct FoldedMlp {
 
 size_t mlp_floats(int in, int hid, int out) { return (size_t)hid * in + 3 * (size_t)hid + (size_t)out * hid + out; }
 
+// stages per layer (0 in the config = 1): m->layers has stage_rows(c) rows per reference layer
+inline int num_x2h(const td_config &c) { return c.num_x2h > 0 ? c.num_x2h : 1; }
+inline int num_h2x(const td_config &c) { return c.num_h2x > 0 ? c.num_h2x : 1; }
+inline int stage_rows(const td_config &c) { return num_x2h(c) > num_h2x(c) ? num_x2h(c) : num_h2x(c); }
+
 int kv_in(const td_config &c) { return 2 * c.hidden_dim + c.edge_feat_dim + 4 * c.num_r_gaussian; }
 
 bool config_supported(const td_config &c) {
@@ -421,11 +426,12 @@ extern "C" size_t td_model_num_weights(const td_config *cfg) {
     const int H = c.hidden_dim, E = H - 1, KV = kv_in(c);
     size_t n = (size_t)E * c.protein_feat_dim + E + (size_t)E * c.ligand_num_classes + E;
     n += c.num_r_gaussian + (c.ew_net_type == 0 ? mlp_floats(c.num_r_gaussian, H, 1) : 0);
-    n += (size_t)c.num_layers * (c.num_r_gaussian + 2 * mlp_floats(KV, H, H) + 2 * mlp_floats(H, H, H) +
-                                 mlp_floats(KV, H, H) + mlp_floats(KV, H, c.n_heads));
-    if (c.ew_net_type == 1) n += (size_t)c.num_layers * 2 * (4 * c.num_r_gaussian + 1);       // the two stages' ew_net
-    if (c.ew_net_type == 3) n += (size_t)c.num_layers * (H + 1);                                // 'm': the x2h stage's ew_net
-    if (c.x2h_out_fc) n += (size_t)c.num_layers * mlp_floats(2 * H, H, H);                     // node_output
+    const size_t nx = num_x2h(c), nh = num_h2x(c);
+    size_t xs = 2 * mlp_floats(KV, H, H) + mlp_floats(H, H, H), hs = mlp_floats(KV, H, H) + mlp_floats(KV, H, c.n_heads) + mlp_floats(H, H, H);
+    if (c.ew_net_type == 1) { xs += 4 * c.num_r_gaussian + 1; hs += 4 * c.num_r_gaussian + 1; }   // the stages' ew_net ('r')
+    if (c.ew_net_type == 3) xs += H + 1;                                                            // 'm': the x2h stages' ew_net
+    if (c.x2h_out_fc) xs += mlp_floats(2 * H, H, H);                                               // node_output
+    n += (size_t)c.num_layers * (c.num_r_gaussian + nx * xs + nh * hs);
     n += (size_t)H * H + H + (size_t)c.ligand_num_classes * H + c.ligand_num_classes;
     return n;
 }
@@ -460,6 +466,14 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     if (c.ew_net_type < 0 || c.ew_net_type > 3 || (c.x2h_out_fc != 0 && c.x2h_out_fc != 1)) {
         td_set_error("td_model_create: ew_net_type must be 0 ('global'), 1 ('r'), 2 (none) or 3 ('m'), x2h_out_fc 0 or 1; got %d / %d",
                      c.ew_net_type, c.x2h_out_fc);
+        return TD_EINVAL;
+    }
+    if (c.num_x2h < 0 || c.num_x2h > 4 || c.num_h2x < 0 || c.num_h2x > 4) {
+        td_set_error("td_model_create: num_x2h / num_h2x must be 1 .. 4 (0 = 1), got %d / %d", c.num_x2h, c.num_h2x);
+        return TD_EINVAL;
+    }
+    if (stage_rows(c) > 1 && c.sync_twoup) {
+        td_set_error("td_model_create: sync_twoup with several stages per layer is not built");
         return TD_EINVAL;
     }
     if (c.sync_twoup != 0 && c.sync_twoup != 1) { td_set_error("td_model_create: sync_twoup must be 0 or 1, got %d", c.sync_twoup); return TD_EINVAL; }
@@ -529,62 +543,74 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
                         dp[(((size_t)p * 8 + hb) * 48 + l48) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
             }
     }
-    // ---- layers
-    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; size_t ew_x2h = 0, ew_h2x = 0, gate_m = 0, noB = 0, nob1 = 0, nog = 0, nobeta = 0, nob2 = 0; };
-    std::vector<LayerOff> lo(L);
-    for (int l = 0; l < L; ++l) {
+    // ---- layers.  A reference layer is num_x2h x2h stages followed by num_h2x h2x stages (models/uni_transformer.py:190-206; both 1 in
+    // configs/training.yml); row l * M + i of m->layers holds x2h stage i and h2x stage i of layer l (M = max of the two counts), so with
+    // one stage of each kind the array is the layer list.  Blob order per layer: offsets; per x2h stage hk, hv, hq, [node_output],
+    // [ew_net]; per h2x stage xk, xv, xq, [ew_net].
+    struct LayerOff { NodeOff nx, nh; EdgeOff hk, hv, xk, xv; size_t off; float coeff; size_t ew_x2h = 0, ew_h2x = 0, gate_m = 0, noB = 0, nob1 = 0, nog = 0, nobeta = 0, nob2 = 0;
+                      bool has_x = false, has_h = false; };
+    const int NX = num_x2h(c), NH = num_h2x(c), M = stage_rows(c);
+    std::vector<LayerOff> lo((size_t)L * M);
+    auto gate_rows = [&](size_t &dst, const float *src) {          // [4 types][20] + bias; 'm' and none: sigmoid(40) = 1.0f
+        dst = pk.alloc(4 * TD_NG + 1);
+        if (src) memcpy(pk.data.data() + dst, src, (4 * TD_NG + 1) * sizeof(float));
+        else pk.data[dst + 4 * TD_NG] = 40.f;
+    };
+    for (int l = 0; l < L && cur.ok; ++l) {
         const float *off = cur.take(TD_NG);
-        // blob order per layer: offsets, hk, hv, hq, [node_output], [x2h ew_net], xk, xv, xq, [h2x ew_net]
-        MlpSrc hk = cur.mlp(KV, H, H), hv = cur.mlp(KV, H, H), hq = cur.mlp(H, H, H);
-        MlpSrc nout{};
-        if (c.x2h_out_fc) nout = cur.mlp(2 * H, H, H);
-        const float *ewx = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
-        const float *ewm = c.ew_net_type == 3 ? cur.take(H + 1) : nullptr;
-        MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
-        const float *ewh = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
         if (!cur.ok) break;
-        // the four edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
-        const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H), fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
-        hk = fhk.src(); hv = fhv.src(); xk = fxk.src(); xv = fxv.src();
-        if (c.ew_net_type != 0) {            // [4 types][20] + bias per stage; 'm' and none: sigmoid(40) = 1.0f
-            lo[l].ew_x2h = pk.alloc(4 * TD_NG + 1);
-            lo[l].ew_h2x = pk.alloc(4 * TD_NG + 1);
-            if (c.ew_net_type == 1) {
-                memcpy(pk.data.data() + lo[l].ew_x2h, ewx, (4 * TD_NG + 1) * sizeof(float));
-                memcpy(pk.data.data() + lo[l].ew_h2x, ewh, (4 * TD_NG + 1) * sizeof(float));
-            } else {
-                pk.data[lo[l].ew_x2h + 4 * TD_NG] = 40.f;
-                pk.data[lo[l].ew_h2x + 4 * TD_NG] = 40.f;
+        const size_t ooff = pack_vec(pk, off, TD_NG);
+        for (int i = 0; i < M; ++i) { lo[(size_t)l * M + i].off = ooff; lo[(size_t)l * M + i].coeff = gaussian_coeff(off); }
+        for (int i = 0; i < NX; ++i) {
+            LayerOff &o = lo[(size_t)l * M + i];
+            MlpSrc hk = cur.mlp(KV, H, H), hv = cur.mlp(KV, H, H), hq = cur.mlp(H, H, H);
+            MlpSrc nout{};
+            if (c.x2h_out_fc) nout = cur.mlp(2 * H, H, H);
+            const float *ewx = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
+            const float *ewm = c.ew_net_type == 3 ? cur.take(H + 1) : nullptr;
+            if (!cur.ok) break;
+            // the edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
+            const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H);
+            hk = fhk.src(); hv = fhv.src();
+            if (c.ew_net_type != 0) gate_rows(o.ew_x2h, ewx);
+            if (ewm) {          // u'_n = sum_o w_m[o] W2v'[o][n] on the FOLDED second Linear (its columns carry |gamma_n|), c = w_m . b2v + b_m
+                o.gate_m = pk.alloc(TD_H + 1);
+                double cc = ewm[H];
+                for (int oo = 0; oo < H; ++oo) cc += (double)ewm[oo] * (double)fhv.b3[oo];
+                for (int n = 0; n < H; ++n) {
+                    double u = 0.0;
+                    for (int oo = 0; oo < H; ++oo) u += (double)ewm[oo] * (double)fhv.w3[(size_t)oo * H + n];
+                    pk.data[o.gate_m + n] = (float)u;
+                }
+                pk.data[o.gate_m + H] = (float)cc;
             }
-        }
-        if (ewm) {          // u'_n = sum_o w_m[o] W2v'[o][n] on the FOLDED second Linear (its columns carry |gamma_n|), c = w_m . b2v + b_m
-            lo[l].gate_m = pk.alloc(TD_H + 1);
-            double cc = ewm[H];
-            for (int o = 0; o < H; ++o) cc += (double)ewm[o] * (double)fhv.b3[o];
-            for (int n = 0; n < H; ++n) {
-                double u = 0.0;
-                for (int o = 0; o < H; ++o) u += (double)ewm[o] * (double)fhv.w3[(size_t)o * H + n];
-                pk.data[lo[l].gate_m + n] = (float)u;
+            if (c.x2h_out_fc) {
+                o.noB = pack_B128(pk, nout.w0, 2 * TD_H, 0);           // the attention-output half of net.0 (cat([output, h]), :83)
+                pack_B128(pk, nout.w0, 2 * TD_H, TD_H);                // the h half (consecutive blocks)
+                pack_B128(pk, nout.w3, TD_H, 0);
+                o.nob1 = pack_vec(pk, nout.b0, TD_H);
+                o.nog = pack_vec(pk, nout.g, TD_H);
+                o.nobeta = pack_vec(pk, nout.b, TD_H);
+                o.nob2 = pack_vec(pk, nout.b3, TD_H);
             }
-            pk.data[lo[l].gate_m + H] = (float)cc;
+            o.nx = pack_node_stage(pk, hk, hv, hq, KV);
+            o.hk = pack_edge_mlp(pk, hk, KV, H, 1);
+            o.hv = pack_edge_mlp(pk, hv, KV, H, 2);
+            o.has_x = true;
         }
-        if (c.x2h_out_fc) {
-            lo[l].noB = pack_B128(pk, nout.w0, 2 * TD_H, 0);           // the attention-output half of net.0 (cat([output, h]), :83)
-            pack_B128(pk, nout.w0, 2 * TD_H, TD_H);                    // the h half (consecutive blocks)
-            pack_B128(pk, nout.w3, TD_H, 0);
-            lo[l].nob1 = pack_vec(pk, nout.b0, TD_H);
-            lo[l].nog = pack_vec(pk, nout.g, TD_H);
-            lo[l].nobeta = pack_vec(pk, nout.b, TD_H);
-            lo[l].nob2 = pack_vec(pk, nout.b3, TD_H);
+        for (int j = 0; j < NH && cur.ok; ++j) {
+            LayerOff &o = lo[(size_t)l * M + j];
+            MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
+            const float *ewh = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
+            if (!cur.ok) break;
+            const FoldedMlp fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
+            xk = fxk.src(); xv = fxv.src();
+            if (c.ew_net_type != 0) gate_rows(o.ew_h2x, ewh);
+            o.nh = pack_node_stage(pk, xk, xv, xq, KV);
+            o.xk = pack_edge_mlp(pk, xk, KV, H, 1);
+            o.xv = pack_edge_mlp(pk, xv, KV, c.n_heads, 0);
+            o.has_h = true;
         }
-        lo[l].off = pack_vec(pk, off, TD_NG);
-        lo[l].coeff = gaussian_coeff(off);
-        lo[l].nx = pack_node_stage(pk, hk, hv, hq, KV);
-        lo[l].nh = pack_node_stage(pk, xk, xv, xq, KV);
-        lo[l].hk = pack_edge_mlp(pk, hk, KV, H, 1);
-        lo[l].hv = pack_edge_mlp(pk, hv, KV, H, 2);
-        lo[l].xk = pack_edge_mlp(pk, xk, KV, H, 1);
-        lo[l].xv = pack_edge_mlp(pk, xv, KV, c.n_heads, 0);
     }
     // ---- head
     const float *V0 = cur.take((size_t)H * H), *vb0 = cur.take(H), *V2 = cur.take((size_t)C * H), *vb2 = cur.take(C);
@@ -604,7 +630,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     if (!m) { td_set_error("td_model_create: out of host memory"); return TD_ENOMEM; }
     m->cfg = c;
     m->blob_floats = pk.data.size();
-    m->layers = new (std::nothrow) TdLayer[L];
+    m->layers = new (std::nothrow) TdLayer[(size_t)L * stage_rows(c)]();
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->blob), m->blob_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->blob, pk.data.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess || !m->layers) {
@@ -625,16 +651,22 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
                            m->opt.node_proj_split != 0, m->opt.node_proj_bpipe != 0, m->opt.node_proj_async != 0};
     };
-    for (int l = 0; l < L; ++l) {
+    for (size_t l = 0; l < lo.size(); ++l) {
         TdLayer &Ly = m->layers[l];
-        Ly.nodeX2h = node(lo[l].nx); Ly.nodeH2x = node(lo[l].nh);
-        Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true); Ly.xk = edge(lo[l].xk, true); Ly.xv = edge(lo[l].xv, true);
+        Ly = TdLayer{};
         Ly.offsets = D + lo[l].off; Ly.coeff = lo[l].coeff;
-        Ly.ew_x2h = c.ew_net_type != 0 ? D + lo[l].ew_x2h : nullptr;
-        Ly.ew_h2x = c.ew_net_type != 0 ? D + lo[l].ew_h2x : nullptr;
-        Ly.gate_m = c.ew_net_type == 3 ? D + lo[l].gate_m : nullptr;
-        Ly.nodeOut = c.x2h_out_fc ? TdNodeOut{D + lo[l].noB, D + lo[l].nob1, D + lo[l].nog, D + lo[l].nobeta, D + lo[l].nob2}
-                                  : TdNodeOut{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (lo[l].has_x) {
+            Ly.nodeX2h = node(lo[l].nx);
+            Ly.hk = edge(lo[l].hk, true); Ly.hv = edge(lo[l].hv, true);
+            Ly.ew_x2h = c.ew_net_type != 0 ? D + lo[l].ew_x2h : nullptr;
+            Ly.gate_m = c.ew_net_type == 3 ? D + lo[l].gate_m : nullptr;
+            if (c.x2h_out_fc) Ly.nodeOut = TdNodeOut{D + lo[l].noB, D + lo[l].nob1, D + lo[l].nog, D + lo[l].nobeta, D + lo[l].nob2};
+        }
+        if (lo[l].has_h) {
+            Ly.nodeH2x = node(lo[l].nh);
+            Ly.xk = edge(lo[l].xk, true); Ly.xv = edge(lo[l].xv, true);
+            Ly.ew_h2x = c.ew_net_type != 0 ? D + lo[l].ew_h2x : nullptr;
+        }
     }
     m->head = TdHead{D + oW0T, D + ohb0, D + oW2T, D + ohb2};
     const float *S = D + oS;
@@ -656,21 +688,21 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     if (strcmp(name, "h2x_fused") == 0) m->opt.h2x_fused = value != 0;
     else if (strcmp(name, "node_proj_split") == 0) {
         m->opt.node_proj_split = value != 0;
-        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) m->layers[l].nodeX2h.use_split = m->layers[l].nodeH2x.use_split = value != 0;
     } else if (strcmp(name, "edge_row_dealing") == 0) {
         m->opt.edge_row_dealing = value < 0 ? 0 : (value > 2 ? 2 : value);
-        for (int l = 0; l < m->cfg.num_layers; ++l)
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l)
             m->layers[l].hk.deal_rows = m->layers[l].hv.deal_rows = m->layers[l].xk.deal_rows = m->layers[l].xv.deal_rows = m->opt.edge_row_dealing;
     } else if (strcmp(name, "node_proj_bpipe") == 0) {
         m->opt.node_proj_bpipe = value != 0;
-        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.bpipe = m->layers[l].nodeH2x.bpipe = value != 0;
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) m->layers[l].nodeX2h.bpipe = m->layers[l].nodeH2x.bpipe = value != 0;
     } else if (strcmp(name, "node_proj_async") == 0) {
         m->opt.node_proj_async = value != 0;
-        for (int l = 0; l < m->cfg.num_layers; ++l) m->layers[l].nodeX2h.async_copy = m->layers[l].nodeH2x.async_copy = value != 0;
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) m->layers[l].nodeX2h.async_copy = m->layers[l].nodeH2x.async_copy = value != 0;
     } else if (strcmp(name, "edge_key_split") == 0) {
         m->opt.edge_key_split = value != 0;
         m->gate.use_split = value != 0;
-        for (int l = 0; l < m->cfg.num_layers; ++l) {
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) {
             m->layers[l].hk.use_split = m->layers[l].hk.R16p && value != 0;
             m->layers[l].hv.use_split = m->layers[l].hv.R16p && value != 0;
             m->layers[l].xk.use_split = m->layers[l].xk.R16p && value != 0;
@@ -796,11 +828,15 @@ struct FwdReach {
     const float *hs;
 };
 
+int run_backbone_stages(const td_model *m, Workspace &w, const GraphTab &gt, float *h, int64_t N, int64_t Nl, int fix_x,
+                        float4 **x_final, hipStream_t s, bool init_xn);
+
 int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, int64_t N, int64_t Nl, int fix_x,
                  float4 **x_final, hipStream_t s, bool init_xn, bool layer0_x2h_done = false,
                  const int32_t *hop_rows = nullptr, const int32_t *hop_count = nullptr, int hop_levels = 0,
                  const FwdReach *fwd = nullptr) {
     int rc;
+    if (stage_rows(m->cfg) > 1 || m->cfg.num_x2h > 1 || m->cfg.num_h2x > 1) return run_backbone_stages(m, w, gt, h, N, Nl, fix_x, x_final, s, init_xn);
     const int Lc = m->cfg.num_layers;
     // row list of receptive-field level k (1-based); nullptr = every row
     auto level_rows = [&](int k) -> const int32_t * { return (hop_rows && k <= hop_levels) ? hop_rows + (size_t)(k - 1) * N : nullptr; };
@@ -866,6 +902,39 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
         }
         if ((rc = h2x_attend(m, L, w, gt, Nl, xc, xn, w.Px, w.qx, s)) != TD_OK) return rc;
         float4 *t = xc; xc = xn; xn = t;
+    }
+    *x_final = xc;
+    return TD_OK;
+}
+
+// The same on a model with several stages per layer (num_x2h / num_h2x != 1; models/uni_transformer.py:190-206): the x2h stages of a layer one
+// after the other on the layer's start coordinates, then its h2x stages, each on the coordinates the previous one left and all on the last
+// x2h stage's features.  Every stage takes its own projections (nothing is fused across stages); every row, no caching.
+int run_backbone_stages(const td_model *m, Workspace &w, const GraphTab &gt, float *h, int64_t N, int64_t Nl, int fix_x,
+                        float4 **x_final, hipStream_t s, bool init_xn) {
+    int rc;
+    const int Lc = m->cfg.num_layers, NX = num_x2h(m->cfg), NH = num_h2x(m->cfg), M = stage_rows(m->cfg);
+    float4 *xc = w.x4a, *xn = w.x4b;
+    const bool do_h2x = !fix_x && Nl > 0;
+    if (do_h2x && init_xn) TD_CHECK_HIP(hipMemcpyAsync(xn, xc, (size_t)N * sizeof(float4), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < Lc; ++l) {
+        for (int i = 0; i < NX; ++i) {
+            const TdLayer &L = m->layers[(size_t)l * M + i];
+            { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_proj(L.nodeX2h, h, N, nullptr, 0x1f, w.P, w.q, s, nullptr)) != TD_OK) return rc; }
+            if (L.ew_x2h) { ProfScope ps(PC_GATE, s); if ((rc = td_launch_layer_gate(L.ew_x2h, L.offsets, L.coeff, xc, gt.nbr, N, gt.ew, s)) != TD_OK) return rc; }
+            { ProfScope ps(PC_X2H_K, s); if ((rc = key_pass(L.hk, L, xc, gt, gt.ew, gt.nbr, w.P, w.q, nullptr, nullptr, N, gt.alpha, s, w.lig_node, Nl)) != TD_OK) return rc; }
+            float *att_out = L.nodeOut.B ? w.q : nullptr;
+            { ProfScope ps(PC_X2H_V, s); if ((rc = value_pass(L.hv, L, xc, gt, gt.nbr, w.P, nullptr, nullptr, N, h, gt.alpha, w.lig_node, Nl, s, att_out)) != TD_OK) return rc; }
+            if (att_out) { ProfScope ps(PC_NODE, s); if ((rc = td_launch_node_output(L.nodeOut, att_out, h, N, s)) != TD_OK) return rc; }
+        }
+        if (!do_h2x) continue;
+        for (int j = 0; j < NH; ++j) {
+            const TdLayer &L = m->layers[(size_t)l * M + j];
+            if ((rc = h2x_project(L, w, h, N, Nl, w.Px, w.qx, nullptr, nullptr, s)) != TD_OK) return rc;
+            if (L.ew_h2x) { ProfScope ps(PC_GATE, s); if ((rc = td_launch_layer_gate(L.ew_h2x, L.offsets, L.coeff, xc, gt.nbr, N, gt.ew, s)) != TD_OK) return rc; }
+            if ((rc = h2x_attend(m, L, w, gt, Nl, xc, xn, w.Px, w.qx, s)) != TD_OK) return rc;
+            float4 *t = xc; xc = xn; xn = t;
+        }
     }
     *x_final = xc;
     return TD_OK;
@@ -1633,7 +1702,7 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->graph_nodes_max = gmax;
     const bool knn_like = m->cfg.cutoff_mode == TD_CUTOFF_KNN || m->cfg.cutoff_mode == TD_CUTOFF_HYBRID;
     S->caching = knn_like && (!S->chunked || gmax <= TD_STEP_LISTS_MAX_NODES) && num_blocks(m->cfg) == 1 && m->cfg.ew_net_type == 0 &&
-                 !m->cfg.x2h_out_fc && !m->cfg.sync_twoup;      // (the static-protein tables hold the global gate's rows and plain x2h outputs;
+                 !m->cfg.x2h_out_fc && !m->cfg.sync_twoup && stage_rows(m->cfg) == 1;      // (the static-protein tables hold the global gate's rows and plain x2h outputs;
                                                                  // a cached layer 0 skips the projections sync_twoup takes at its top)
     if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
     const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table

@@ -153,7 +153,8 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
                                         (cutoff_mode == 'radius' and max_num_neighbors > 32)):
             unsupported.append(f'ew_net_type={ew_net_type!r} on a graph wider than 32 slots per node')
         if act_fn != 'relu' or not norm: unsupported.append(f'act_fn={act_fn!r}/norm={norm}')
-        if num_x2h != 1 or num_h2x != 1: unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x}')
+        if not (1 <= num_x2h <= 4 and 1 <= num_h2x <= 4): unsupported.append(f'num_x2h={num_x2h}/num_h2x={num_h2x} (1..4 each)')
+        if sync_twoup and (num_x2h != 1 or num_h2x != 1): unsupported.append('sync_twoup with several stages per layer')
         if (hidden_dim, n_heads, num_r_gaussian, edge_feat_dim) != (128, 16, 20, 4):
             unsupported.append(f'shape {(hidden_dim, n_heads, num_r_gaussian, edge_feat_dim)}')
         if not 1 <= k <= capi.MAX_FANIN: unsupported.append(f'knn={k} (1..{capi.MAX_FANIN})')
@@ -174,6 +175,7 @@ class UniTransformerO2TwoUpdateGeneral(nn.Module):
         self.num_blocks, self.num_layers, self.hidden_dim, self.n_heads, self.k = num_blocks, num_layers, hidden_dim, n_heads, k
         self.num_r_gaussian, self.edge_feat_dim = num_r_gaussian, edge_feat_dim
         self.cutoff_mode, self.ew_net_type, self.x2h_out_fc, self.sync_twoup = cutoff_mode, ew_net_type, bool(x2h_out_fc), bool(sync_twoup)
+        self.num_x2h, self.num_h2x = int(num_x2h), int(num_h2x)
         self.distance_expansion = _Offsets(num_r_gaussian)
         if ew_net_type == 'global':                                  # :241-242 (the per-stage gates of 'r' live in the layers)
             self.edge_pred_layer = _MLPParams(num_r_gaussian, 1, hidden_dim)
@@ -396,6 +398,7 @@ class ScorePosNet3D(nn.Module):
             cfg['model_mean_type'] = self.model_mean_type
             cfg['num_blocks'] = int(rn.num_blocks)
             cfg['ew_net_type'], cfg['x2h_out_fc'], cfg['sync_twoup'] = rn.ew_net_type, rn.x2h_out_fc, rn.sync_twoup
+            cfg['num_x2h'], cfg['num_h2x'] = rn.num_x2h, rn.num_h2x
             sd = self.state_dict()
             if self.time_emb_dim > 0:         # the kernels embed the one-hot part; the time columns go through _time_bias
                 sd = dict(sd)

@@ -165,7 +165,9 @@ def test_layernorm_weights_of_every_sign_vs_reference():
                                        ('forward_ew_none.npz', dict(ew_net_type='none')),
                                        ('forward_out_fc.npz', dict(x2h_out_fc=True)),
                                        ('forward_ew_m.npz', dict(ew_net_type='m')),
-                                       ('forward_sync_twoup.npz', dict(sync_twoup=True))])
+                                       ('forward_sync_twoup.npz', dict(sync_twoup=True)),
+                                       ('forward_stages_2_2.npz', dict(num_x2h=2, num_h2x=2)),
+                                       ('forward_stages_1_3_r.npz', dict(num_x2h=1, num_h2x=3, ew_net_type='r', x2h_out_fc=True))])
 def test_gate_and_output_options_vs_reference(name, over):
     """ew_net_type = 'r' (every stage's own gate on the layer's radial features), 'm' (the x2h gate from the edge's value vector, which the
     kernels never form: its logit is a dot product with the hidden activations), any value that means e_w = 1, and x2h_out_fc = True

@@ -57,19 +57,20 @@ def test_unsupported_config_is_rejected_not_emulated():
     assert lib.td_model_create(ctypes.byref(cfg3), dummy, 4, None, 0, ctypes.byref(h)) == -1      # radius mode needs r > 0
     from targetdiff_amd.models import ScorePosNet3D
     for bad in (dict(cutoff_mode='cutoff'), dict(knn=100), dict(ew_net_type='m', knn=48), dict(ew_net_type='r', knn=48), dict(ew_net_type='r', cutoff_mode='hybrid'),
-                dict(num_blocks=9), dict(num_x2h=2), dict(act_fn='silu'), dict(hidden_dim=256)):
+                dict(num_blocks=9), dict(num_x2h=5), dict(num_x2h=2, sync_twoup=True), dict(act_fn='silu'), dict(hidden_dim=256)):
         with pytest.raises(NotImplementedError):
             ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **bad), 27, 13)
     # the gate / output options of the attention layers (round 4): the reference's key sets (oracle.weights mirrors the reference modules)
-    for opt in (dict(ew_net_type='r', x2h_out_fc=True), dict(ew_net_type='none'), dict(x2h_out_fc=True), dict(ew_net_type='m')):
+    for opt in (dict(ew_net_type='r', x2h_out_fc=True), dict(ew_net_type='none'), dict(x2h_out_fc=True), dict(ew_net_type='m'),
+                dict(num_x2h=2, num_h2x=3, ew_net_type='r')):
         cfgo = dict(weights.DEFAULT_MODEL_CONFIG, **opt)
         m = ScorePosNet3D(cfgo, 27, 13)
         learn = {k for k, p in m.named_parameters() if p.requires_grad}
         assert learn == {k for k in weights.make_state_dict(2021, cfgo) if not k.endswith('distance_expansion.offset')}, opt
-        blob = capi.flatten_state_dict(weights.make_state_dict(2021, cfgo), 9, cfgo['ew_net_type'], cfgo['x2h_out_fc'])
+        blob = capi.flatten_state_dict(weights.make_state_dict(2021, cfgo), 9, cfgo['ew_net_type'], cfgo['x2h_out_fc'], cfgo['num_x2h'], cfgo['num_h2x'])
         c = capi.TdConfig(hidden_dim=128, n_heads=16, knn=32, num_layers=9, num_r_gaussian=20, edge_feat_dim=4, protein_feat_dim=27,
                           ligand_num_classes=13, num_timesteps=1000, ew_net_type=capi.ew_net_code(cfgo['ew_net_type']),
-                          x2h_out_fc=int(cfgo['x2h_out_fc']))
+                          x2h_out_fc=int(cfgo['x2h_out_fc']), num_x2h=cfgo['num_x2h'], num_h2x=cfgo['num_h2x'])
         assert lib.td_model_num_weights(ctypes.byref(c)) == blob.size, opt
     for ok in (dict(cutoff_mode='hybrid'), dict(knn=48), dict(cutoff_mode='radius', r=6.0, max_num_neighbors=16)):
         m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG, **ok), 27, 13)
