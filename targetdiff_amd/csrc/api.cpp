@@ -805,9 +805,10 @@ int h2x_project(const TdLayer &L, Workspace &w, float *h, int64_t N, int64_t Nl,
 int h2x_attend(const td_model *m, const TdLayer &L, Workspace &w, const GraphTab &gt, int64_t Nl, float4 *xc, float4 *xn, float *P,
                float *q, hipStream_t s) {
     int rc;
-    if (m->opt.h2x_fused && !gt.cptr) {
+    if (m->opt.h2x_fused && (!gt.cptr || (L.xk.use_split && L.xv.use_split))) {
+        // (general graphs: the chunk-walking fused form exists for the bf16 first layer; alpha holds the logits between its two sweeps)
         ProfScope ps(PC_H2X_K, s);
-        return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, gt.nbr, gt.ew, P, q, w.lig_node, Nl, s);
+        return td_launch_edge_h2x16(L.xk, L.xv, L, xc, xn, gt.nbr, gt.ew, P, q, w.lig_node, Nl, s, gt.cptr, gt.alpha);
     }
     {
         ProfScope ps(PC_H2X_K, s);

@@ -904,6 +904,153 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     }
 }
 
+// The fused h2x stage on general graphs (chunk-walking; bf16 first layer only): one wave per ligand row, two sweeps over the row's chunks in
+// ONE launch instead of a key launch (logits -> softmax over all chunks -> alpha) and an xv launch.  Sweep 1 stores the scaled logits in
+// alpha[c] and keeps a running (max, sum) per head; sweep 2 runs the xv MLP on each chunk and weights it with exp(x - max) / sum * gate
+// computed on the fly from the stored logits (same lane layout), accumulating delta x.  Arithmetic as in edge_key16_kernel<false, .., 1> +
+// edge_key16_kernel<true, .., 1>; tables as in edge_h2x16_kernel (both MLPs' ligand-destination halves resident).
+__global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(ArgsH2x ar) {
+    constexpr int WAVES = H2X16_WAVES;
+    constexpr int RH = h2x16_table_floats<true>();
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Args16 &a = ar.a;
+    float *Rk = lds, *WqF = Rk + RH, *Rv = WqF + E16_WQ_FLOATS, *WxF = Rv + RH, *GB = WxF + H2X16_WX_FLOATS;
+    const float4 *Wq = reinterpret_cast<const float4 *>(WqF);
+    const float *Wx = WxF;
+    const float *KBk = GB, *KBv = GB + TD_H;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    {
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16p), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16p), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
+        if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
+        else if (tid < 2 * TD_H) GB[tid] = ar.mlp_v.beta[tid - TD_H];
+    }
+    float offk[8];
+#pragma unroll
+    for (int sx = 0; sx < 8; ++sx) offk[sx] = (8 * g + sx) < TD_NG ? a.offsets[8 * g + sx] : TD_FAR_CENTRE;
+    int64_t begin, end;
+    td_node_range16(a.count, a.count_ptr, begin, end);
+    Args16 av = a;
+    av.p_off = 2 * TD_H;
+    const float b2 = ar.mlp_v.b2[lo];
+    __syncthreads();
+    for (int64_t it = begin + wid; it < end; it += WAVES) {
+        const int64_t i = a.rows ? (int64_t)a.rows[it] : it;
+        const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+        const float4 q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+        // ---- sweep 1: keys -> scaled logits into alpha[c], running (max, sum) per head ---------------------------------------------
+        float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, srun[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = c0; c < c1; ++c) {
+            RowIn16 rin;
+            floatx4_t acc[2][8];
+            Edge2 ed;
+            td_row_index16(a, i, c, lane, rin);
+            td_row_gather16<false>(a, i, c, lane, rin, acc);
+            if (__ballot(rin.j[1] >= 0) == 0ull)              // wave-uniform: the chunk's second block is all padding
+                td_first_layer_split16<false, true, false, 1>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+            else
+                td_first_layer_split16<false, true, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+            floatx4_t lg[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            float4 w0 = Wq[lane], w1 = Wq[64 + lane];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                float4 n0 = w0, n1 = w1;
+                if (kk + 1 < 32) {
+                    n0 = Wq[((kk + 1) * 2 + 0) * 64 + lane];
+                    n1 = Wq[((kk + 1) * 2 + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                lg[0] = td_mfma16(u, acc[0][kk >> 2][kk & 3], lg[0]);
+                if (ed.any[1]) lg[1] = td_mfma16(u, acc[1][kk >> 2][kk & 3], lg[1]);
+                w0 = n0; w1 = n1;
+            }
+            float x0[4], x1[4], mn[4], ps[4];
+            const float sc0 = ed.rstd[0] * TD_ATT_SCALE_16, sc1 = ed.rstd[1] * TD_ATT_SCALE_16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x0[r] = ed.valid[0] ? lg[0][r] * sc0 : -INFINITY;
+                x1[r] = ed.valid[1] ? lg[1][r] * sc1 : -INFINITY;
+                float *dst = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                dst[0] = x0[r];
+                dst[16] = x1[r];
+                mn[r] = fmaxf(x0[r], x1[r]);
+            }
+            td_max16x4(mn);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mn[r] = fmaxf(mrun[r], mn[r]);
+                const float ms = mn[r] == -INFINITY ? 0.f : mn[r];
+                ps[r] = __expf(x0[r] - ms) + __expf(x1[r] - ms);
+            }
+            td_sum16x4(ps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mn[r] != -INFINITY) {
+                    srun[r] = srun[r] * __expf(mrun[r] - mn[r]) + ps[r];
+                    mrun[r] = mn[r];
+                }
+        }
+        float inv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            inv[r] = srun[r] > 0.f ? __builtin_amdgcn_rcpf(srun[r]) : 0.f;
+            if (mrun[r] == -INFINITY) mrun[r] = 0.f;
+        }
+        // ---- sweep 2: xv MLP per chunk, weighted with the normalised, gated attention weights from the stored logits -----------------
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        float4 xi_keep = a.x4[i];
+        for (int c = c0; c < c1; ++c) {
+            RowIn16 rin;
+            floatx4_t acc[2][8];
+            Edge2 ed;
+            td_row_index16(av, i, c, lane, rin);
+            td_row_gather16<false>(av, i, c, lane, rin, acc);
+            const float ew0 = a.ew[(size_t)c * TD_K + lo], ew1 = a.ew[(size_t)c * TD_K + 16 + lo];       // 0 on pads
+            if (__ballot(rin.j[1] >= 0) == 0ull)
+                td_first_layer_split16<false, true, false, 1>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+            else
+                td_first_layer_split16<false, true, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+            floatx4_t xv[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float u = Wx[(hb * 4 + r) * 64 + lane];
+                    xv[0] = td_mfma16(u, acc[0][hb][r], xv[0]);
+                    if (ed.any[1]) xv[1] = td_mfma16(u, acc[1][hb][r], xv[1]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bias = __shfl(b2, 4 * g + r);
+                const float *lp = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
+                const float ex[2] = {__expf(lp[0] - mrun[r]) * inv[r] * ew0, __expf(lp[16] - mrun[r]) * inv[r] * ew1};
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb) {
+                    const float wgt = ed.valid[eb] ? ex[eb] * fmaf(xv[eb][r], ed.rstd[eb], bias) : 0.f;
+                    sx = fmaf(wgt, ed.rel[eb][0], sx);
+                    sy = fmaf(wgt, ed.rel[eb][1], sy);
+                    sz = fmaf(wgt, ed.rel[eb][2], sz);
+                }
+            }
+        }
+        sx = td_sum64(sx) * (1.0f / TD_HEADS);
+        sy = td_sum64(sy) * (1.0f / TD_HEADS);
+        sz = td_sum64(sz) * (1.0f / TD_HEADS);
+        if (lane == 0) a.x4_out[i] = make_float4(xi_keep.x + sx, xi_keep.y + sy, xi_keep.z + sz, xi_keep.w);
+    }
+}
+
 // ================================================================================================ value pass (x2h)
 constexpr int V16_WAVES = 8;
 constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
@@ -1585,16 +1732,20 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
 // Fused h2x stage (keys + softmax + xv + coordinate update) on the listed ligand rows.
 int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
-                         int64_t count, hipStream_t s) {
+                         int64_t count, hipStream_t s, const int32_t *cptr, float *alpha) {
     if (count == 0) return TD_OK;
     ArgsH2x ar = {};
     Args16 &a = ar.a;
     a.x4 = x4_in; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = nullptr; a.h = nullptr;
-    a.alpha = nullptr; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    a.alpha = alpha; a.x4_out = x4_out; a.count = count; a.mlp = mlp_k; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
+    a.cptr = cptr;
     ar.mlp_v = mlp_v;
-    a.trace = wg_trace_slot(2);
+    a.trace = cptr ? nullptr : wg_trace_slot(2);
     const dim3 grid(grid16(count, H2X16_WAVES)), block(H2X16_WAVES * 64);
-    if (mlp_k.use_split && mlp_v.use_split) {
+    if (cptr) {           // general graphs: the chunk-walking form (bf16 first layer; the caller checks use_split)
+        TD_LDS_ONCE((edge_h2x16_chunked_kernel), h2x16_lds_bytes<true>());
+        edge_h2x16_chunked_kernel<<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
+    } else if (mlp_k.use_split && mlp_v.use_split) {
         TD_LDS_ONCE((edge_h2x16_kernel<true>), h2x16_lds_bytes<true>());
         edge_h2x16_kernel<true><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
     } else {

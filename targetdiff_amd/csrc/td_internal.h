@@ -246,7 +246,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
                          int64_t lig_count = 0, int cpn_p = 0);
 int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,
-                         int64_t count, hipStream_t s);
+                         int64_t count, hipStream_t s, const int32_t *cptr = nullptr, float *alpha = nullptr);
 int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4_in, float4 *x4_out, const int32_t *nbr,
                         const float *P, const int32_t *rows, int64_t count, const float *alpha, hipStream_t s,
                         const int32_t *cptr = nullptr);
