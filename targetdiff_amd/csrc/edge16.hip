@@ -97,9 +97,10 @@ __device__ __forceinline__ void td_deal16(int64_t count, int U, int64_t &first, 
                                           int b = blockIdx.x) {
     const int x = b & 7, r = G & 7, w = b >> 3;
     const int c0 = x * (G >> 3) + (x < r ? x : r), nx = (G >> 3) + (x < r ? 1 : 0);
-    const int64_t per = (count + G - 1) / G;
-    const int64_t xb = (int64_t)c0 * per;
-    end = xb + (int64_t)nx * per < count ? xb + (int64_t)nx * per : count;
+    // the XCD's range in proportion to its workgroups (with ceil(count / G) rows per workgroup the last XCD came 4 % short at C2 and idled
+    // while the others finished)
+    const int64_t xb = count * c0 / G;
+    end = count * (c0 + nx) / G;
     first = xb + (int64_t)w * U;
     stride = (int64_t)nx * U;
 }

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(128) void head_kernel(TdHead hd, const float *__res
     const float b0 = hd.b0[n];
 #pragma unroll
     for (int a = 0; a < HEAD_ATOMS; ++a) acc[a] = b0;
+#pragma unroll 16        // sixteen weight loads in flight
     for (int k = 0; k < TD_H; ++k) {
         const float wv = hd.W0T[k * TD_H + n];
 #pragma unroll
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(128) void head_kernel(TdHead hd, const float *__res
     const int a = n >> 4, cc = n & 15;
     if (cc < C && a0 + a < Nl) {
         float o = hd.b2[cc];
+#pragma unroll 16
         for (int k = 0; k < TD_H; ++k) o = fmaf(hd.W2T[k * TD_MAXC + cc], s_y[a][k], o);
         pred_v[(a0 + a) * C + cc] = o;
     }
