@@ -211,7 +211,7 @@ def test_gate_and_output_options_sampling_vs_reference():
     gs = load_golden('sample_ew_r_out_fc_4.npz')
     b = small_batch()[0].to(dev)
     outs = []
-    for kw in (dict(), dict(use_graph=False), dict(use_session=False)):
+    for kw in (dict(use_graph=True), dict(use_graph=False), dict(use_session=False)):          # the captured step, launch by launch, stateless
         r = model.sample_diffusion(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch,
                                    torch.from_numpy(gs['init_ligand_pos']).to(dev), torch.from_numpy(gs['init_ligand_v']).to(dev),
                                    b.ligand_element_batch, num_steps=int(gs['steps']), center_pos_mode='protein',
@@ -220,6 +220,7 @@ def test_gate_and_output_options_sampling_vs_reference():
         assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
         outs.append(r)
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[2]['pos_traj']))
+    assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[1]['pos_traj']))
     with pytest.raises(NotImplementedError, match='32 slots'):
         _model(weights.make_state_dict(SEED), ew_net_type='r', knn=48)
     # x2h_out_fc and sync_twoup are graph-agnostic: on a hybrid graph (chunk-walking kernels) the session and the stateless forward agree
