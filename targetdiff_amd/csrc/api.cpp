@@ -1894,9 +1894,10 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
             }
             lists_done = true;
         } else {
+            // the protein rows' merge and the ligand rows' full search: independent, one launch
             if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
-                                          S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn)) != TD_OK) return rc;
-            if ((rc = td_launch_knn_rows(w.x4a, w.node_ptr, w.gid, w.lig_node, Nl, S->max_graph_nodes, w.nbr, s, m->cfg.knn)) != TD_OK) return rc;
+                                          S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn,
+                                          w.lig_node, Nl, S->max_graph_nodes)) != TD_OK) return rc;
             // every row list of the step (dirty rows, forward reach, receptive-field levels) in one launch, one workgroup per graph;
             // graphs too large for its LDS flags take the separate kernels
             rc = (m->opt.session_step_lists && S->graph_nodes_max > 0) ? td_launch_step_lists(S->clean, w.x4a, w.nbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s)

@@ -121,15 +121,15 @@ constexpr int TD_COMPOSE_ATOMS = 16;
 // STATIC = true builds the protein-only neighbour lists of a sampling session: ligand candidates (x4.w > 0.5) are
 // skipped and the sorted keys are kept (skeys) so that later steps only have to merge the few ligand atoms in.
 template <int CH, bool STATIC>
-__global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
-                                                  const int32_t *__restrict__ gid, const int32_t *__restrict__ rows,
-                                                  int64_t N, int k, int32_t *__restrict__ nbr,
-                                                  unsigned long long *__restrict__ skeys) {
+__device__ __forceinline__ void knn_body(unsigned bid, const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
+                                         const int32_t *__restrict__ gid, const int32_t *__restrict__ rows,
+                                         int64_t N, int k, int32_t *__restrict__ nbr,
+                                         unsigned long long *__restrict__ skeys) {
     // k <= 32 neighbours per row in a 32-slot row (slots >= k: -1).  The k nearest are the first k of the 32 nearest, so
     // every fan-in up to 32 shares the 32-slot fast path; STATIC extracts all 32 keys (the session merges into them).
     const int rounds = STATIC ? TD_K : k;
     const int lane = threadIdx.x & 63;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t qi = (int64_t)bid * 4 + (threadIdx.x >> 6);
     if (qi >= N) return;
     const int64_t i = rows ? (int64_t)rows[qi] : qi;
     const int g = gid[i];
@@ -169,6 +169,13 @@ __global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4,
         nbr[i * TD_K + lane] = (best == TD_KEY_MAX || lane >= k) ? -1 : (int32_t)(unsigned)(best & 0xffffffffull);
         if (STATIC) skeys[i * TD_K + lane] = best;
     }
+}
+template <int CH, bool STATIC>
+__global__ __launch_bounds__(256) void knn_kernel(const float4 *__restrict__ x4, const int32_t *__restrict__ ptr,
+                                                  const int32_t *__restrict__ gid, const int32_t *__restrict__ rows,
+                                                  int64_t N, int k, int32_t *__restrict__ nbr,
+                                                  unsigned long long *__restrict__ skeys) {
+    knn_body<CH, STATIC>(blockIdx.x, x4, ptr, gid, rows, N, k, nbr, skeys);
 }
 
 template <bool STATIC>
@@ -211,14 +218,24 @@ int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_
 // list.  If no ligand atom beats the 32nd static neighbour the row is unchanged ("clean"): its gate row and its
 // layer-0 output are step-invariant too and are copied from the session cache instead of being recomputed.
 // One wave per protein row.  Ligand rows of a graph are contiguous: [node_ptr[g] + n_prot(g), node_ptr[g+1]).
-__global__ __launch_bounds__(256) void knn_merge_kernel(
-    const float4 *__restrict__ x4, const int32_t *__restrict__ ptr, const int32_t *__restrict__ pptr,
-    const int32_t *__restrict__ gid, const int32_t *__restrict__ prot_rows, int64_t Np,
-    const unsigned long long *__restrict__ skeys, const int32_t *__restrict__ snbr, const float *__restrict__ h0,
-    const float *__restrict__ h1s, const float *__restrict__ ews, int32_t *__restrict__ nbr, float *__restrict__ h,
-    float *__restrict__ ew, uint8_t *__restrict__ clean, uint8_t *__restrict__ flags2, int k) {
+struct TdMergeArgs {
+    const float4 *x4; const int32_t *ptr, *pptr, *gid, *prot_rows; int64_t Np;
+    const unsigned long long *skeys; const int32_t *snbr; const float *h0, *h1s, *ews; int32_t *nbr; float *h, *ew;
+    uint8_t *clean, *flags2; int k;
+};
+__device__ __forceinline__ void knn_merge_body(unsigned bid, const TdMergeArgs &ma) {
+    const float4 *__restrict__ x4 = ma.x4;
+    const int32_t *__restrict__ ptr = ma.ptr, *__restrict__ pptr = ma.pptr, *__restrict__ gid = ma.gid, *__restrict__ prot_rows = ma.prot_rows;
+    const int64_t Np = ma.Np;
+    const unsigned long long *__restrict__ skeys = ma.skeys;
+    const int32_t *__restrict__ snbr = ma.snbr;
+    const float *__restrict__ h0 = ma.h0, *__restrict__ h1s = ma.h1s, *__restrict__ ews = ma.ews;
+    int32_t *__restrict__ nbr = ma.nbr;
+    float *__restrict__ h = ma.h, *__restrict__ ew = ma.ew;
+    uint8_t *__restrict__ clean = ma.clean, *__restrict__ flags2 = ma.flags2;
+    const int k = ma.k;
     const int lane = threadIdx.x & 63;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t qi = (int64_t)bid * 4 + (threadIdx.x >> 6);
     if (qi >= Np) return;
     const int64_t i = prot_rows[qi];
     const int g = gid[i];
@@ -324,13 +341,35 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void knn_merge_kernel(TdMergeArgs ma) { knn_merge_body(blockIdx.x, ma); }
+
+// The two independent halves of a session step's neighbour search in ONE launch: the full k-NN search of the ligand rows (blocks [0, GB):
+// a few thousand long, latency-bound waves -- first, so that they run from the start; at the end of the grid they were its tail) and the
+// protein rows' merge (blocks [GB, GB + GA)), which fills in beside them.
+template <int CH>
+__global__ __launch_bounds__(256) void knn_step_kernel(TdMergeArgs ma, unsigned GB, const int32_t *__restrict__ lig_rows, int64_t Nl,
+                                                       int32_t *__restrict__ nbr) {
+    if (blockIdx.x < GB) knn_body<CH, false>(blockIdx.x, ma.x4, ma.ptr, ma.gid, lig_rows, Nl, ma.k, nbr, nullptr);
+    else knn_merge_body(blockIdx.x - GB, ma);
+}
+
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k) {
-    if (Np == 0) return TD_OK;
-    knn_merge_kernel<<<dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, s>>>(x4, node_ptr, pptr, gid, prot_rows, Np, skeys,
-                                                                        snbr, h0, h1s, ews, nbr, h, ew, clean, flags2, k);
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k, const int32_t *lig_rows, int64_t Nl,
+                        int max_graph_nodes) {
+    const TdMergeArgs ma{x4, node_ptr, pptr, gid, prot_rows, Np, skeys, snbr, h0, h1s, ews, nbr, h, ew, clean, flags2, k};
+    const unsigned GA = (unsigned)((Np + 3) / 4), GB = lig_rows ? (unsigned)((Nl + 3) / 4) : 0u;
+    if (GA + GB == 0) return TD_OK;
+    if (GB == 0) {
+        knn_merge_kernel<<<dim3(GA), dim3(256), 0, s>>>(ma);
+    } else {           // (the same candidates-per-lane variants as launch_knn_t)
+        const dim3 grid(GA + GB), block(256);
+        if (max_graph_nodes > 0 && max_graph_nodes <= 256) knn_step_kernel<4><<<grid, block, 0, s>>>(ma, GB, lig_rows, Nl, nbr);
+        else if (max_graph_nodes > 0 && max_graph_nodes <= 384) knn_step_kernel<6><<<grid, block, 0, s>>>(ma, GB, lig_rows, Nl, nbr);
+        else if (max_graph_nodes <= 704) knn_step_kernel<11><<<grid, block, 0, s>>>(ma, GB, lig_rows, Nl, nbr);       // also the "unknown" (0) default
+        else knn_step_kernel<17><<<grid, block, 0, s>>>(ma, GB, lig_rows, Nl, nbr);
+    }
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

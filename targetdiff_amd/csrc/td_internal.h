@@ -188,7 +188,8 @@ int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_
 int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t *pptr, const int32_t *gid,
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
-                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k = TD_K);
+                        uint8_t *clean, uint8_t *flags2, hipStream_t s, int k = TD_K, const int32_t *lig_rows = nullptr, int64_t Nl = 0,
+                        int max_graph_nodes = 0);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
 int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
