@@ -22,6 +22,15 @@ rm -rf "$ROOT/$OUT/stats_c2"
 cd "$ROOT"
 python bench.py --no-cpu-baseline --profile-all --no-full-run --no-sweep > $OUT/bench_c2_profile_all.json 2> $OUT/bench_c2_breakdown.txt
 python tools/wg_balance.py > $OUT/wg_balance_c2.txt 2>/dev/null
+# the same counters at C3 (BASELINE's HBM-roofline run) and C5, so that their bench lines carry roofline.traffic of this build too
+for W in c3 c5; do
+  BENCH_ARGS="--workload $W" PMC_SHORT=1 bash tools/pmc_collect.sh $OUT/pmc_$W > $OUT/pmc_$W.log 2>&1
+  python tools/pmc_summary.py $OUT/pmc_$W > $OUT/pmc_$W.txt
+  cp $OUT/pmc_$W.txt profiles/${TAG}_pmc_$W.txt
+  python tools/traffic_from_pmc.py profiles/${TAG}_pmc_$W.txt $W >> $OUT/traffic.log 2>&1
+  cp profiles/traffic_x2h_value_$W.json profiles/traffic_x2h_key_$W.json $OUT/ 2>/dev/null
+  rm -rf $OUT/pmc_$W
+done
 for W in c1 c3 c5; do python bench.py --workload $W --no-cpu-baseline > $OUT/bench_$W.json 2>/dev/null; done
 python bench.py --workload c5 --no-cpu-baseline --knn 48 > $OUT/bench_c5_knn48.json 2>/dev/null
 python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
