@@ -251,13 +251,51 @@ size_t pack_B128_split(Packer &pk, const float *W, int ld, int col0) {
     return off;
 }
 
+
+// The same 21-wide first layer (k < 20 Gaussians, k = 20 the edge-type column) for the K-PACKED products of
+// td_first_layer_split16<PK>: the six bf16 piece products a_p b_q (p + q <= 4; a = this table, b = the per-edge inputs) of the 21 inputs
+// are 123 (p, q, k) slot pairs -- k = 20 has b = 1.0 exactly, i.e. three -- and fit the 4 x 32 K slots of FOUR v_mfma_f32_16x16x32_bf16
+// (the plain layout spends six, one per product, with 11 of every 32 K slots empty).  Lane group g owns the Gaussians 5g .. 5g+4
+// (k0 .. k4).  Per lane (hidden lo, group g) and hidden block, in halves of four bf16 (slot 2w = low half of word w):
+//   a1, a2, a3 = pieces 1 .. 3 of k0 .. k3;   H6 = (a1, a2, a1, a2)[k4];   H7 = (a3[k4], a1[k4], T, T')
+//   t0: (a1 | a2) x (b1 | b2)     t1: (a1 | a2) x (b2 | b1)     t2: (a3 | H6) x (b1 | p1 p1 p2 p2 [k4])     t3: (a1 | H7) x (b3 | p1 p3 [k4], C)
+// with the type column's three pieces in the spare slot pair: (T, T') = (t1, t2) in group 0, (t3, 0) in group 1, 0 elsewhere; C = (1, 1) /
+// (1, 0) / 0.  One (dst class, source class) table: QA[hb][lane] = (a1 | a2), QB[hb][lane] = (a3 | H6), H7[hb][lane] (8 bytes),
+// QC[hb][lane] = (a1 | H7): a kernel stages QA, QB and either H7 (40 bytes per lane and hidden block: t3's operand is two 8-byte
+// reads, the a1 half of QA and H7) or QC (48 bytes: three 16-byte reads).  w(n, k): the folded first-layer weight, k = 20 = type column.
+constexpr size_t PK4_QA = 0, PK4_QB = (size_t)8 * 64 * 4, PK4_H7 = 2 * PK4_QB, PK4_QC = PK4_H7 + (size_t)8 * 64 * 2;
+constexpr size_t PK4_WORDS = PK4_QC + (size_t)8 * 64 * 4;        // 32-bit words of one (dst class, source class) table: 28 KiB
+template <class F>
+void pack_pk4_table(uint32_t *dst, F w) {
+    for (int hb = 0; hb < 8; ++hb)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lo = lane & 15, g = lane >> 4, n = 16 * hb + lo;
+            uint32_t a[3][6];                          // pieces of k0 .. k4 and of the type column
+            for (int i = 0; i < 6; ++i) {
+                float r = w(n, i < 5 ? 5 * g + i : TD_NG);
+                for (int p = 0; p < 3; ++p) {
+                    a[p][i] = bf16_rne(r);
+                    r -= bf16_to_f32(a[p][i]);
+                }
+            }
+            auto pair = [](uint32_t lo16, uint32_t hi16) { return lo16 | (hi16 << 16); };
+            const size_t e = (size_t)hb * 64 + lane;
+            uint32_t *QA = dst + PK4_QA + e * 4, *QB = dst + PK4_QB + e * 4, *H7 = dst + PK4_H7 + e * 2, *QC = dst + PK4_QC + e * 4;
+            QA[0] = pair(a[0][0], a[0][1]); QA[1] = pair(a[0][2], a[0][3]); QA[2] = pair(a[1][0], a[1][1]); QA[3] = pair(a[1][2], a[1][3]);
+            QB[0] = pair(a[2][0], a[2][1]); QB[1] = pair(a[2][2], a[2][3]); QB[2] = pair(a[0][4], a[1][4]); QB[3] = pair(a[0][4], a[1][4]);
+            H7[0] = pair(a[2][4], a[0][4]);
+            H7[1] = g == 0 ? pair(a[0][5], a[1][5]) : (g == 1 ? pair(a[2][5], 0u) : 0u);
+            QC[0] = QA[0]; QC[1] = QA[1]; QC[2] = H7[0]; QC[3] = H7[1];
+        }
+}
+
 size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     size_t off = pk.alloc(padded ? padded : n);
     if (v) memcpy(pk.data.data() + off, v, n * sizeof(float));
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p, R16q; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int alt) {
     EdgeOff o;
@@ -327,6 +365,15 @@ EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int 
                     }
             }
     }
+    // ... and K-packed (pack_pk4_table): [dst class][source class] x 24 KiB
+    o.R16q = pk.alloc((size_t)2 * 2 * PK4_WORDS);
+    for (int cls = 0; cls < 2; ++cls)
+        for (int sl = 0; sl < 2; ++sl) {
+            const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+            pack_pk4_table(reinterpret_cast<uint32_t *>(pk.data.data() + o.R16q) + ((size_t)cls * 2 + sl) * PK4_WORDS, [&](int n, int k) {
+                return k < TD_NG ? m.w0[(size_t)n * in_dim + 4 + TD_NG * type + k] : m.w0[(size_t)n * in_dim + type];
+            });
+        }
     o.gamma = pack_vec(pk, m.g, TD_H);
     o.beta = pack_vec(pk, m.b, TD_H);
     if (out_dim == TD_H) {
@@ -645,7 +692,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         o.R16p ? D + o.R16p : nullptr, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         o.R16p ? D + o.R16p : nullptr, D + o.R16q, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,

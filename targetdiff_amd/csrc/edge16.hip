@@ -350,7 +350,6 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
 // issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds (before or after the products).
 typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
 constexpr int E16P_U4 = 2 * 2 * 3 * 8 * 48;                 // uint4 entries of the piece table [cls][slot][piece][hb][48] (72 KiB)
-constexpr int E16P_HALF_U4 = E16P_U4 / 2;                   // one destination class
 
 __device__ __forceinline__ floatx4_t td_mfma16b(uint4 a, uint4 b, floatx4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b), c, 0, 0, 0);
@@ -370,10 +369,31 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
     p3 = td_cvt_pk_bf16_e(rx, ry);
 }
 
+// K-packed piece tables (pack_pk4_table, api.cpp): one (dst class, source class) table is QA[hb 8][lane 64] (16 B), QB (16 B), H7 (8 B),
+// QC (16 B) = 28 KiB in global memory; in LDS a kernel keeps QA, QB and either H7 (PK = 2: 20 KiB) or QC (PK = 1: 24 KiB)
+constexpr int E16Q_GLOBAL_CS_U4 = 512 + 512 + 256 + 512;
+template <int PK> constexpr int e16q_cs_u4() { return PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256; }
+template <int PK> constexpr int e16q_u4() { return 4 * e16q_cs_u4<PK>(); }           // all four (dst class, source class) tables
+template <int PK> constexpr int e16q_half_u4() { return 2 * e16q_cs_u4<PK>(); }      // one destination class
+// stage `ncs` consecutive (dst class, source class) tables from the packed blob into LDS (all waves of the workgroup; the caller's
+// barrier publishes them)
+template <int PK>
+__device__ __forceinline__ void td_stage_pk4(const float *__restrict__ src, float *__restrict__ dst, int ncs, int tid, int nthreads) {
+    for (int cs = 0; cs < ncs; ++cs) {
+        const float4 *sp = reinterpret_cast<const float4 *>(src) + (size_t)cs * E16Q_GLOBAL_CS_U4;
+        float4 *dp = reinterpret_cast<float4 *>(dst) + (size_t)cs * e16q_cs_u4<PK>();
+        td_stage_lds16(sp, dp, 1024, tid, nthreads);
+        if (PK == 1) td_stage_lds16(sp + 1280, dp + 1024, 512, tid, nthreads);
+        else td_stage_lds16(sp + 1024, dp + 1024, 256, tid, nthreads);
+    }
+}
+
 // Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
-// offj[j] = Gaussian centre of k = 8g + j (TD_FAR_CENTRE for k >= 20).  Uses r.xi / r.xj / r.j / r.ew and the P_j already gathered into acc.
-// PI_LATE: the P_i loads are issued first and consumed after the products (their latency hides behind the MFMAs at the
-// price of 32 registers); otherwise P_i is added up front.
+// PK = 1 / 2: the K-packed form -- FOUR products per (hidden block, edge block) and source class instead of six: the 21 inputs' six piece
+// products are 123 (piece, piece, k) slot pairs and fit 4 x 32 K slots (pack_pk4_table, api.cpp); lane group g owns the Gaussians
+// 5g .. 5g+4 (offj[0..4]; ten exponentials per lane instead of sixteen) and splits five values per edge instead of eight.  PK = 1: the
+// table in LDS holds QA, QB, QC (three 16-byte reads per hidden block); PK = 2: QA, QB, H7 (40 bytes per lane and hidden block; the
+// fourth product's operand is two 8-byte reads, QA's first half and H7).
 struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // before_products: called once the gathered operands have been consumed (Gaussians computed, P_i added) and before the matrix products
 // are issued -- the place to start loads whose data is needed after the first layer (the key pass's query): the live set is at its
@@ -382,7 +402,7 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // k = 48; the caller tests it, wave-uniform) and costs nothing: no P_i adds, no Gaussians, no products, z = 0 and 1 / sigma = 0.
 // LN_SKIP (NEB = 2 only): the LayerNorm leaves out a second block without edges (z = 0, 1 / sigma = 0) -- what the chunk-walking key pass, which
 // has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, class Hook = TdNoHook>
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, int PK = 0, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ KB,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
@@ -410,7 +430,9 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     if (!PI_LATE) add_pi();
     int slot[NEB];
     bool has[2][NEB];
-    float gv[NEB][8];
+    constexpr bool PK4 = PK != 0;
+    constexpr int NGV = PK4 ? 5 : 8;
+    float gv[NEB][NGV];
     if (NEB == 1) {
         ed.valid[1] = false; ed.any[1] = false; ed.rstd[1] = 0.f;
         ed.rel[1][0] = ed.rel[1][1] = ed.rel[1][2] = 0.f;
@@ -437,15 +459,71 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
         ed.any[eb] = has[0][eb] || has[1][eb];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NGV; ++j) {
             const float u = dist - offj[j];
             gv[eb][j] = __builtin_amdgcn_exp2f(c2 * (u * u));
         }
-        if (g == 2) gv[eb][4] = 1.f;
+        if (!PK4 && g == 2) gv[eb][4] = 1.f;
     }
     before_products();
+    // K-packed products of source class sl: B quads t0 = (b1 | b2)[k0..k3], t1 = (b2 | b1)[k0..k3], t2 = b1[k0..k3] | (p1 p1 p2 p2)[k4],
+    // t3 = b3[k0..k3] | (p1 p3)[k4], type constant; A quads QA (t0 and t1), QB (t2), QC (t3)
+    auto products4 = [&](int sl) {
+        if constexpr (PK4) {
+        uint4 bq[NEB][4];
+        const unsigned ctype = g == 0 ? 0x3f803f80u : (g == 1 ? 0x00003f80u : 0u);       // bf16 1.0 in the type column's slots
+#pragma unroll
+        for (int eb = 0; eb < NEB; ++eb) {
+            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
+            float m[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) m[j] = keep ? gv[eb][j] : 0.f;
+            unsigned d1a, d2a, d3a, d1b, d2b, d3b;
+            td_split_pair(m[0], m[1], d1a, d2a, d3a);
+            td_split_pair(m[2], m[3], d1b, d2b, d3b);
+            // k4 alone: both halves of a word hold the same piece
+            const unsigned u1 = td_cvt_pk_bf16_e(m[4], m[4]);
+            const float r1 = m[4] - __uint_as_float(u1 & 0xffff0000u);
+            const unsigned u2 = td_cvt_pk_bf16_e(r1, r1);
+            const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
+            const unsigned u3 = td_cvt_pk_bf16_e(r2, r2);
+            const unsigned e13 = __builtin_amdgcn_perm(u3, u1, 0x07060100u);      // low half p1, high half p3
+            bq[eb][0] = make_uint4(d1a, d1b, d2a, d2b);
+            bq[eb][1] = make_uint4(d2a, d2b, d1a, d1b);
+            bq[eb][2] = make_uint4(d1a, d1b, u1, u2);
+            bq[eb][3] = make_uint4(d3a, d3b, e13, keep ? ctype : 0u);
+        }
+        const uint4 *Rs = Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane;
+        // PK = 2: the a1 half of QA is read a second time, as the first half of t3's operand, through a pointer the compiler cannot
+        // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
+        const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
+        if constexpr (PK == 2) asm volatile("" : "+v"(Ra));
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            uint4 ar[2][3];                 // A quads of hidden blocks 2hp, 2hp + 1
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int hb = 2 * hp + h2;
+                ar[h2][0] = Rs[hb * 64];
+                ar[h2][1] = Rs[512 + hb * 64];
+                if constexpr (PK == 1) ar[h2][2] = Rs[1024 + hb * 64];
+                else {
+                    const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
+                    ar[h2][2] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                }
+            }
+            // the low-order instructions first; two hidden blocks x two edge blocks interleave four accumulator chains
+#define TD_PROD4(qa, tb)                                                                                 \
+    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < NEB; ++eb)    \
+        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][qa], bq[eb][tb], acc[eb][2 * hp + h2]);
+            TD_PROD4(2, 3) TD_PROD4(1, 2) TD_PROD4(0, 1) TD_PROD4(0, 0)
+#undef TD_PROD4
+        }
+        }
+    };
     // products of source class sl with the edge inputs (B operand: the edge inputs in 3 pieces, zeros for the edges of the other class)
     auto products = [&](int sl) {
+        if constexpr (!PK4) {
         uint4 bm[NEB][3];
 #pragma unroll
         for (int eb = 0; eb < NEB; ++eb) {
@@ -474,12 +552,16 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
         }
+        }
     };
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         bool any_sl = has[sl][0];
         if (NEB == 2) any_sl = any_sl || has[sl][NEB - 1];
-        if (any_sl) products(sl);
+        if (any_sl) {
+            if constexpr (PK4) products4(sl);
+            else products(sl);
+        }
     }
     if (PI_LATE) add_pi();
     if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(KB, g, acc, ed.rstd, ed.any);
@@ -503,7 +585,7 @@ constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, o
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 4) * sizeof(float);       // + the row counter
 constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
-constexpr size_t K16S_LDS_BYTES = (size_t)(E16P_U4 * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
+constexpr size_t K16S_LDS_BYTES = (size_t)(e16q_u4<2>() * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -523,7 +605,7 @@ template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
-    constexpr int RF = SPLIT ? E16P_U4 * 4 : E16_R_FLOATS;       // floats of the radial/type table
+    constexpr int RF = SPLIT ? e16q_u4<2>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed, 40 bytes per lane and hidden block)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -533,22 +615,23 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     const int lo = lane & 15, g = lane >> 4;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
-        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, WAVES * 64);
+        if (SPLIT) td_stage_pk4<2>(a.mlp.R16q, lds, 4, tid, WAVES * 64);
+        else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, WAVES * 64);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + RF), nw4, tid,
                        WAVES * 64);
         if (tid < TD_H) lds[RF + E16_WQ_FLOATS + tid] = a.mlp.beta[tid];
         else if (tid == TD_H) *reinterpret_cast<int *>(lds + RF + E16_WQ_FLOATS + TD_H) = 0;
         else if (SPLIT && tid >= TD_H + 32 && tid < TD_H + 64) {
-            const int k = tid - (TD_H + 32);
-            lds[RF + E16_WQ_FLOATS + TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
+            const int s8 = tid - (TD_H + 32);          // K-packed products: entry 8g + i = centre of k = 5g + i (i < 5)
+            lds[RF + E16_WQ_FLOATS + TD_H + 4 + s8] = (s8 & 7) < 5 ? a.offsets[5 * (s8 >> 3) + (s8 & 7)] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];          // Gaussian centres of the lane's K slots: k = 4s + g (fp32 tiles), k = 8g + s (bf16 tiles)
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
-        const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
+        const int k = SPLIT ? 5 * g + s : 4 * s + g;
+        offk[s] = SPLIT ? (s < 5 ? a.offsets[k] : TD_FAR_CENTRE) : (k < TD_NG ? a.offsets[k] : 0.f);
     }
     __syncthreads();
     if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -598,9 +681,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             // a chunk whose second block is all padding (wave-uniform): the xv pass (8 waves, 256 registers) has room for a path without
             // it; the key pass at 168 registers does not (126 spilled registers) and only leaves the block out of its LayerNorm and logits
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<EW, false, false, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 1, false, 2>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED, 2>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
@@ -774,7 +857,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 // logits and softmax run.  Arithmetic is identical to edge_key16_kernel<false> followed by edge_key16_kernel<true>.
 constexpr int H2X16_WAVES = 8;
 constexpr int H2X16_WX_FLOATS = 8 * 4 * 64;                                  // W2xv16[hb][r][lane]
-template <bool SPLIT> constexpr int h2x16_table_floats() { return SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS / 2; }
+template <bool SPLIT> constexpr int h2x16_table_floats() { return SPLIT ? e16q_half_u4<2>() * 4 : E16_R_FLOATS / 2; }
 template <bool SPLIT> constexpr size_t h2x16_lds_bytes() {
     return (size_t)(2 * h2x16_table_floats<SPLIT>() + E16_WQ_FLOATS + H2X16_WX_FLOATS + 2 * TD_H) * sizeof(float);
 }
@@ -800,9 +883,11 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         // destination class 0 (ligand) is the first half of either table
-        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? a.mlp.R16p : a.mlp.R16), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        if (SPLIT) td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
+        else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
-        td_stage_lds16(reinterpret_cast<const float4 *>(SPLIT ? ar.mlp_v.R16p : ar.mlp_v.R16), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        if (SPLIT) td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
+        else td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
         if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
         else if (tid < 2 * TD_H) GB[tid] = ar.mlp_v.beta[tid - TD_H];
@@ -810,8 +895,8 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     float offk[NOFF];
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
-        const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
+        const int k = SPLIT ? 5 * g + s : 4 * s + g;         // (SPLIT: the K-packed products' assignment, five per lane group)
+        offk[s] = SPLIT ? (s < 5 ? a.offsets[k] : TD_FAR_CENTRE) : (k < TD_NG ? a.offsets[k] : 0.f);
     }
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
@@ -829,7 +914,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         Edge2 ed;
         td_row_index16(a, i, i, lane, rin);
         td_row_gather16<true>(a, i, i, lane, rin, acc);
-        if constexpr (SPLIT) td_first_layer_split16<true, true, false>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+        if constexpr (SPLIT) td_first_layer_split16<true, true, false, 2, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
         else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), KBk, offk, rin, lane, acc, ed);
         // the value half's gathers (its own accumulators) fly while the logits and the softmax run.  The query is fetched BEFORE they are
         // issued: vmcnt counts in order, so a load issued after the gathers could only be waited for together with them -- and the
@@ -864,7 +949,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
-        if constexpr (SPLIT) td_first_layer_split16<false, true, false>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
+        if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
         else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), KBv, offk, rv, lane, accv, ev);
         floatx4_t xv[2];
 #pragma unroll
@@ -922,16 +1007,16 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
-        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16p), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
-        td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16p), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
         if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
         else if (tid < 2 * TD_H) GB[tid] = ar.mlp_v.beta[tid - TD_H];
     }
     float offk[8];
 #pragma unroll
-    for (int sx = 0; sx < 8; ++sx) offk[sx] = (8 * g + sx) < TD_NG ? a.offsets[8 * g + sx] : TD_FAR_CENTRE;
+    for (int sx = 0; sx < 8; ++sx) offk[sx] = sx < 5 ? a.offsets[5 * g + sx] : TD_FAR_CENTRE;          // K-packed products: five Gaussians per lane group
     int64_t begin, end;
     td_node_range16(a.count, a.count_ptr, begin, end);
     Args16 av = a;
@@ -952,9 +1037,9 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
             td_row_index16(a, i, c, lane, rin);
             td_row_gather16<false>(a, i, c, lane, rin, acc);
             if (__ballot(rin.j[1] >= 0) == 0ull)              // wave-uniform: the chunk's second block is all padding
-                td_first_layer_split16<false, true, false, 1>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 1, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
             else
-                td_first_layer_split16<false, true, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 2, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
             floatx4_t lg[2];
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -1017,9 +1102,9 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
             td_row_gather16<false>(av, i, c, lane, rin, acc);
             const float ew0 = a.ew[(size_t)c * TD_K + lo], ew1 = a.ew[(size_t)c * TD_K + 16 + lo];       // 0 on pads
             if (__ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<false, true, false, 1>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 1, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
             else
-                td_first_layer_split16<false, true, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 2, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
             floatx4_t xv[2];
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -1054,6 +1139,9 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
 
 // ================================================================================================ value pass (x2h)
 constexpr int V16_WAVES = 8;
+#ifndef TD_VALUE_PK
+#define TD_VALUE_PK 1          // K-packed first layer with QC in LDS (48 bytes per lane and hidden block: the value pass has the room)
+#endif
 constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
 constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidden + 4]
 constexpr int V16_ZB_STRIDE = 132;
@@ -1067,7 +1155,8 @@ constexpr int V16_SB_FLOATS = 48;                         // per wave: S[16 head
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
-    (size_t)(E16P_HALF_U4 * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
+    (size_t)(e16q_half_u4<TD_VALUE_PK>() * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
+static_assert(V16S_LDS_BYTES <= 160 * 1024, "value pass: LDS");
 
 // SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
 // (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
@@ -1090,7 +1179,7 @@ constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // which enters the output linearly, it multiplies the attention weight instead: alpha_e e_w_e feeds both the aggregation and S.
 template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
-    constexpr int RF = SPLIT ? E16P_HALF_U4 * 4 : E16_R_FLOATS;
+    constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -1131,23 +1220,23 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     const int GP = gridDim.x - GL;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
-        td_stage_lds16(SPLIT ? reinterpret_cast<const float4 *>(a.mlp.R16p) + my_cls * E16P_HALF_U4 : reinterpret_cast<const float4 *>(a.mlp.R16),
-                       reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
+        if (SPLIT) td_stage_pk4<TD_VALUE_PK>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 2, tid, V16_WAVES * 64);
+        else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid,
                        V16_WAVES * 64);
         if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
         else if (tid < 2 * TD_H) B2[tid] = a.mlp.beta[tid - TD_H];
         else if (tid == 2 * TD_H) *reinterpret_cast<int *>(B2 + 2 * TD_H) = 0;
         else if (SPLIT && tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {           // Gaussian centres, read per row (see edge_key16_kernel)
-            const int k = tid - (2 * TD_H + 32);
-            B2[2 * TD_H + 4 + k] = k < TD_NG ? a.offsets[k] : TD_FAR_CENTRE;
+            const int s8 = tid - (2 * TD_H + 32);          // K-packed products: entry 8g + i = centre of k = 5g + i (i < 5)
+            B2[2 * TD_H + 4 + s8] = (s8 & 7) < 5 ? a.offsets[5 * (s8 >> 3) + (s8 & 7)] : TD_FAR_CENTRE;
         }
     }
     float offk[NOFF];
 #pragma unroll
     for (int s = 0; s < NOFF; ++s) {
-        const int k = SPLIT ? 8 * g + s : 4 * s + g;
-        offk[s] = k < TD_NG ? a.offsets[k] : (SPLIT ? TD_FAR_CENTRE : 0.f);
+        const int k = SPLIT ? 5 * g + s : 4 * s + g;         // (SPLIT: the K-packed products' assignment, five per lane group)
+        offk[s] = SPLIT ? (s < 5 ? a.offsets[k] : TD_FAR_CENTRE) : (k < TD_NG ? a.offsets[k] : 0.f);
     }
     __syncthreads();
     if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -1274,7 +1363,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         }
                     }
                     if constexpr (SPLIT)
-                        td_first_layer_split16<false, true, false, FULL ? 2 : 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
                     else
                         td_first_layer_compute16<false, true>(a, Rt, KB, offk, rcur, lane, acc, ed);
                     float part = (al[0] + al[1]) + (al[2] + al[3]);
@@ -1394,7 +1483,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
-            td_first_layer_split16<false, true, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+            td_first_layer_split16<false, true, true, 2, false, TD_VALUE_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);

@@ -62,6 +62,8 @@ struct TdEdgeMlp {
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
     const float *R16p;     // the radial/type table as bf16 piece triples for v_mfma_f32_16x16x32_bf16:
                            // [2 dst class][2 slot][3 piece][8 hidden block][48 lanes (k group g < 3)] x 8 bf16 (k = 8g + j)
+    const float *R16q;     // the same pieces K-packed for four instead of six products per tile (pack_pk4_table, api.cpp):
+                           // [2 dst class][2 slot][8 hidden block][3 quad][64 lanes] x 8 bf16
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
                            // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
