@@ -373,7 +373,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 // QC (16 B) = 28 KiB in global memory; in LDS a kernel keeps QA, QB and either H7 (PK = 2: 20 KiB) or QC (PK = 1: 24 KiB)
 constexpr int E16Q_GLOBAL_CS_U4 = 512 + 512 + 256 + 512;
 template <int PK> constexpr int e16q_cs_u4() { return PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256; }
-template <int PK> constexpr int e16q_u4() { return 4 * e16q_cs_u4<PK>(); }           // all four (dst class, source class) tables
+template <int PK> constexpr int e16q_u4() { return PK == 3 ? 2 * e16q_cs_u4<2>() + 2 * e16q_cs_u4<1>() : 4 * e16q_cs_u4<PK>(); }   // all four (dst class, source class) tables
 template <int PK> constexpr int e16q_half_u4() { return 2 * e16q_cs_u4<PK>(); }      // one destination class
 // stage `ncs` consecutive (dst class, source class) tables from the packed blob into LDS (all waves of the workgroup; the caller's
 // barrier publishes them)
@@ -493,32 +493,42 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             bq[eb][2] = make_uint4(d1a, d1b, u1, u2);
             bq[eb][3] = make_uint4(d3a, d3b, e13, keep ? ctype : 0u);
         }
-        const uint4 *Rs = Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane;
-        // PK = 2: the a1 half of QA is read a second time, as the first half of t3's operand, through a pointer the compiler cannot
-        // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
-        const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
-        if constexpr (PK == 2) asm volatile("" : "+v"(Ra));
+        // PK = 3 (all four tables resident, key pass): the protein-destination tables in the 48-byte form, the ligand-destination ones
+        // (one row in 25) in the 40-byte form -- together 88 KiB
+        auto tiles = [&](auto pk_tag, const uint4 *Rs) {
+            constexpr int PKR = decltype(pk_tag)::value;
+            // PKR = 2: the a1 half of QA is read a second time, as the first half of t3's operand, through a pointer the compiler cannot
+            // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
+            const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
+            if constexpr (PKR == 2) asm volatile("" : "+v"(Ra));
 #pragma unroll
-        for (int hp = 0; hp < 4; ++hp) {
-            uint4 ar[2][3];                 // A quads of hidden blocks 2hp, 2hp + 1
+            for (int hp = 0; hp < 4; ++hp) {
+                uint4 ar[2][3];                 // A quads of hidden blocks 2hp, 2hp + 1
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int hb = 2 * hp + h2;
-                ar[h2][0] = Rs[hb * 64];
-                ar[h2][1] = Rs[512 + hb * 64];
-                if constexpr (PK == 1) ar[h2][2] = Rs[1024 + hb * 64];
-                else {
-                    const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
-                    ar[h2][2] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int hb = 2 * hp + h2;
+                    ar[h2][0] = Rs[hb * 64];
+                    ar[h2][1] = Rs[512 + hb * 64];
+                    if constexpr (PKR == 1) ar[h2][2] = Rs[1024 + hb * 64];
+                    else {
+                        const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
+                        ar[h2][2] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                    }
                 }
-            }
-            // the low-order instructions first; two hidden blocks x two edge blocks interleave four accumulator chains
+                // the low-order instructions first; two hidden blocks x two edge blocks interleave four accumulator chains
 #define TD_PROD4(qa, tb)                                                                                 \
     _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < NEB; ++eb)    \
         acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][qa], bq[eb][tb], acc[eb][2 * hp + h2]);
-            TD_PROD4(2, 3) TD_PROD4(1, 2) TD_PROD4(0, 1) TD_PROD4(0, 0)
+                TD_PROD4(2, 3) TD_PROD4(1, 2) TD_PROD4(0, 1) TD_PROD4(0, 0)
 #undef TD_PROD4
-        }
+            }
+        };
+        if constexpr (PK == 3) {
+            static_assert(PK != 3 || !ONE_CLASS, "PK = 3 holds both destination classes");
+            if (cls) tiles(std::integral_constant<int, 1>(), Rp + 2 * e16q_cs_u4<2>() + (size_t)sl * e16q_cs_u4<1>() + lane);
+            else tiles(std::integral_constant<int, 2>(), Rp + (size_t)sl * e16q_cs_u4<2>() + lane);
+        } else
+            tiles(std::integral_constant<int, PK>(), Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane);
         }
     };
     // products of source class sl with the edge inputs (B operand: the edge inputs in 3 pieces, zeros for the edges of the other class)
@@ -585,7 +595,11 @@ constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, o
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 4) * sizeof(float);       // + the row counter
 constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
-constexpr size_t K16S_LDS_BYTES = (size_t)(e16q_u4<2>() * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);        // + the row counter, the Gaussian centres
+#ifndef TD_KEY_PK
+#define TD_KEY_PK 3
+#endif
+constexpr size_t K16S_LDS_BYTES = (size_t)(e16q_u4<TD_KEY_PK>() * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);
+static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the row counter, the Gaussian centres
 
 // XV = false: key pass (logits -> softmax -> alpha).
 // XV = true : h2x value pass.  xv[e][head] = W2xv[head, :] . z_e + b has the shape of the logits product with a static
@@ -605,7 +619,7 @@ template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
-    constexpr int RF = SPLIT ? e16q_u4<2>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed, 40 bytes per lane and hidden block)
+    constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -615,7 +629,13 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     const int lo = lane & 15, g = lane >> 4;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
-        if (SPLIT) td_stage_pk4<2>(a.mlp.R16q, lds, 4, tid, WAVES * 64);
+        if (SPLIT) {
+            if constexpr (TD_KEY_PK == 3) {
+                td_stage_pk4<2>(a.mlp.R16q, lds, 2, tid, WAVES * 64);
+                td_stage_pk4<1>(a.mlp.R16q + (size_t)2 * E16Q_GLOBAL_CS_U4 * 4, lds + 2 * e16q_cs_u4<2>() * 4, 2, tid, WAVES * 64);
+            } else
+                td_stage_pk4<TD_KEY_PK>(a.mlp.R16q, lds, 4, tid, WAVES * 64);
+        }
         else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, WAVES * 64);
         const int nw4 = XV ? 8 * 4 * 64 / 4 : E16_WQ_FLOATS / 4;      // XV: W2xv16[hb][r][lane]
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(lds + RF), nw4, tid,
@@ -681,9 +701,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             // a chunk whose second block is all padding (wave-uniform): the xv pass (8 waves, 256 registers) has room for a path without
             // it; the key pass at 168 registers does not (126 spilled registers) and only leaves the block out of its LayerNorm and logits
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<EW, false, false, 1, false, 2>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 1, false, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED, 2>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
