@@ -132,19 +132,34 @@ struct Cursor {
 //    compute neither a mean nor a subtraction;
 //  * beta_n / a_n replaces beta, a_n goes into column n of the second Linear, and 1 / sigma (one number per edge) multiplies the
 //    second layer's per-edge result in the consumer (logit, xv, or the attention weight of the aggregation).
-// Exact algebra; per hidden value the kernels are left with one FMA for the variance, one FMA and one max.  (gamma_n = 0 is carried
-// as a_n = 1e-20: the unit's constant relu(beta_n) survives, nothing overflows for |beta sigma| < 1e18.)
+// Exact algebra.  (gamma_n = 0 is carried as a_n = 1e-20: the unit's constant relu(beta_n) survives.)
+// Round 5 -- the ReLU as the FMA's own output clamp.  Dividing by sigma M instead of carrying sigma along,
+//     relu(s_n c_n / sigma + beta_n / a_n) / M = clamp_[0,1](s_n c_n (1 / (sigma M)) + beta_n / (a_n M)),
+// holds whenever the left side never exceeds 1: |c_n| <= sqrt(hid) sigma (the c_n are centred and sigma^2 >= their mean square), so
+// M = (sqrt(hid) + max_n beta_n / a_n) (1 + 2^-10) does.  v_fma_f32 has a free clamp-to-[0, 1] output modifier: ONE instruction per hidden
+// value where the round-4 form took an FMA and a max, no per-edge 1 / sigma for the consumers to apply (M a_n goes into column n of the
+// second Linear instead of a_n), and the kernels keep s_e = 1 / (sigma_e M) per edge only as the FMA's multiplier.
 struct FoldedMlp {
     std::vector<float> w0, b0, g, b, w3;
     const float *b3;
+    float ln_c1 = 1.f / 128.f, ln_c2 = 1e-5f;        // the kernels' variance constants (below)
     FoldedMlp(const MlpSrc &m, int in, int hid, int out) : w0((size_t)hid * in), b0(hid), g(hid), b(hid), w3((size_t)out * hid), b3(m.b3) {
         std::vector<float> sg(hid);
+        double bmax = 0.0;
         for (int n = 0; n < hid; ++n) {
             const float a = fabsf(m.g[n]) > 1e-20f ? fabsf(m.g[n]) : 1e-20f;
             sg[n] = m.g[n] < 0.f ? -1.f : 1.f;
             g[n] = a;
             b[n] = m.b[n] / a;
+            if ((double)b[n] > bmax) bmax = (double)b[n];
         }
+        const double M = (sqrt((double)hid) + bmax) * (1.0 + 1.0 / 1024.0);
+        for (int n = 0; n < hid; ++n) {
+            b[n] = (float)((double)b[n] / M);
+            g[n] = (float)((double)g[n] * M);          // what column n of the second Linear carries
+        }
+        ln_c1 = (float)(M * M / hid);                  // 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2)
+        ln_c2 = (float)(1e-5 * M * M);
         for (int k = 0; k < in; ++k) {
             double mean = 0.0;
             for (int n = 0; n < hid; ++n) mean += (double)m.w0[(size_t)n * in + k];
@@ -295,10 +310,12 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p, R16q; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p, R16q; float ln_c1, ln_c2; };
 
-EdgeOff pack_edge_mlp(Packer &pk, const MlpSrc &m, int in_dim, int out_dim, int alt) {
+EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, int alt) {
+    const MlpSrc m = fm.src();
     EdgeOff o;
+    o.ln_c1 = fm.ln_c1; o.ln_c2 = fm.ln_c2;
     o.Walt = 0;
     o.Walt16 = 0;
     // first layer radial / type table: [cls][slot][kstep][lane][ntile]
@@ -641,8 +658,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
                 o.nob2 = pack_vec(pk, nout.b3, TD_H);
             }
             o.nx = pack_node_stage(pk, hk, hv, hq, KV);
-            o.hk = pack_edge_mlp(pk, hk, KV, H, 1);
-            o.hv = pack_edge_mlp(pk, hv, KV, H, 2);
+            o.hk = pack_edge_mlp(pk, fhk, KV, H, 1);
+            o.hv = pack_edge_mlp(pk, fhv, KV, H, 2);
             o.has_x = true;
         }
         for (int j = 0; j < NH && cur.ok; ++j) {
@@ -654,8 +671,8 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             xk = fxk.src(); xv = fxv.src();
             if (c.ew_net_type != 0) gate_rows(o.ew_h2x, ewh);
             o.nh = pack_node_stage(pk, xk, xv, xq, KV);
-            o.xk = pack_edge_mlp(pk, xk, KV, H, 1);
-            o.xv = pack_edge_mlp(pk, xv, KV, c.n_heads, 0);
+            o.xk = pack_edge_mlp(pk, fxk, KV, H, 1);
+            o.xv = pack_edge_mlp(pk, fxv, KV, c.n_heads, 0);
             o.has_h = true;
         }
     }
@@ -689,10 +706,10 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     }
     const float *D = m->blob;
     m->emb = TdEmbed{D + oWpT, D + obp, D + oWlT, D + obl};
-    m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, m->opt.edge_key_split != 0};
+    m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         o.R16p ? D + o.R16p : nullptr, D + o.R16q, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         o.R16p ? D + o.R16p : nullptr, D + o.R16q, o.ln_c1, o.ln_c2, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,

@@ -149,15 +149,12 @@ __device__ __forceinline__ void td_sum16x4(float (&v)[4]) {
 // softmax over the 32 edges of a row for the four heads 4g + r of the lane group (lg[eb][r] = logit of edge 16eb + lo), times the edge
 // gate: p[eb][r] = exp(x - max) / sum * ew[eb].  A pad's logit is -inf, so its weight is exp(-inf) = 0 without a select; a row without
 // edges gets zeros.  1 / sum is v_rcp_f32 (1 ulp; the correctly rounded __frcp_rn is an 11-instruction sequence per head).
-// rstd[eb]: 1 / sigma of the edge's LayerNorm, which td_ln_relu16 leaves to the consumer of the second layer (the logit is linear in z).
-__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], const float (&rstd)[2],
-                                               floatx4_t (&p)[2]) {
+__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], floatx4_t (&p)[2]) {
     float x0[4], x1[4], mx[4], sm[4];
-    const float sc0 = rstd[0] * TD_ATT_SCALE_16, sc1 = rstd[1] * TD_ATT_SCALE_16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        x0[r] = valid[0] ? lg[0][r] * sc0 : -INFINITY;
-        x1[r] = valid[1] ? lg[1][r] * sc1 : -INFINITY;
+        x0[r] = valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
+        x1[r] = valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
         mx[r] = fmaxf(x0[r], x1[r]);
     }
     td_max16x4(mx);
@@ -182,7 +179,6 @@ struct Edge2 {          // the two edges (lo and 16 + lo) a lane looks at
     bool valid[2];
     bool any[2];       // wave-uniform: does the 16-edge block hold any edge at all (false: all pads, e.g. slots 48 .. 63 at k = 48)
     float ew[2];
-    float rstd[2];     // 1 / sigma of the edge's LayerNorm: multiplies the second layer's per-edge result (td_ln_relu16)
     float rel[2][3];   // x_i - x_j
     float4 xi;
 };
@@ -228,14 +224,14 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
 
 // LayerNorm + ReLU of an edge MLP in the transposed accumulator layout (a lane owns 32 of an edge's 128 hidden units for each of its
 // two edges; the other 96 sit in the lanes lo + 16 g'), in the folded form the weights are packed for (FoldedMlp, api.cpp): the
-// accumulators hold the CENTRED pre-activation with the sign of gamma applied, KB[n] = beta_n / |gamma_n|, and
-//     z'_n = relu(acc_n + sigma KB[n]),   sigma = sqrt(mean_n acc_n^2 + eps)
-// is the normalised activation times sigma / |gamma_n|: |gamma_n| sits in the second Linear's columns, rstd = 1 / sigma is returned for
-// the consumer to apply to the second layer's per-edge result.  Per hidden value: one FMA (variance), one FMA, one max.
-// SKIP_EMPTY: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 instead of the LayerNorm of its padding
+// accumulators hold the CENTRED pre-activation with the sign of gamma applied, KB[n] = beta_n / (|gamma_n| M), and
+//     z''_n = clamp_[0,1](acc_n s + KB[n]),   s = 1 / (sigma M) = rsqrt(sum_n acc_n^2 * ln.c1 + ln.c2)
+// is the normalised activation over |gamma_n| M (M bounds it by 1, so the FMA's output clamp IS the ReLU); |gamma_n| M sits in the second
+// Linear's columns, nothing is left for the consumer to apply.  Per hidden value: one FMA (variance) and one FMA with the clamp modifier.
 // NEB = 1: only the first edge block is live (the caller has zeroed the second one)
+struct TdLn { float c1, c2; };
 template <int NEB = 2>
-__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2]) {
+__device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], const TdLn ln) {
     float s2[NEB];
 #pragma unroll
     for (int eb = 0; eb < NEB; ++eb) {
@@ -247,36 +243,30 @@ __device__ __forceinline__ void td_ln_relu16(const float *__restrict__ KB, int g
         }
         s2[eb] = sa + sb;
     }
-    float sig[NEB];
+    float sc[NEB];
 #pragma unroll
-    for (int eb = 0; eb < NEB; ++eb) {
-        const float var = td_sum_groups(s2[eb]) * (1.0f / TD_H) + 1e-5f;
-        rstd[eb] = __frsqrt_rn(var);
-        sig[eb] = var * rstd[eb];
-    }
+    for (int eb = 0; eb < NEB; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(s2[eb]), ln.c1, ln.c2));
 #pragma unroll
     for (int hb = 0; hb < 8; ++hb) {
         const float4 kb = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
 #pragma unroll
         for (int eb = 0; eb < NEB; ++eb) {
-            acc[eb][hb][0] = fmaxf(fmaf(sig[eb], kb.x, acc[eb][hb][0]), 0.f);
-            acc[eb][hb][1] = fmaxf(fmaf(sig[eb], kb.y, acc[eb][hb][1]), 0.f);
-            acc[eb][hb][2] = fmaxf(fmaf(sig[eb], kb.z, acc[eb][hb][2]), 0.f);
-            acc[eb][hb][3] = fmaxf(fmaf(sig[eb], kb.w, acc[eb][hb][3]), 0.f);
+            acc[eb][hb][0] = td_clamp01(fmaf(acc[eb][hb][0], sc[eb], kb.x));
+            acc[eb][hb][1] = td_clamp01(fmaf(acc[eb][hb][1], sc[eb], kb.y));
+            acc[eb][hb][2] = td_clamp01(fmaf(acc[eb][hb][2], sc[eb], kb.z));
+            acc[eb][hb][3] = td_clamp01(fmaf(acc[eb][hb][3], sc[eb], kb.w));
         }
     }
 }
-// fp32 first layer on general graphs: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 and 1 / sigma = 0 instead of the
-// LayerNorm of its padding
-__device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], float (&rstd)[2],
+// general graphs: a block without a single edge (any[eb] false, wave-uniform) gets z = 0 instead of the LayerNorm of its padding
+__device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, int g, floatx4_t (&acc)[2][8], const TdLn ln,
                                                   const bool (&any)[2]) {
     if (any[1]) {
-        td_ln_relu16<2>(KB, g, acc, rstd);
+        td_ln_relu16<2>(KB, g, acc, ln);
     } else {
-        td_ln_relu16<1>(KB, g, acc, rstd);
+        td_ln_relu16<1>(KB, g, acc, ln);
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) acc[1][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
-        rstd[1] = 0.f;
     }
 }
 
@@ -338,8 +328,9 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
             }
         }
     }
-    if (SKIP_EMPTY) td_ln_relu16_skip(KB, g, acc, ed.rstd, ed.any);
-    else td_ln_relu16<2>(KB, g, acc, ed.rstd);
+    const TdLn ln{a.mlp.ln_c1, a.mlp.ln_c2};
+    if (SKIP_EMPTY) td_ln_relu16_skip(KB, g, acc, ln, ed.any);
+    else td_ln_relu16<2>(KB, g, acc, ln);
 }
 
 // ---- the same first layer on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
@@ -434,7 +425,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     constexpr int NGV = PK4 ? 5 : 8;
     float gv[NEB][NGV];
     if (NEB == 1) {
-        ed.valid[1] = false; ed.any[1] = false; ed.rstd[1] = 0.f;
+        ed.valid[1] = false; ed.any[1] = false;
         ed.rel[1][0] = ed.rel[1][1] = ed.rel[1][2] = 0.f;
         if (LOAD_EW) ed.ew[1] = 0.f;
 #pragma unroll
@@ -574,8 +565,9 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         }
     }
     if (PI_LATE) add_pi();
-    if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(KB, g, acc, ed.rstd, ed.any);
-    else td_ln_relu16<NEB>(KB, g, acc, ed.rstd);
+    const TdLn ln{a.mlp.ln_c1, a.mlp.ln_c2};
+    if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(KB, g, acc, ln, ed.any);
+    else td_ln_relu16<NEB>(KB, g, acc, ln);
 }
 
 template <bool LOAD_EW, bool SKIP_EMPTY = false>
@@ -748,7 +740,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                     const float *ap = a.alpha + ((size_t)c * TD_HEADS + 4 * g + r) * TD_K + lo;
 #pragma unroll
                     for (int eb = 0; eb < 2; ++eb) {
-                        const float wgt = ed.valid[eb] ? ap[16 * eb] * fmaf(xv[eb][r], ed.rstd[eb], bias) : 0.f;
+                        const float wgt = ed.valid[eb] ? ap[16 * eb] * (xv[eb][r] + bias) : 0.f;
                         sx = fmaf(wgt, ed.rel[eb][0], sx);
                         sy = fmaf(wgt, ed.rel[eb][1], sy);
                         sz = fmaf(wgt, ed.rel[eb][2], sz);
@@ -800,7 +792,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             }
             // ---- softmax over the 32 edges for heads 4g .. 4g+3 (register r), times the edge gate ---------------------
             floatx4_t pr[2];
-            td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, pr);
+            td_softmax16x4(lg, ed.valid, ed.ew, pr);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
@@ -818,7 +810,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             first_layer(i, c, acc, ed);
             logits(acc, lg, ed);
             float x0[4], x1[4], mn[4], ps[4];
-            const float sc0 = ed.rstd[0] * TD_ATT_SCALE_16, sc1 = ed.rstd[1] * TD_ATT_SCALE_16;
+            const float sc0 = TD_ATT_SCALE_16, sc1 = TD_ATT_SCALE_16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 x0[r] = ed.valid[0] ? lg[0][r] * sc0 : -INFINITY;
@@ -922,6 +914,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     td_node_range16(a.count, a.count_ptr, begin, end);
     Args16 av = a;
     av.p_off = 2 * TD_H;
+    av.mlp.ln_c1 = ar.mlp_v.ln_c1; av.mlp.ln_c2 = ar.mlp_v.ln_c2;      // the value half's LayerNorm constants (its tables come through Rv / KBv)
     const float b2 = ar.mlp_v.b2[lo];
     __syncthreads();
     if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -966,7 +959,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
             }
         }
         floatx4_t al[2];
-        td_softmax16x4(lg, ed.valid, ed.ew, ed.rstd, al);
+        td_softmax16x4(lg, ed.valid, ed.ew, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
         if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
@@ -992,7 +985,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
             const float bias = __shfl(b2, 4 * g + r);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) {
-                const float wgt = ev.valid[eb] ? al[eb][r] * fmaf(xv[eb][r], ev.rstd[eb], bias) : 0.f;
+                const float wgt = ev.valid[eb] ? al[eb][r] * (xv[eb][r] + bias) : 0.f;
                 sx = fmaf(wgt, ev.rel[eb][0], sx);
                 sy = fmaf(wgt, ev.rel[eb][1], sy);
                 sz = fmaf(wgt, ev.rel[eb][2], sz);
@@ -1041,6 +1034,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
     td_node_range16(a.count, a.count_ptr, begin, end);
     Args16 av = a;
     av.p_off = 2 * TD_H;
+    av.mlp.ln_c1 = ar.mlp_v.ln_c1; av.mlp.ln_c2 = ar.mlp_v.ln_c2;      // the value half's LayerNorm constants (its tables come through Rv / KBv)
     const float b2 = ar.mlp_v.b2[lo];
     __syncthreads();
     for (int64_t it = begin + wid; it < end; it += WAVES) {
@@ -1080,7 +1074,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
                 w0 = n0; w1 = n1;
             }
             float x0[4], x1[4], mn[4], ps[4];
-            const float sc0 = ed.rstd[0] * TD_ATT_SCALE_16, sc1 = ed.rstd[1] * TD_ATT_SCALE_16;
+            const float sc0 = TD_ATT_SCALE_16, sc1 = TD_ATT_SCALE_16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 x0[r] = ed.valid[0] ? lg[0][r] * sc0 : -INFINITY;
@@ -1143,7 +1137,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
                 const float ex[2] = {__expf(lp[0] - mrun[r]) * inv[r] * ew0, __expf(lp[16] - mrun[r]) * inv[r] * ew1};
 #pragma unroll
                 for (int eb = 0; eb < 2; ++eb) {
-                    const float wgt = ed.valid[eb] ? ex[eb] * fmaf(xv[eb][r], ed.rstd[eb], bias) : 0.f;
+                    const float wgt = ed.valid[eb] ? ex[eb] * (xv[eb][r] + bias) : 0.f;
                     sx = fmaf(wgt, ed.rel[eb][0], sx);
                     sy = fmaf(wgt, ed.rel[eb][1], sy);
                     sz = fmaf(wgt, ed.rel[eb][2], sz);
@@ -1209,15 +1203,14 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     float *TB = lds + RF + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
     float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * V16_SB_FLOATS, *RS = SB + 16;
     float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS;
-    // the attention weights of the aggregation product (A operand: edge 8g + s, head lo) times the edges' 1 / sigma, which the first
-    // layer leaves in the lanes of the z^T layout (edge 16eb + lo): 32 floats through the wave's own LDS
+    // GATE_M: the attention weights of the aggregation product (A operand: edge 8g + s, head lo) times the edges' gates, which are computed
+    // in the lanes of the z^T layout (edge 16eb + lo): 32 floats through the wave's own LDS
     auto scale_edges = [&](float (&alx)[8], float v0, float v1) {          // alx[s] *= v of edge 8g + s (v0 / v1: the lane's two edges)
         if (g < 2) RS[16 * g + lo] = g == 0 ? v0 : v1;
         const float4 r0 = *reinterpret_cast<const float4 *>(RS + 8 * g), r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
         alx[0] *= r0.x; alx[1] *= r0.y; alx[2] *= r0.z; alx[3] *= r0.w; alx[4] *= r1.x; alx[5] *= r1.y; alx[6] *= r1.z; alx[7] *= r1.w;
     };
-    auto scale_alpha = [&](float (&alx)[8], const Edge2 &ed) { scale_edges(alx, ed.rstd[0], ed.rstd[1]); };
-    const float *KB = B2 + TD_H;                          // beta / |gamma| of the folded LayerNorm (td_ln_relu16)
+    const float *KB = B2 + TD_H;                          // beta / (|gamma| M) of the folded LayerNorm (td_ln_relu16)
     // SPLIT: workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0)
     int my_cls = 1, GL = 0;
     int64_t n_rows = 0;
@@ -1389,15 +1382,6 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                     float part = (al[0] + al[1]) + (al[2] + al[3]);
                     if constexpr (FULL) part += (al[4] + al[5]) + (al[6] + al[7]);
                     asum += part;
-                    {   // times the edges' 1 / sigma (see scale_alpha)
-                        if (g < 2) RS[16 * g + lo] = g == 0 ? ed.rstd[0] : ed.rstd[1];
-                        const float4 r0 = *reinterpret_cast<const float4 *>(RS + (FULL ? 8 : 4) * g);
-                        al[0] *= r0.x; al[1] *= r0.y; al[2] *= r0.z; al[3] *= r0.w;
-                        if constexpr (FULL) {
-                            const float4 r1 = *reinterpret_cast<const float4 *>(RS + 8 * g + 4);
-                            al[4] *= r1.x; al[5] *= r1.y; al[6] *= r1.z; al[7] *= r1.w;
-                        }
-                    }
                     auto flip_store = [&](int hb) {
                         float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
@@ -1522,13 +1506,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             const float cm = a.gate_m[TD_H];
             float gm[2];
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb) gm[eb] = 1.0f / (1.0f + expf(-fmaf(td_sum_groups(part[eb]), ed.rstd[eb], cm)));
+            for (int eb = 0; eb < 2; ++eb) gm[eb] = 1.0f / (1.0f + expf(-(td_sum_groups(part[eb]) + cm)));
             scale_edges(al, gm[0], gm[1]);
         }
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
         if (lane < TD_HEADS) SB[lane] = ssum;
-        scale_alpha(al, ed);
 
         // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time: flip z^T (lane = edge) through
         //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
@@ -1689,8 +1672,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
             TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
 #undef TD_PROD
         }
-        float rstd[2];
-        td_ln_relu16<2>(BET, g, acc, rstd);
+        td_ln_relu16<2>(BET, g, acc, TdLn{gt.ln_c1, gt.ln_c2});
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
             float part = 0.f;
@@ -1700,7 +1682,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
                 part = fmaf(acc[eb][hb][0], w.x, part); part = fmaf(acc[eb][hb][1], w.y, part);
                 part = fmaf(acc[eb][hb][2], w.z, part); part = fmaf(acc[eb][hb][3], w.w, part);
             }
-            const float logit = fmaf(td_sum_groups(part), rstd[eb], gt.b3);
+            const float logit = td_sum_groups(part) + gt.b3;
             if (g == 0) ew[row * TD_K + 16 * eb + lo] = valid[eb] ? 1.0f / (1.0f + expf(-logit)) : 0.f;
         }
     }

@@ -61,18 +61,17 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
             acc[3] = td_mfma(av, R[s].w, acc[3]);
         }
         // LayerNorm in the folded form the gate's weights are packed for (FoldedMlp, api.cpp): the accumulators hold the centred
-        // pre-activation times the sign of the LayerNorm weight, bet = beta / |gamma|, w3 carries |gamma|, 1 / sigma multiplies the dot product
+        // pre-activation times the sign of the LayerNorm weight, bet = beta / (|gamma| M), w3 carries |gamma| M, the ReLU is the FMA's output clamp
         float outv = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float d0 = acc[0][r], d1 = acc[1][r], d2 = acc[2][r], d3 = acc[3][r];
-            const float var = td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / TD_H) + 1e-5f;
-            const float rstd = __frsqrt_rn(var), sig = var * rstd;
-            float part = fmaxf(fmaf(sig, bet[0], d0), 0.f) * w3[0];
-            part = fmaf(fmaxf(fmaf(sig, bet[1], d1), 0.f), w3[1], part);
-            part = fmaf(fmaxf(fmaf(sig, bet[2], d2), 0.f), w3[2], part);
-            part = fmaf(fmaxf(fmaf(sig, bet[3], d3), 0.f), w3[3], part);
-            const float logit = fmaf(td_sum32(part), rstd, g.b3);
+            const float sc = __frsqrt_rn(fmaf(td_sum32((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)), g.ln_c1, g.ln_c2));      // 1 / (sigma M)
+            float part = td_clamp01(fmaf(d0, sc, bet[0])) * w3[0];
+            part = fmaf(td_clamp01(fmaf(d1, sc, bet[1])), w3[1], part);
+            part = fmaf(td_clamp01(fmaf(d2, sc, bet[2])), w3[2], part);
+            part = fmaf(td_clamp01(fmaf(d3, sc, bet[3])), w3[3], part);
+            const float logit = td_sum32(part) + g.b3;
             if (c == r) outv = 1.0f / (1.0f + expf(-logit));
         }
         // lane (c < 16, hi) holds the gate of edge row erow(c, hi)

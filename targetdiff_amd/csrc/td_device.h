@@ -20,6 +20,10 @@ __device__ __forceinline__ floatx16 td_mfma(float a, float b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// clamp to [0, 1] in the form the backend folds into the producing instruction's output modifier (v_fma_f32 ... clamp): HIP's __saturatef
+// becomes two compare + select pairs once the operands are elements of a vector
+__device__ __forceinline__ float td_clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
 // ---- cross-lane reductions without LDS round trips (DPP modifiers + gfx950 v_permlane32_swap) -------------
 template <int CTRL>
 __device__ __forceinline__ float td_dpp(float v) {

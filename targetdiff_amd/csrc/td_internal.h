@@ -54,7 +54,7 @@ struct TdEdgeMlp {
     const float *R;        // [2 dst class][2 slot][12 kstep][64 lane][4 ntile]  first-layer radial+type B fragments
     // (every table below comes from the MLP with its LayerNorm folded into the two Linears: FoldedMlp, api.cpp)
     const float *gamma;    // [128] |LayerNorm weight| (already inside the second Linear's columns; not read by the kernels)
-    const float *beta;     // [128] LayerNorm bias / |LayerNorm weight|: z' = relu(centred pre-activation + sigma * beta)
+    const float *beta;     // [128] LayerNorm bias / (|LayerNorm weight| M): z'' = clamp_[0,1](centred pre-activation / (sigma M) + beta)
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]
     const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
@@ -64,6 +64,7 @@ struct TdEdgeMlp {
                            // [2 dst class][2 slot][3 piece][8 hidden block][48 lanes (k group g < 3)] x 8 bf16 (k = 8g + j)
     const float *R16q;     // the same pieces K-packed for four instead of six products per tile (pack_pk4_table, api.cpp):
                            // [2 dst class][2 slot][8 hidden block][3 quad][64 lanes] x 8 bf16
+    float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, api.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
                            // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
@@ -102,11 +103,12 @@ struct TdLayer {
 
 struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_transformer.py:236-237,312-316)
     const float *R;        // [12 kstep][64 lane][4 ntile]
-    const float *b0, *gamma, *beta, *w3;   // [128] each, LayerNorm folded like the edge MLPs' (FoldedMlp): beta = bias / |weight|, w3 carries |weight|
+    const float *b0, *gamma, *beta, *w3;   // [128] each, LayerNorm folded like the edge MLPs' (FoldedMlp): beta = bias / (|weight| M), w3 carries |weight| M
     float b3;
     const float *offsets;  // [20]
     float coeff;
     const float *R16p;     // the 20 x 128 first layer as bf16 piece triples [3 piece][8 hidden block][48 lanes] x 8 bf16 (k = 8g + j)
+    float ln_c1, ln_c2;    // as in TdEdgeMlp
     bool use_split;        // model option "edge_key_split"
 };
 
