@@ -393,7 +393,7 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // k = 48; the caller tests it, wave-uniform) and costs nothing: no P_i adds, no Gaussians, no products, z = 0 and 1 / sigma = 0.
 // LN_SKIP (NEB = 2 only): the LayerNorm leaves out a second block without edges (z = 0, 1 / sigma = 0) -- what the chunk-walking key pass, which
 // has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, int PK = 0, class Hook = TdNoHook>
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, int PK = 0, int AH = 0, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ KB,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
@@ -492,26 +492,61 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
             const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
             if constexpr (PKR == 2) asm volatile("" : "+v"(Ra));
+            // Twelve steps = 4 pairs of hidden blocks x {QC (t3), QB (t2), QA (t1, t0)}, low-order instructions first within a pair; a
+            // step's two A quads feed 4 (8) products on four interleaved accumulator chains.  The quads of step n + AH are
+            // read BEFORE step n's products are issued (scheduling barrier): left to itself the compiler keeps two quads live and reads
+            // each pair right in front of its products -- twelve exposed LDS round trips per row and source class.
+            auto quad = [&](int step, int h2) -> uint4 {
+                const int hb = 2 * (step / 3) + h2, kind = step % 3;
+                if (kind == 2) return Rs[hb * 64];
+                if (kind == 1) return Rs[512 + hb * 64];
+                if constexpr (PKR == 1) return Rs[1024 + hb * 64];
+                else {
+                    const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
+                    return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                }
+            };
+            if constexpr (AH == 0) {          // the compiler's own order (two quads live: what the key pass's 168 registers allow)
 #pragma unroll
-            for (int hp = 0; hp < 4; ++hp) {
-                uint4 ar[2][3];                 // A quads of hidden blocks 2hp, 2hp + 1
+                for (int hp = 0; hp < 4; ++hp) {
+                    uint4 ar[2][3];
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const int hb = 2 * hp + h2;
-                    ar[h2][0] = Rs[hb * 64];
-                    ar[h2][1] = Rs[512 + hb * 64];
-                    if constexpr (PKR == 1) ar[h2][2] = Rs[1024 + hb * 64];
-                    else {
-                        const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
-                        ar[h2][2] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int kind = 0; kind < 3; ++kind) ar[h2][kind] = quad(3 * hp + kind, h2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kind = t < 2 ? t : 2, tb = 3 - t;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                            for (int eb = 0; eb < NEB; ++eb)
+                                acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][kind], bq[eb][tb], acc[eb][2 * hp + h2]);
                     }
                 }
-                // the low-order instructions first; two hidden blocks x two edge blocks interleave four accumulator chains
-#define TD_PROD4(qa, tb)                                                                                 \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < NEB; ++eb)    \
-        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][qa], bq[eb][tb], acc[eb][2 * hp + h2]);
-                TD_PROD4(2, 3) TD_PROD4(1, 2) TD_PROD4(0, 1) TD_PROD4(0, 0)
-#undef TD_PROD4
+                return;
+            }
+            uint4 ring[AH + 1][2];
+#pragma unroll
+            for (int n = 0; n < AH; ++n) { ring[n][0] = quad(n, 0); ring[n][1] = quad(n, 1); }
+#pragma unroll
+            for (int step = 0; step < 12; ++step) {
+                if (step + AH < 12) {
+                    ring[(step + AH) % (AH + 1)][0] = quad(step + AH, 0);
+                    ring[(step + AH) % (AH + 1)][1] = quad(step + AH, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int hp = step / 3, kind = step % 3;
+                const uint4 (&aq)[2] = ring[step % (AH + 1)];
+#pragma unroll
+                for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
+                    const int tb = kind == 0 ? 3 : (kind == 1 ? 2 : 1 - pass);
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int eb = 0; eb < NEB; ++eb)
+                            acc[eb][2 * hp + h2] = td_mfma16b(aq[h2], bq[eb][tb], acc[eb][2 * hp + h2]);
+                }
             }
         };
         if constexpr (PK == 3) {
@@ -927,7 +962,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         Edge2 ed;
         td_row_index16(a, i, i, lane, rin);
         td_row_gather16<true>(a, i, i, lane, rin, acc);
-        if constexpr (SPLIT) td_first_layer_split16<true, true, false, 2, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+        if constexpr (SPLIT) td_first_layer_split16<true, true, false, 2, false, 2, 1>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
         else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), KBk, offk, rin, lane, acc, ed);
         // the value half's gathers (its own accumulators) fly while the logits and the softmax run.  The query is fetched BEFORE they are
         // issued: vmcnt counts in order, so a load issued after the gathers could only be waited for together with them -- and the
@@ -962,7 +997,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_softmax16x4(lg, ed.valid, ed.ew, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
-        if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
+        if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, 2, 1>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
         else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), KBv, offk, rv, lane, accv, ev);
         floatx4_t xv[2];
 #pragma unroll
@@ -1376,7 +1411,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         }
                     }
                     if constexpr (SPLIT)
-                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK, 0>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
                     else
                         td_first_layer_compute16<false, true>(a, Rt, KB, offk, rcur, lane, acc, ed);
                     float part = (al[0] + al[1]) + (al[2] + al[3]);
@@ -1431,13 +1466,15 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
             asm volatile("" : "+v"(zoff));
             const float *zrow = lds + zoff;
-                float o = B2[n] * SB[8 * ph + (lane >> 3)];
+                // four independent chains (one per k mod 4): a single accumulator makes the 128 FMAs of a phase one dependent chain
+                float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 8
                 for (int kq = 0; kq < 32; ++kq) {
                     const float4 w = Wv[kq * TD_H + n];
                     const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                    o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
+                    o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
                 }
+                o = (o + o1) + (o2 + o3);
                 if (a.out) a.out[(size_t)i * TD_H + n] = o;
                 else a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
             }
@@ -1487,7 +1524,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
-            td_first_layer_split16<false, true, true, 2, false, TD_VALUE_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+            td_first_layer_split16<false, true, true, 2, false, TD_VALUE_PK, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
@@ -1578,13 +1615,15 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
             asm volatile("" : "+v"(zoff));
             const float *zrow = lds + zoff;
-            float o = B2[n] * SB[8 * ph + (lane >> 3)];
+            // four independent chains (one per k mod 4): a single accumulator makes the 128 FMAs of a phase one dependent chain
+            float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll 8
             for (int kq = 0; kq < 32; ++kq) {
                 const float4 w = Wv[kq * TD_H + n];
                 const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                o = fmaf(w.x, z.x, o); o = fmaf(w.y, z.y, o); o = fmaf(w.z, z.z, o); o = fmaf(w.w, z.w, o);
+                o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
             }
+            o = (o + o1) + (o2 + o3);
             if (a.out) a.out[(size_t)icur * TD_H + n] = o;
             else a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
         }
