@@ -778,6 +778,7 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
     } else if (strcmp(name, "session_forward_reach") == 0) m->opt.session_forward_reach = value != 0;
     else if (strcmp(name, "session_step_lists") == 0) m->opt.session_step_lists = value != 0;
     else { td_set_error("td_model_set_option: unknown option '%s'", name); return TD_EINVAL; }
+    ++m->option_epoch;          // sessions re-capture their step graph (the captured nodes copied the old variants' arguments by value)
     return TD_OK;
 }
 
@@ -1706,6 +1707,7 @@ struct td_session {
     hipGraph_t graph;
     hipGraphExec_t graph_exec;
     td_step_io graph_io;         // the arguments the graph was captured with
+    unsigned graph_epoch = 0;    // ... and the model's option epoch at that time
     int eager_steps;             // steps issued launch by launch so far (the first one also does the one-time kernel set-up)
     bool graph_failed, last_step_graph;
 };
@@ -2030,7 +2032,7 @@ extern "C" int td_session_step(td_session *S, const td_step_io *io, int32_t use_
     S->last_step_graph = false;
     // measurement hooks put events / trace pointers into the launch sequence: those steps are issued launch by launch
     const bool graph_ok = use_graph && !S->graph_failed && g_prof.mask == 0 && !td_wg_trace_armed();
-    if (graph_ok && S->graph_exec && memcmp(&S->graph_io, io, sizeof(td_step_io)) != 0) session_drop_graph(S);
+    if (graph_ok && S->graph_exec && (memcmp(&S->graph_io, io, sizeof(td_step_io)) != 0 || S->graph_epoch != S->m->option_epoch)) session_drop_graph(S);
     if (graph_ok && !S->graph_exec && S->eager_steps > 0) {
         // capture the launch sequence of a step (nothing executes while the stream captures), instantiate it once
         hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
@@ -2040,7 +2042,7 @@ extern "C" int td_session_step(td_session *S, const td_step_io *io, int32_t use_
             e = hipStreamEndCapture(s, &g);
             if (rc == TD_OK && e == hipSuccess && g) {
                 e = hipGraphInstantiate(&S->graph_exec, g, nullptr, nullptr, 0);
-                if (e == hipSuccess) { S->graph = g; S->graph_io = *io; }
+                if (e == hipSuccess) { S->graph = g; S->graph_io = *io; S->graph_epoch = S->m->option_epoch; }
                 else { (void)hipGraphDestroy(g); S->graph_exec = nullptr; }
             } else if (g) {
                 (void)hipGraphDestroy(g);

@@ -170,6 +170,7 @@ struct td_model {
     TdLayer *layers;       // host array [num_layers]
     TdHead head;
     TdSchedules sched;
+    unsigned option_epoch = 0;   // bumped by td_model_set_option: sessions drop a step graph captured under older options
 };
 
 // ---- kernel launchers (each defined next to its kernels) --------------------------------------------
