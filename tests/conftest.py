@@ -51,3 +51,25 @@ def pocket_1h36():
     from targetdiff_amd import workloads
     g = load_golden('pocket_1h36.npz')
     return workloads.Pocket(g['pos'], g['feat'].astype(np.int64), '1h36_pocket10'), g['prior_sizes_seed2021']
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How much of its stated tolerance every comparison used (tests/_tol.py): the largest first."""
+    try:
+        from _tol import MARGINS
+    except Exception:
+        return
+    if not MARGINS:
+        return
+    rows = sorted(MARGINS, key=lambda r: -(r[2] / r[3] if r[3] > 0 else 0.0))
+    lines = [f'{d / tol if tol > 0 else 0.0:6.3f}  {d:10.3e} / {tol:8.1e}  {test}  {where}' for test, where, d, tol in rows]
+    worst = {}          # the tightest comparison of every test
+    for test, where, d, tol in rows:
+        worst.setdefault(test, (d, tol, where))
+    terminalreporter.write_line(f'tolerance margins (difference / tolerance): {len(rows)} comparisons in {len(worst)} tests, the tightest of each test, largest first:')
+    for test, (d, tol, where) in list(worst.items())[:20]:
+        terminalreporter.write_line(f'  {d / tol if tol > 0 else 0.0:6.3f}  {d:10.3e} / {tol:8.1e}  {test}  {where}')
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'margins.txt'), 'w') as f:
+            f.write('ratio   difference / tolerance   test   where\n' + '\n'.join(lines) + '\n')

@@ -8,7 +8,7 @@ real reference: oracle/make_golden_r2.py).  Needs an MI355X: ``-m gpu``.
   * the batching driver ``sample_diffusion_ligand`` value by value, incl. its pos_only branch.
 
 Tolerances (fp32, stated once): atom types and neighbour indices bit-exact; free-running trajectories |dx| <= 5e-5 A;
-teacher-forced single steps |dx| <= 2e-5 A, |d log-prob| <= 2e-4.
+teacher-forced single steps |dx| <= 1e-5 A, |d log-prob| <= 1e-4 (tests/_tol.py).
 """
 import types
 
@@ -20,9 +20,8 @@ from conftest import load_golden, pocket_1h36
 
 pytestmark = pytest.mark.gpu
 
-TOL_TRAJ = 5e-5
-TOL_STEP = 2e-5
-TOL_LOGP = 2e-4
+from _tol import TOL_TRAJ, TOL_FWD, close, maxdiff as _maxdiff
+from _tol import TOL_X as TOL_STEP, TOL_H as TOL_LOGP
 
 
 def _dev():
@@ -47,12 +46,6 @@ def _golden_or_skip(name):
     if not os.path.exists(os.path.join(GOLDEN, name)):
         pytest.skip(f'{name} not generated yet (oracle/make_golden_r3.py)')
     return load_golden(name)
-
-
-def _maxdiff(a, b):
-    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
-    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
-    return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
 def _free_run(model, batch, init_pos, init_v, steps, base, dev, **kw):
@@ -97,9 +90,9 @@ def _check_trajectory(r, g, steps, what):
     assert first_flip is None, f'{what}: atom types differ from the reference at step {first_flip}'
     assert dx.max() <= TOL_TRAJ, f'{what}: |dx| = {dx.max():.3e} at step {int(dx.argmax())}'
     assert np.array_equal(r['v'].cpu().numpy(), g['v'].astype(np.int64))
-    assert _maxdiff(r['pos'], g['pos']) <= TOL_TRAJ
+    close(r['pos'], g['pos'], TOL_TRAJ)
     for j, s in enumerate(g['kept_steps']):
-        assert _maxdiff(r['v0_traj'][int(s)], g['v0_traj'][j]) <= TOL_LOGP, (what, 'v0', int(s))
+        close(r['v0_traj'][int(s)], g['v0_traj'][j], TOL_LOGP, (what, 'v0', int(s)))
         # log-posteriors of impossible classes sit near log(1e-30): compare in probability space there
         a, b = r['vt_traj'][int(s)].double().numpy(), g['vt_traj'][j].astype(np.float64)
         live = b > -20.0
@@ -136,9 +129,9 @@ def test_c1_teacher_forced_steps_vs_reference(model):
         pos, v, _, _ = _one_step(model, batch, torch.from_numpy(g['pos_traj'][s - 1]),
                                  torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s, int(g['draws_base']), dev)
         assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s}'
-        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
+        worst = max(worst, close(pos, g['pos_traj'][s], TOL_STEP, f'step {s}'))
     print(f'C1 teacher-forced: max |dx| = {worst:.3e}')
-    assert worst <= TOL_STEP
+    assert worst <= TOL_STEP, worst
 
 
 # ------------------------------------------------------------------------------------------ a complete 1000-step run
@@ -174,11 +167,11 @@ def test_late_steps_teacher_forced_vs_reference(model):
                                              torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s,
                                              int(g['draws_base']), dev)
         assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s} (t = {999 - s})'
-        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
+        worst = max(worst, close(pos, g['pos_traj'][s], TOL_STEP, f'step {s}'))
         if s in kept:
-            assert _maxdiff(log_v0, g['v0_traj'][kept[s]]) <= TOL_LOGP
+            close(log_v0, g['v0_traj'][kept[s]], TOL_LOGP)
     print(f'late steps teacher-forced: max |dx| = {worst:.3e}')
-    assert worst <= TOL_STEP
+    assert worst <= TOL_STEP, worst
 
 
 # ------------------------------------------------------------------------------------------ 1000 steps on the real pocket
@@ -219,10 +212,10 @@ def test_real_pocket_teacher_forced_steps_vs_reference(model):
                                              torch.from_numpy(g['v_traj'][s - 1].astype(np.int64)), 999 - s, s,
                                              int(g['draws_base']), dev)
         assert np.array_equal(v.cpu().numpy(), g['v_traj'][s].astype(np.int64)), f'types differ at step {s} (t = {999 - s})'
-        worst = max(worst, _maxdiff(pos, g['pos_traj'][s]))
-        assert _maxdiff(log_v0, g['v0_traj'][j]) <= TOL_LOGP
+        worst = max(worst, close(pos, g['pos_traj'][s], TOL_STEP, f'step {s}'))
+        close(log_v0, g['v0_traj'][j], TOL_LOGP)
     print(f'1h36 x 2 teacher-forced ({len(g["kept_steps"])} steps): max |dx| = {worst:.3e}')
-    assert worst <= TOL_STEP
+    assert worst <= TOL_STEP, worst
 
 
 # ------------------------------------------------------------------------------------------ C5 shape
@@ -242,10 +235,10 @@ def test_forward_c5_shape_vs_reference_golden(model):
     pptr, lptr = nat.graph_ptr(b.protein_element_batch, 2), nat.graph_ptr(b.ligand_element_batch, 2)
     pv = b.protein_atom_feature.float()
     preds = nat.model_forward(ppos, pv, pptr, lpos, lv, lptr, max_graph_nodes=1150)
-    assert _maxdiff(preds['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_STEP
-    assert _maxdiff(preds['pred_ligand_v'], g['pred_ligand_v']) <= 2e-4
-    assert _maxdiff(preds['final_ligand_h'], g['final_ligand_h']) <= 2e-4
-    assert _maxdiff(preds['final_h'][::16], g['final_h_sample']) <= 2e-4
+    close(preds['pred_ligand_pos'], g['pred_ligand_pos'], TOL_FWD)
+    close(preds['pred_ligand_v'], g['pred_ligand_v'], TOL_FWD)
+    close(preds['final_ligand_h'], g['final_ligand_h'], TOL_FWD)
+    close(preds['final_h'][::16], g['final_h_sample'], TOL_FWD)
     # neighbour table on the composed coordinates (protein rows first inside each graph)
     x = torch.cat([ppos[:1000], lpos[:150], ppos[1000:], lpos[150:]])
     node_ptr = torch.tensor([0, 1150, 2180], dtype=torch.int32, device=dev)
@@ -387,8 +380,8 @@ def test_unsorted_batch_vectors_follow_compose_context(model, state_dict):
     for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h', 'final_h'):
         assert torch.equal(got[k], pre[k]), k
     want = R.model_forward(state_dict, None, *u)
-    assert _maxdiff(got['pred_ligand_pos'], want['pred_ligand_pos']) <= 2e-5
-    assert _maxdiff(got['pred_ligand_v'], want['pred_ligand_v']) <= 2e-4
+    close(got['pred_ligand_pos'], want['pred_ligand_pos'], 2e-5)
+    close(got['pred_ligand_v'], want['pred_ligand_v'], 2e-4)
     with pytest.raises(ValueError, match='ligand_v'):
         model(*[t.to(dev) for t in u[:4]], (u[4] + 13).to(dev), u[5].to(dev))
 
@@ -423,7 +416,7 @@ def test_sampling_with_unsorted_batch_vectors_follows_the_reference_loop(model, 
         tt = torch.full((int(bp.max()) + 1,), t, dtype=torch.long)
         x, v, l0, lp = R.posterior_step(sched, tt, x, v, preds['pred_ligand_pos'], preds['pred_ligand_v'], bl,
                                         src(s, 'noise', x), src(s, 'uniform', preds['pred_ligand_v']), 13)
-        assert _maxdiff(r['pos_traj'][s], x + off[bl]) <= 5e-5, s
+        close(r['pos_traj'][s], x + off[bl], 5e-5, s)
         assert torch.equal(r['v_traj'][s], v), s
 def test_model_copy_after_first_use(model):
     """copy.deepcopy / pickle after a forward has created the native handle; the copy packs its own weights."""
@@ -489,13 +482,13 @@ def test_c3_full_size_pack_reproduces_reference_golden(model):
     pptr, lptr = nat.graph_ptr(b.protein_element_batch, 3200), nat.graph_ptr(b.ligand_element_batch, 3200)
     ppos, lposd = b.protein_pos.clone(), lpos.to(dev)
     nat.center_pos(ppos, pptr, lposd, lptr)
-    assert _maxdiff(lposd[idx.to(dev)], g['ligand_pos']) <= 1e-5
+    close(lposd[idx.to(dev)], g['ligand_pos'], 1e-5)
     pv, lvd = b.protein_atom_feature.float(), lv.to(dev)
     preds = nat.model_forward(ppos, pv, pptr, lposd, lvd, lptr, max_graph_nodes=325, want_final_h=False)
     sel = idx.to(dev)
-    assert _maxdiff(preds['pred_ligand_pos'][sel], g['pred_ligand_pos']) <= TOL_STEP
-    assert _maxdiff(preds['pred_ligand_v'][sel], g['pred_ligand_v']) <= 2e-4
-    assert _maxdiff(preds['final_ligand_h'][sel], g['final_ligand_h']) <= 2e-4
+    close(preds['pred_ligand_pos'][sel], g['pred_ligand_pos'], TOL_FWD)
+    close(preds['pred_ligand_v'][sel], g['pred_ligand_v'], TOL_FWD)
+    close(preds['final_ligand_h'][sel], g['final_ligand_h'], TOL_FWD)
     sess = capi.NativeSession(nat, ppos, pv, pptr, lptr, lposd.shape[0], 325)
     ps = sess.forward(lposd, lvd)
     for key in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):

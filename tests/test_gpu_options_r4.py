@@ -9,17 +9,11 @@ import torch
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
-TOL_X, TOL_H, TOL_TRAJ = 2e-5, 2e-4, 5e-5
+from _tol import TOL_X, TOL_H, TOL_FWD, TOL_TRAJ, close, maxdiff as _maxdiff
 
 
 def _dev():
     return torch.device('cuda:0')
-
-
-def _maxdiff(a, b):
-    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
-    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
-    return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
 def _model(sd, **over):
@@ -45,10 +39,10 @@ def test_forward_with_simple_time_embedding_vs_reference():
     p = model(torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
               torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch, time_step=t,
               return_all=True)
-    assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
-    assert _maxdiff(p['pred_ligand_v'], g['pred_ligand_v']) <= TOL_H
-    assert _maxdiff(p['final_ligand_h'], g['final_ligand_h']) <= TOL_H
-    assert _maxdiff(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v']) <= TOL_H
+    close(p['pred_ligand_pos'], g['pred_ligand_pos'], TOL_X)
+    close(p['pred_ligand_v'], g['pred_ligand_v'], TOL_H)
+    close(p['final_ligand_h'], g['final_ligand_h'], TOL_H)
+    close(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v'], TOL_H)
     # the time step matters (another one moves the outputs), and it is required
     p2 = model(torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
                torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch, time_step=t * 0)
@@ -80,8 +74,8 @@ def test_sampling_with_time_embedding_and_noise_mean_type_vs_reference(fixture, 
                                        noise_source=draws.Source(int(g['draws_base']), dev), **kw)
         torch.cuda.current_stream(dev).wait_stream(side)
         assert np.array_equal(torch.stack(r['v_traj']).numpy(), g['v_traj'].astype(np.int64)), (fixture, kw)
-        assert _maxdiff(torch.stack(r['pos_traj']), g['pos_traj']) <= TOL_TRAJ, (fixture, kw)
-        assert _maxdiff(torch.stack(r['v0_traj']), g['v0_traj']) <= TOL_H, (fixture, kw)
+        close(torch.stack(r['pos_traj']), g['pos_traj'], TOL_TRAJ, (fixture, kw))
+        close(torch.stack(r['v0_traj']), g['v0_traj'], TOL_H, (fixture, kw))
         outs.append(r)
     for r in outs[1:]:
         for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
@@ -102,12 +96,12 @@ def test_two_blocks_vs_reference():
     args = (torch.from_numpy(g['protein_pos']).to(dev), b.protein_atom_feature.float(), b.protein_element_batch,
             torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev), b.ligand_element_batch)
     p = model(*args)
-    assert _maxdiff(p['pred_ligand_pos'], g['pred_ligand_pos']) <= TOL_X
-    assert _maxdiff(p['pred_ligand_v'], g['pred_ligand_v']) <= TOL_H
-    assert _maxdiff(p['final_ligand_h'], g['final_ligand_h']) <= TOL_H
-    assert _maxdiff(p['final_h'], g['final_h']) <= TOL_H
+    close(p['pred_ligand_pos'], g['pred_ligand_pos'], TOL_X)
+    close(p['pred_ligand_v'], g['pred_ligand_v'], TOL_H)
+    close(p['final_ligand_h'], g['final_ligand_h'], TOL_H)
+    close(p['final_h'], g['final_h'], TOL_H)
     f = model(*args, fix_x=True)
-    assert _maxdiff(f['final_ligand_h'], g['fix_x_final_ligand_h']) <= TOL_H
+    close(f['final_ligand_h'], g['fix_x_final_ligand_h'], TOL_H)
     with pytest.raises(NotImplementedError, match='return_all'):
         model(*args, return_all=True)
     one = _model(sd)(*args)                       # one block gives something else
@@ -120,7 +114,7 @@ def test_two_blocks_vs_reference():
                                    b.ligand_element_batch, num_steps=int(gs['steps']), center_pos_mode='protein',
                                    noise_source=draws.Source(int(gs['draws_base']), dev), **kw)
         assert np.array_equal(torch.stack(r['v_traj']).numpy(), gs['v_traj'].astype(np.int64)), kw
-        assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
+        close(torch.stack(r['pos_traj']), gs['pos_traj'], TOL_TRAJ, kw)
         outs.append(r)
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[1]['pos_traj']))
     hyb = _model(sd, num_blocks=2, cutoff_mode='hybrid')
@@ -154,8 +148,8 @@ def test_layernorm_weights_of_every_sign_vs_reference():
         d = {k: _maxdiff(p[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h', 'final_h')}
         print('edge_key_split', split, d)
         assert d['pred_ligand_pos'] <= TOL_X and d['pred_ligand_v'] <= TOL_H and d['final_ligand_h'] <= TOL_H and d['final_h'] <= TOL_H
-        assert _maxdiff(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v']) <= TOL_H
-        assert _maxdiff(p['layer_pred_ligand_pos'][0], g['layer0_pred_ligand_pos']) <= TOL_X
+        close(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v'], TOL_H)
+        close(p['layer_pred_ligand_pos'][0], g['layer0_pred_ligand_pos'], TOL_X)
     # the all-positive weights give something else
     one = _model(weights.make_state_dict(SEED))(*args)
     assert _maxdiff(one['pred_ligand_v'], g['pred_ligand_v']) > 1e-3
@@ -192,7 +186,7 @@ def test_gate_and_output_options_vs_reference(name, over):
     print(name, d)
     assert d['pred_ligand_pos'] <= TOL_X and d['pred_ligand_v'] <= TOL_H and d['final_ligand_h'] <= TOL_H and d['final_h'] <= TOL_H
     f = model(*args, fix_x=True)
-    assert _maxdiff(f['final_ligand_h'], g['fix_x_final_ligand_h']) <= TOL_H
+    close(f['final_ligand_h'], g['fix_x_final_ligand_h'], TOL_H)
     assert torch.equal(f['pred_ligand_pos'].cpu(), torch.from_numpy(g['ligand_pos']))
     base = _model(weights.make_state_dict(SEED))(*args)            # configs/training.yml's options give something else
     assert max(_maxdiff(base['pred_ligand_v'], g['pred_ligand_v']), _maxdiff(base['pred_ligand_pos'], g['pred_ligand_pos'])) > 10 * TOL_X
@@ -217,7 +211,7 @@ def test_gate_and_output_options_sampling_vs_reference():
                                    b.ligand_element_batch, num_steps=int(gs['steps']), center_pos_mode='protein',
                                    noise_source=draws.Source(int(gs['draws_base']), dev), **kw)
         assert np.array_equal(torch.stack(r['v_traj']).numpy(), gs['v_traj'].astype(np.int64)), kw
-        assert _maxdiff(torch.stack(r['pos_traj']), gs['pos_traj']) <= TOL_TRAJ, kw
+        close(torch.stack(r['pos_traj']), gs['pos_traj'], TOL_TRAJ, kw)
         outs.append(r)
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[2]['pos_traj']))
     assert torch.equal(torch.stack(outs[0]['pos_traj']), torch.stack(outs[1]['pos_traj']))

@@ -1,8 +1,9 @@
 """Parity of the HIP path (through the C ABI) against the oracle restatement and against the golden
 vectors of the real reference.  Needs an MI355X: run with ``-m gpu``.
 
-Tolerances (fp32, stated once): neighbour indices and sampled atom types bit-exact; |dx| <= 2e-5 A on
-coordinates, |dh|, |dlogit| <= 2e-4 on features / type logits (the re-association noise floor of one
+Tolerances (fp32, stated once in tests/_tol.py): neighbour indices and sampled atom types bit-exact; one forward pass against a
+reference golden 5e-6 (positions in A, features and logits alike); teacher-forced steps |dx| <= 1e-5 A on
+coordinates, |dh|, |dlogit| <= 1e-4 on features / type logits (the re-association noise floor of one
 reference forward is ~4e-7 A / 8e-7).
 """
 import numpy as np
@@ -13,20 +14,13 @@ from conftest import load_golden, small_inputs, pocket_1h36
 
 pytestmark = pytest.mark.gpu
 
-TOL_X = 2e-5
-TOL_H = 2e-4
+from _tol import TOL_X, TOL_H, TOL_FWD, close, maxdiff as _maxdiff      # 1e-5 A / 1e-4 teacher-forced, 5e-6 for one forward vs a golden
 
 
 def _dev():
     if not torch.cuda.is_available():
         pytest.skip('no HIP device')
     return torch.device('cuda:0')
-
-
-def _maxdiff(a, b):
-    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
-    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
-    return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
 @pytest.fixture(scope='module')
@@ -144,10 +138,10 @@ def test_node_stage_projections(model, state_dict):
                 want.append(fold(hd @ w0[:, 84:212].T + b0))
                 want.append(fold(hd @ w0[:, 212:340].T))
             want = torch.cat(want, dim=1)
-            assert _maxdiff(P, want) < 5e-5, (N, layer, stage)
+            close(P, want, 5e-5, (N, layer, stage))
             from oracle import restatement as R
             qw = R._mlp(state_dict, pre + names[2], hd, torch.float64)
-            assert _maxdiff(q, qw) < 5e-5, (N, layer, stage)
+            close(q, qw, 5e-5, (N, layer, stage))
 
 
 # ------------------------------------------------------------------------------------------ backbone stages
@@ -184,17 +178,15 @@ def test_refine_first_layer_stagewise(state_dict, golden_small):
                                                 want_graph=True)
     np.testing.assert_array_equal(nbr.cpu().numpy(), g['nbr'])
     valid = g['nbr'] >= 0
-    assert _maxdiff(ew.cpu().numpy()[valid], g['e_w'][valid]) < 1e-5
+    close(ew.cpu().numpy()[valid], g['e_w'][valid], 1e-5)
     assert np.all(ew.cpu().numpy()[~valid] == 0)
-    dh = _maxdiff(out_h, g['h_layers'][0])
-    dx = _maxdiff(out_x, g['x_layers'][0])
-    print(f'layer0: |dh|={dh:.3e} |dx|={dx:.3e}')
-    assert dh < TOL_H and dx < TOL_X
+    close(out_h, g['h_layers'][0], TOL_FWD, 'layer 0 h')
+    close(out_x, g['x_layers'][0], TOL_FWD, 'layer 0 x')
     # fix_x: coordinates untouched, same h
     out_h2, out_x2, _, _ = nat1.refine_forward(h.to(dev).contiguous(), x.to(dev).contiguous(), mask.to(dev), ptr,
                                                fix_x=True)
     assert torch.equal(out_x2.cpu(), x)
-    assert _maxdiff(out_h2, g['h_layers'][0]) < TOL_H
+    close(out_h2, g['h_layers'][0], TOL_FWD)
 
 
 def test_refine_net_module_full_depth(model, state_dict, golden_small):
@@ -213,10 +205,8 @@ def test_refine_net_module_full_depth(model, state_dict, golden_small):
                                               inp['batch_ligand'])
     out = model.refine_net(h.to(dev), x.to(dev), mask.to(dev), batch_all.to(dev), return_all=True)
     assert len(out['all_x']) == 2 and torch.equal(out['all_x'][1], out['x']) and torch.equal(out['all_h'][0].cpu(), h)
-    dh = _maxdiff(out['h'], g['h_layers'][8])
-    dx = _maxdiff(out['x'], g['x_layers'][8])
-    print(f'layer8: |dh|={dh:.3e} |dx|={dx:.3e}')
-    assert dh < TOL_H and dx < TOL_X
+    close(out['h'], g['h_layers'][8], TOL_FWD, 'layer 8 h')
+    close(out['x'], g['x_layers'][8], TOL_FWD, 'layer 8 x')
 
 
 # ------------------------------------------------------------------------------------------ full forward
@@ -229,10 +219,8 @@ def test_forward_small_vs_reference_golden(model, golden_small):
     dev = _dev()
     g = golden_small
     out = _forward(model, small_inputs(g), dev)
-    d = {k: _maxdiff(out[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h', 'final_ligand_h')}
-    print(d)
-    assert d['pred_ligand_pos'] < TOL_X
-    assert d['pred_ligand_v'] < TOL_H and d['final_h'] < TOL_H and d['final_ligand_h'] < TOL_H
+    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h', 'final_ligand_h'):
+        close(out[k], g[k], TOL_FWD, k)
 
 
 def test_forward_small_fix_x(model, golden_small):
@@ -241,8 +229,8 @@ def test_forward_small_fix_x(model, golden_small):
     inp = small_inputs(golden_small)
     out = _forward(model, inp, dev, fix_x=True)
     assert torch.equal(out['pred_ligand_pos'].cpu(), inp['ligand_pos'])
-    assert _maxdiff(out['pred_ligand_v'], g['pred_ligand_v']) < TOL_H
-    assert _maxdiff(out['final_ligand_h'], g['final_ligand_h']) < TOL_H
+    close(out['pred_ligand_v'], g['pred_ligand_v'], TOL_FWD)
+    close(out['final_ligand_h'], g['final_ligand_h'], TOL_FWD)
     emb = model.fetch_embedding(inp['protein_pos'].to(dev), inp['protein_v'].to(dev), inp['batch_protein'].to(dev),
                                 inp['ligand_pos'].to(dev), inp['ligand_v'].to(dev), inp['batch_ligand'].to(dev))
     assert torch.equal(emb['final_ligand_h'], out['final_ligand_h'])
@@ -260,11 +248,9 @@ def test_forward_1h36_vs_reference_golden(model):
     out = model(ppos.to(dev), b.protein_atom_feature.float().to(dev), b.protein_element_batch.to(dev),
                 torch.from_numpy(g['ligand_pos']).to(dev), torch.from_numpy(g['ligand_v']).to(dev),
                 b.ligand_element_batch.to(dev))
-    d = {k: _maxdiff(out[k], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h')}
-    d['final_h_sample'] = _maxdiff(out['final_h'][::16], g['final_h_sample'])
-    print(d)
-    assert d['pred_ligand_pos'] < TOL_X
-    assert max(d['pred_ligand_v'], d['final_ligand_h'], d['final_h_sample']) < TOL_H
+    for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+        close(out[k], g[k], TOL_FWD, k)
+    close(out['final_h'][::16], g['final_h_sample'], TOL_FWD, 'final_h')
 
 
 def test_forward_deterministic_and_batch_independent(model):
@@ -392,9 +378,9 @@ def test_posterior_known_answers(model):
     log_post = torch.empty(n, 13, device=dev)
     pos_next, v_next = nat.posterior_step(torch.from_numpy(g['t']).int().to(dev), lptr, T('x_t'), T('v_t'), T('x0'),
                                           T('v0_logits'), T('noise'), T('uniform'), log_v0=log_v0, log_post=log_post)
-    assert _maxdiff(pos_next, g['pos_next']) < 2e-6
-    assert _maxdiff(log_v0, g['log_v0']) < 1e-5
-    assert _maxdiff(log_post, g['log_post']) < 2e-5
+    close(pos_next, g['pos_next'], 2e-6)
+    close(log_v0, g['log_v0'], 1e-5)
+    close(log_post, g['log_post'], 2e-5)
     np.testing.assert_array_equal(v_next.cpu().numpy(), g['v_next'])
 
 
@@ -477,8 +463,8 @@ def test_return_all_vs_reference_golden(model, golden_small):
     out = _forward(model, small_inputs(golden_small), dev, return_all=True)
     assert len(out['layer_pred_ligand_pos']) == len(out['layer_pred_ligand_v']) == 2
     for l in range(2):
-        assert _maxdiff(out['layer_pred_ligand_pos'][l], g['layer_pred_ligand_pos'][l]) < TOL_X
-        assert _maxdiff(out['layer_pred_ligand_v'][l], g['layer_pred_ligand_v'][l]) < TOL_H
+        close(out['layer_pred_ligand_pos'][l], g['layer_pred_ligand_pos'][l], TOL_X)
+        close(out['layer_pred_ligand_v'][l], g['layer_pred_ligand_v'][l], TOL_H)
 
 
 def test_likelihood_estimation_vs_reference_golden(model):
@@ -571,9 +557,8 @@ def test_full_size_c2_pack_reproduces_reference_golden(model):
     got = sess.forward(lpos_p, lv_p)
     sel = torch.cat([torch.arange(cum[37], cum[38]), torch.arange(cum[81], cum[82])]).to(dev)
     for name, res in (('stateless', out), ('session', got)):
-        d = {k: _maxdiff(res[k][sel], g[k]) for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h')}
-        print(name, d)
-        assert d['pred_ligand_pos'] < TOL_X and d['pred_ligand_v'] < TOL_H and d['final_ligand_h'] < TOL_H, (name, d)
+        for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
+            close(res[k][sel], g[k], TOL_FWD, f'{name} {k}')
     for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_ligand_h'):
         assert torch.equal(out[k], got[k]), k
     n_all, dirty, levels = sess.row_counts()
@@ -598,11 +583,12 @@ def test_egnn_vs_reference_golden():
     mask, batch = torch.from_numpy(g['mask_ligand']).to(dev), torch.from_numpy(g['batch']).to(dev)
     out = net(h, x, mask, batch, return_all=True)
     assert len(out['all_x']) == L + 1 and len(out['all_h']) == L + 1
-    d = {'x': max(_maxdiff(out['all_x'][l], g['all_x'][l]) for l in range(L + 1)),
-         'h1': _maxdiff(out['all_h'][1], g['h_layer1']), 'h5': _maxdiff(out['all_h'][5], g['h_layer5']),
-         'h': _maxdiff(out['h'], g['h_final'])}
-    print(d)
-    assert d['x'] < 5e-5 and d['h1'] < TOL_H and d['h5'] < TOL_H and d['h'] < 5e-4
+    # (the EGNN's features grow by three orders of magnitude over its nine residual layers: the last layer's tolerance is scaled with them)
+    for l in range(L + 1):
+        close(out['all_x'][l], g['all_x'][l], 5e-5, f'x after layer {l}')
+    close(out['all_h'][1], g['h_layer1'], TOL_H, 'h layer 1')
+    close(out['all_h'][5], g['h_layer5'], TOL_H, 'h layer 5')
+    close(out['h'], g['h_final'], 5e-4, 'h final')
     # protein rows never move
     assert torch.equal(out['x'][~mask], x[~mask])
     out2 = net(h, x, mask, batch)
