@@ -397,6 +397,9 @@ def run_c4(args, model, dev, rank, world, fence):
                    'pockets_this_rank': len(mine), 'nodes_rank0': nodes,
                    'parallelism': f'pocket i -> rank i % {world} (no data-path collective)'},
         'load_balance': {'per_rank_seconds': per_rank, 'max_over_mean': max(per_rank) / (sum(per_rank) / len(per_rank))},
+        # what RCCL / the launcher actually gave this job: world size, and per rank its device ordinal, PCI address, own ms per step
+        # (fails loudly when two ranks share a device)
+        'ranks': launch.rank_census(dev, mine_elapsed / args.steps, {'pockets': len(mine), 'nodes': nodes}),
         'roofline': None}
 
 
@@ -444,7 +447,10 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI; rendezvous + timing max only
+        with launch.stdout_to_stderr():          # RCCL's version banner goes to stdout: keep rank 0's stdout to the one JSON line
+            dist.init_process_group('nccl', device_id=dev)          # RCCL over xGMI; rendezvous + timing max only
+            dist.barrier()
+            torch.cuda.synchronize()
 
     def fence():
         if distributed:
@@ -498,10 +504,13 @@ def main():
         sampler.step()
     torch.cuda.synchronize()
     prof = capi.profile_end()
+    my_elapsed = elapsed
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # what RCCL / the launcher actually gave this job (gathered on every rank; fails loudly when two ranks share a device)
+    census = launch.rank_census(dev, my_elapsed / args.steps, {'nodes': n_nodes})
     sec_per_step = elapsed / args.steps
     graphs = len(pockets) * spp
     value = world * graphs / (1000.0 * sec_per_step)
@@ -617,6 +626,7 @@ def main():
                    'step_launch': step_launch, 'build_tag': capi.build_tag(),
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,
+        'ranks': census,
     }
     # the sampler's own initial state (ligand cloud N(0, I)): cheaper steps, reported beside the headline number
     if args.initial_state and args.ligand_spread != 1.0 and sampler.session is not None:

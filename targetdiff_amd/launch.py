@@ -125,7 +125,12 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=Non
             tails.append(line.decode('utf-8', 'replace'))
         stream.close()
 
+    cleaning_up = []        # non-empty once the `finally` below has started: a second signal is noted, not raised
+
     def _on_signal(signum, frame):
+        if cleaning_up:
+            cleaning_up.append(signum)
+            return
         raise _Terminated(signum)
 
     old_handlers = {}
@@ -165,6 +170,7 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=Non
     except _Terminated as t:
         stopped_by = t.signum
     finally:
+        cleaning_up.append(0)          # from here on SIGTERM / SIGHUP must not interrupt the clean-up (the handlers only take note)
         _stop(procs)
         for sig, h in old_handlers.items():
             try:
@@ -173,11 +179,14 @@ def spawn_ranks(argv, nprocs: int, timeout=None, extra_env=None, pin_devices=Non
                 pass
         for t in pumps:
             t.join(timeout=2.0)
+    if stopped_by is None and len(cleaning_up) > 1:
+        stopped_by = cleaning_up[1]          # told to stop while cleaning up
     if stopped_by is not None:
         return 128 + int(stopped_by)
     if timed_out:
         return 124
-    if rc != 0 and _retries > 0 and time.monotonic() - t_start < 20.0 and any(k in line for line in tails for k in _ADDR_IN_USE):
+    lines = list(tails)          # a snapshot: a pump thread that outlived its join (a grandchild holding stderr open) may still append
+    if rc != 0 and _retries > 0 and time.monotonic() - t_start < 20.0 and any(k in line for line in lines for k in _ADDR_IN_USE):
         return spawn_ranks(argv, nprocs, timeout, extra_env, pin_devices, _retries - 1)
     return rc
 
@@ -203,3 +212,74 @@ def self_spawn_if_needed(n_gpus: int) -> bool:
         raise SystemExit(f'--gpus {n_gpus}: only {visible} HIP device(s) visible to this process')
     sys.stdout.flush()
     raise SystemExit(spawn_ranks([sys.executable] + sys.argv, n_gpus))
+
+
+def _device_identity(device) -> dict:
+    """What tells two ranks' devices apart: ordinal, PCI address and UUID of a HIP device (whatever torch exposes); for a CPU
+    'device' only its name."""
+    import torch
+    device = torch.device(device)
+    ident = {'device': str(device), 'host': socket.gethostname(), 'pid': os.getpid()}
+    if device.type == 'cuda':
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        ident.update(ordinal=int(idx), name=props.name, visible_devices=os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES')))
+        bus = [getattr(props, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+        ident['pci'] = ':'.join('%04x' % bus[0] if i == 0 else '%02x' % b for i, b in enumerate(bus)) if None not in bus else None
+        uuid = getattr(props, 'uuid', None)
+        ident['uuid'] = str(uuid) if uuid is not None else None
+    return ident
+
+
+def rank_census(device, seconds_per_step=None, extra=None) -> dict:
+    """What the process group actually looks like, gathered from every rank (one object gather: metadata, not data path): world
+    size and backend as torch.distributed reports them, and per rank its RANK / LOCAL_RANK, device ordinal, PCI address, UUID, host,
+    pid and -- when given -- its own seconds per step.  Two ranks on the same physical device (same host and PCI address or UUID)
+    are an error: the job would report N GPUs while running on fewer.  Works without a process group (a census of one)."""
+    import torch.distributed as dist
+    me = _device_identity(device)
+    me.update(rank=int(os.environ.get('RANK', '0')), local_rank=int(os.environ.get('LOCAL_RANK', '0')))
+    if seconds_per_step is not None:
+        me['ms_per_step'] = float(seconds_per_step) * 1e3
+    if extra:
+        me.update(extra)
+    if dist.is_available() and dist.is_initialized():
+        world, backend = dist.get_world_size(), dist.get_backend()
+        me['rank'] = dist.get_rank()
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    else:
+        world, backend, ranks = 1, None, [me]
+    ranks = sorted(ranks, key=lambda r: r['rank'])
+    seen = {}
+    for r in ranks:
+        key = (r['host'], r.get('uuid') or r.get('pci'))
+        if r.get('ordinal') is not None and key[1] is not None:
+            if key in seen:
+                raise RuntimeError(f"ranks {seen[key]} and {r['rank']} run on the same device {key[1]} of host {key[0]}: "
+                                   'the job would report more GPUs than it uses (check LOCAL_RANK / HIP_VISIBLE_DEVICES)')
+            seen[key] = r['rank']
+    out = {'world_size': int(world), 'backend': backend, 'env_world_size': int(os.environ.get('WORLD_SIZE', '1')), 'ranks': ranks}
+    if all('ms_per_step' in r for r in ranks):
+        ms = [r['ms_per_step'] for r in ranks]
+        out['ms_per_step_per_rank'] = ms
+        out['max_over_mean'] = max(ms) / (sum(ms) / len(ms))
+    return out
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr while the block runs.  RCCL prints a version banner ("RCCL version : ...", five lines) to
+    STDOUT when its first communicator is created; rank 0's stdout is the job's one JSON line, so the process group is set up inside
+    this block (init_process_group + a first barrier, which forces the communicator into existence)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False

@@ -97,7 +97,9 @@ def main(argv=None, model_factory=build_model):
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if on_gpu:
-            dist.init_process_group('nccl', device_id=dev)          # RCCL; rendezvous, barrier and one gather only
+            with launch.stdout_to_stderr():          # RCCL's version banner goes to stdout
+                dist.init_process_group('nccl', device_id=dev)          # RCCL; rendezvous, barrier and one gather only
+                dist.barrier()
         else:
             dist.init_process_group('gloo')
     torch.manual_seed(args.seed + rank)                              # utils/misc.py:58 seed_all, decorrelated per rank
