@@ -844,8 +844,8 @@ GraphTab default_tab(Workspace &w) { return GraphTab{nullptr, w.nbr, w.ew, w.alp
 // lig / Nl (x2h passes): the ligand rows of the batch, all of them among `rows`
 int key_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const float *ew, const int32_t *nbr,
              const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count, float *alpha, hipStream_t s,
-             const int32_t *lig = nullptr, int64_t Nl = 0) {
-    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s, gt.cptr, lig, Nl, gt.cpn_p);
+             const int32_t *lig = nullptr, int64_t Nl = 0, bool h2x_stage = false) {
+    return td_launch_edge_key16(mlp, L, x4, nbr, ew, P, q, rows, count_ptr, count, alpha, s, h2x_stage, gt.cptr, lig, Nl, gt.cpn_p);
 }
 // lig / Nl: the ligand rows of the batch (all of them are among `rows`: every row list of a step contains the ligand atoms)
 int value_pass(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const GraphTab &gt, const int32_t *nbr, const float *P,
@@ -877,7 +877,7 @@ int h2x_attend(const td_model *m, const TdLayer &L, Workspace &w, const GraphTab
     }
     {
         ProfScope ps(PC_H2X_K, s);
-        if ((rc = key_pass(L.xk, L, xc, gt, gt.ew, gt.nbr, P, q, w.lig_node, nullptr, Nl, gt.alpha, s)) != TD_OK) return rc;
+        if ((rc = key_pass(L.xk, L, xc, gt, gt.ew, gt.nbr, P, q, w.lig_node, nullptr, Nl, gt.alpha, s, nullptr, 0, true)) != TD_OK) return rc;
     }
     ProfScope ps(PC_H2X_V, s);
     return td_launch_edge_xv16(L.xv, L, xc, xn, gt.nbr, P, w.lig_node, Nl, gt.alpha, s, gt.cptr);
@@ -1651,6 +1651,10 @@ extern "C" int td_debug_node_stage(const td_model *m, int32_t layer, int32_t sta
                                    float *d_P, float *d_q, void *stream) {
     if (!m || layer < 0 || layer >= m->cfg.num_layers || (stage != 0 && stage != 1) || N < 0 || (N > 0 && (!d_h || !d_P || !d_q))) {
         td_set_error("td_debug_node_stage: bad argument");
+        return TD_EINVAL;
+    }
+    if (stage_rows(m->cfg) != 1) {       // m->layers holds stage_rows rows per reference layer: this hook addresses whole layers only
+        td_set_error("td_debug_node_stage: models with several x2h / h2x stages per layer are not addressed by this hook");
         return TD_EINVAL;
     }
     const TdLayer &L = m->layers[layer];

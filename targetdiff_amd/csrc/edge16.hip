@@ -1762,13 +1762,13 @@ static unsigned long long *wg_trace_slot(int pass) {
 // chunk per protein row (`hybrid`) the protein rows run as on the default graph and the ligand rows in a second, chunk-walking launch.
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                         float *alpha, hipStream_t s, const int32_t *cptr, const int32_t *lig_rows, int64_t lig_count, int cpn_p) {
+                         float *alpha, hipStream_t s, bool h2x_stage, const int32_t *cptr, const int32_t *lig_rows, int64_t lig_count, int cpn_p) {
     if (count == 0) return TD_OK;
     Args16 a = {};
     a.x4 = x4; a.nbr = nbr; a.ew = ew; a.P = P; a.q = q; a.rows = rows; a.count_ptr = count_ptr; a.h = nullptr;
     a.alpha = alpha; a.x4_out = nullptr; a.count = count; a.mlp = mlp; a.offsets = L.offsets; a.coeff = L.coeff; a.p_off = 0;
     a.cptr = cptr;
-    const bool h2x = rows && !count_ptr && !lig_rows;      // h2x key pass (ligand row list of known length): STAGE tag 1
+    const bool h2x = h2x_stage;      // h2x key pass (unfused form): STAGE tag 1, contiguous shares, no workgroup trace
     if (!h2x) a.trace = wg_trace_slot(0);
     a.deal = h2x ? 0 : mlp.deal_rows;
 #define TD_KEY_LAUNCH(WAVES, STAGE, CH, SP, BYTES)                                                            \

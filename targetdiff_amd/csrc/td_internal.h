@@ -248,7 +248,7 @@ int td_launch_gate(const TdGate &g, const float4 *x4, const int32_t *nbr, int64_
 // nbr / ew / alpha; nullptr on the default graph (one 32-slot row per node, chunk == node)
 int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4, const int32_t *nbr, const float *ew,
                          const float *P, const float *q, const int32_t *rows, const int32_t *count_ptr, int64_t count,
-                         float *alpha, hipStream_t s, const int32_t *cptr = nullptr, const int32_t *lig_rows = nullptr,
+                         float *alpha, hipStream_t s, bool h2x_stage, const int32_t *cptr = nullptr, const int32_t *lig_rows = nullptr,
                          int64_t lig_count = 0, int cpn_p = 0);
 int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const TdLayer &L, const float4 *x4_in, float4 *x4_out,
                          const int32_t *nbr, const float *ew, const float *P, const float *q, const int32_t *rows,

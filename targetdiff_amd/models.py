@@ -255,6 +255,18 @@ class ShiftedSoftplus(nn.Module):
         raise RuntimeError('evaluated inside libtargetdiff_hip.so')
 
 
+class _SinusoidalPosEmb(nn.Module):
+    """Parameterless first stage of the reference's 'sin' time embedding (models/molopt_score_model.py:182-194); a holder only:
+    it keeps the indices of the Sequential -- and with them the state_dict keys time_emb.1.* / time_emb.3.* -- as the reference has them."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        raise NotImplementedError("time_emb_mode='sin' is constructed for checkpoint compatibility only")
+
+
 class ScorePosNet3D(nn.Module):
     """Drop-in for models/molopt_score_model.py::ScorePosNet3D on the sampling path.
 
@@ -328,10 +340,16 @@ class ScorePosNet3D(nn.Module):
         if self.time_emb_dim > 0:
             if self.time_emb_mode == 'simple':
                 self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim + 1, emb_dim)
+            elif self.time_emb_mode == 'sin':
+                # The reference CONSTRUCTS this variant (:292-299) and loads such checkpoints with strict=True; its forward then
+                # concatenates the per-GRAPH feature time_emb(time_step) [B, dim] with the per-ATOM one-hot [N_l, C] (:326-327, no
+                # [batch_ligand]) and fails unless B == N_l.  Same here: the parameter holders exist (the state_dict round-trips), and
+                # forward / sampling refuse (_time_bias) -- there is no behaviour to reproduce.
+                self.time_emb = nn.Sequential(_SinusoidalPosEmb(self.time_emb_dim), nn.Linear(self.time_emb_dim, self.time_emb_dim * 4),
+                                              nn.GELU(), nn.Linear(self.time_emb_dim * 4, self.time_emb_dim))
+                self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim + self.time_emb_dim, emb_dim)
             else:
-                # 'sin' is dead code in the reference: forward concatenates the per-GRAPH feature time_emb(time_step) [B, dim] with the
-                # per-ATOM one-hot [N_l, C] (:326-327, no [batch_ligand]) and raises unless B == N_l -- nothing to reproduce
-                raise NotImplementedError(f"time_emb_mode={self.time_emb_mode!r}: only 'simple' runs in the reference (:319-329)")
+                raise NotImplementedError(f'time_emb_mode={self.time_emb_mode!r} (the reference knows simple and sin, :288-301)')
         else:
             self.ligand_atom_emb = nn.Linear(ligand_atom_feature_dim, emb_dim)
         self.refine_net_type = g('model_type')
@@ -414,6 +432,8 @@ class ScorePosNet3D(nn.Module):
                 time_step=None, return_all=False, fix_x=False):
         """One denoiser evaluation (models/molopt_score_model.py:313-368).  ``time_step`` [B] is unused by the
         network when time_emb_dim == 0, as in the reference; with a time embedding it is required."""
+        if return_all and self.refine_net.num_blocks != 1:
+            raise NotImplementedError('return_all with num_blocks > 1: only the final state leaves the library')
         native = self._native(protein_pos.device)
         B = int(batch_protein.max().item()) + 1          # same host sync as the reference (:316)
         gbias = self._time_bias(time_step, B)
@@ -431,8 +451,6 @@ class ScorePosNet3D(nn.Module):
         lpos, lv = init_ligand_pos.contiguous().float(), init_ligand_v.contiguous()
         preds = native.model_forward(protein_pos.contiguous().float(), protein_v.contiguous().float(), pptr, lpos, lv, lptr,
                                      fix_x=fix_x, ligand_graph_bias=gbias)
-        if return_all and self.refine_net.num_blocks != 1:
-            raise NotImplementedError('return_all with num_blocks > 1: only the final state leaves the library')
         if return_all:
             # :360-367 -- the refine net records the state before and after each block; num_blocks == 1 here, so the
             # lists hold the block input (the embedded ligand atoms at their input positions) and the block output
@@ -448,6 +466,9 @@ class ScorePosNet3D(nn.Module):
         zero), or None when time_emb_dim == 0 (models/molopt_score_model.py:319-329): ligand_atom_emb is linear in its input
         ``[one_hot(v), time feature]``, so its time columns applied to the graph's time feature are a per-graph vector added to
         every ligand atom's embedding -- a few hundred multiplies, done here with torch; the kernels add the row."""
+        if self.time_emb_dim > 0 and self.time_emb_mode == 'sin':
+            raise NotImplementedError("time_emb_mode='sin': the reference's forward concatenates a per-graph with a per-atom tensor "
+                                      '(models/molopt_score_model.py:326-327) and fails unless every graph has one ligand atom; not reproduced')
         if self.time_emb_dim <= 0:
             return None
         if time_step is None:

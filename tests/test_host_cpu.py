@@ -204,15 +204,23 @@ def test_radius_mode_warns_that_it_is_the_projects_rule():
 
 def test_round4_config_options_are_accepted_or_refused_like_the_reference():
     """model_mean_type 'noise' and time_emb_mode 'simple' construct (state_dict layout as the reference's: one more column of
-    ligand_atom_emb); time_emb_mode 'sin' -- dead code in the reference (torch.cat of [N_l, C] with [B, dim], :326-327) -- and the
-    other architectures outside configs/training.yml raise."""
+    ligand_atom_emb); time_emb_mode 'sin' -- dead code in the reference's forward (torch.cat of [N_l, C] with [B, dim], :326-327) --
+    constructs and refuses at forward, like the reference; the other architectures outside configs/training.yml raise."""
     from targetdiff_amd.models import ScorePosNet3D
     cfg = dict(weights.DEFAULT_MODEL_CONFIG)
     m = ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='simple', model_mean_type='noise'), 27, 13)
     assert m.ligand_atom_emb.weight.shape == (127, 14) and m.model_mean_type == 'noise'
     sd = weights.time_emb_state_dict(5)
     assert not m.load_state_dict(sd, strict=False).unexpected_keys
+    # 'sin': constructed as the reference constructs it (same state_dict keys and shapes, so a checkpoint loads with strict=True);
+    # forward refuses, where the reference's own forward fails (torch.cat of [N_l, C] with [B, dim])
+    ms = ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='sin'), 27, 13)
+    keys = {k: tuple(v.shape) for k, v in ms.state_dict().items() if k.startswith('time_emb') or k.startswith('ligand_atom_emb')}
+    assert keys == {'time_emb.1.weight': (32, 8), 'time_emb.1.bias': (32,), 'time_emb.3.weight': (8, 32), 'time_emb.3.bias': (8,),
+                    'ligand_atom_emb.weight': (127, 21), 'ligand_atom_emb.bias': (127,)}
     with pytest.raises(NotImplementedError, match='sin'):
-        ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='sin'), 27, 13)
+        ms._time_bias(torch.zeros(2), 2)
+    with pytest.raises(NotImplementedError):
+        ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='other'), 27, 13)
     with pytest.raises(ValueError):
         ScorePosNet3D(dict(cfg, model_mean_type='x0'), 27, 13)
