@@ -310,7 +310,7 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded = 0) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16p, R16q; float ln_c1, ln_c2; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, int alt) {
     const MlpSrc m = fm.src();
@@ -353,36 +353,7 @@ EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, 
                         }
             }
     }
-    // the same table as exact bf16 piece triples, A-operand order of v_mfma_f32_16x16x32_bf16 (lane = (hidden lo, k group g),
-    // slots j = 0..7 -> k = 8g + j; k < 20 Gaussians, k = 20 the edge-type column, k >= 21 zero: P_i is added separately)
-    o.R16p = 0;
-    {
-        o.R16p = pk.alloc((size_t)2 * 2 * 3 * 8 * 48 * 4);
-        uint32_t *dp = reinterpret_cast<uint32_t *>(pk.data.data() + o.R16p);
-        for (int cls = 0; cls < 2; ++cls)
-            for (int sl = 0; sl < 2; ++sl) {
-                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
-                for (int hb = 0; hb < 8; ++hb)
-                    for (int l48 = 0; l48 < 48; ++l48) {
-                        const int lo = l48 & 15, g = l48 >> 4, n = 16 * hb + lo;
-                        uint32_t pieces[3][8];
-                        for (int j = 0; j < 8; ++j) {
-                            const int kk = 8 * g + j;
-                            float r = 0.f;
-                            if (kk < TD_NG) r = m.w0[(size_t)n * in_dim + 4 + TD_NG * type + kk];
-                            else if (kk == TD_NG) r = m.w0[(size_t)n * in_dim + type];
-                            for (int p = 0; p < 3; ++p) {
-                                pieces[p][j] = bf16_rne(r);
-                                r -= bf16_to_f32(pieces[p][j]);
-                            }
-                        }
-                        for (int p = 0; p < 3; ++p)
-                            for (int w = 0; w < 4; ++w)
-                                dp[(((((size_t)cls * 2 + sl) * 3 + p) * 8 + hb) * 48 + l48) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
-                    }
-            }
-    }
-    // ... and K-packed (pack_pk4_table): [dst class][source class] x 24 KiB
+    // the same table as exact bf16 piece triples, K-packed (pack_pk4_table): [dst class][source class] x 28 KiB
     o.R16q = pk.alloc((size_t)2 * 2 * PK4_WORDS);
     for (int cls = 0; cls < 2; ++cls)
         for (int sl = 0; sl < 2; ++sl) {
@@ -586,27 +557,9 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     size_t oGb0 = pack_vec(pk, gate.b0, H), oGg = pack_vec(pk, gate.g, H), oGb = pack_vec(pk, gate.b, H),
            oGw3 = pack_vec(pk, gate.w3, H), oGoff = pack_vec(pk, goff, TD_NG);
     const float gate_b3 = gate.b3[0], gate_coeff = gaussian_coeff(goff);
-    // the same first layer as bf16 piece triples in the A-operand order of v_mfma_f32_16x16x32_bf16 (see pack_edge_mlp)
-    const size_t oGRp = pk.alloc((size_t)3 * 8 * 48 * 4);
-    {
-        uint32_t *dp = reinterpret_cast<uint32_t *>(pk.data.data() + oGRp);
-        for (int hb = 0; hb < 8; ++hb)
-            for (int l48 = 0; l48 < 48; ++l48) {
-                const int lo = l48 & 15, g = l48 >> 4, n = 16 * hb + lo;
-                uint32_t pieces[3][8];
-                for (int j = 0; j < 8; ++j) {
-                    const int kk = 8 * g + j;
-                    float r = kk < TD_NG ? gate.w0[(size_t)n * TD_NG + kk] : 0.f;
-                    for (int p = 0; p < 3; ++p) {
-                        pieces[p][j] = bf16_rne(r);
-                        r -= bf16_to_f32(pieces[p][j]);
-                    }
-                }
-                for (int p = 0; p < 3; ++p)
-                    for (int w = 0; w < 4; ++w)
-                        dp[(((size_t)p * 8 + hb) * 48 + l48) * 4 + w] = pieces[p][2 * w] | (pieces[p][2 * w + 1] << 16);
-            }
-    }
+    // the same first layer as exact bf16 piece triples, K-packed like the edge MLPs' (pack_pk4_table; no type column)
+    const size_t oGRp = pk.alloc(PK4_WORDS);
+    pack_pk4_table(reinterpret_cast<uint32_t *>(pk.data.data() + oGRp), [&](int n, int k) { return k < TD_NG ? gate.w0[(size_t)n * TD_NG + k] : 0.f; });
     // ---- layers.  A reference layer is num_x2h x2h stages followed by num_h2x h2x stages (models/uni_transformer.py:190-206; both 1 in
     // configs/training.yml); row l * M + i of m->layers holds x2h stage i and h2x stage i of layer l (M = max of the two counts), so with
     // one stage of each kind the array is the layer list.  Blob order per layer: offsets; per x2h stage hk, hv, hq, [node_output],
@@ -709,7 +662,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         o.R16p ? D + o.R16p : nullptr, D + o.R16q, o.ln_c1, o.ln_c2, split && o.R16p && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         D + o.R16q, o.ln_c1, o.ln_c2, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
@@ -767,10 +720,10 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         m->opt.edge_key_split = value != 0;
         m->gate.use_split = value != 0;
         for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) {
-            m->layers[l].hk.use_split = m->layers[l].hk.R16p && value != 0;
-            m->layers[l].hv.use_split = m->layers[l].hv.R16p && value != 0;
-            m->layers[l].xk.use_split = m->layers[l].xk.R16p && value != 0;
-            m->layers[l].xv.use_split = m->layers[l].xv.R16p && value != 0;
+            m->layers[l].hk.use_split = m->layers[l].hk.R16q && value != 0;
+            m->layers[l].hv.use_split = m->layers[l].hv.R16q && value != 0;
+            m->layers[l].xk.use_split = m->layers[l].xk.R16q && value != 0;
+            m->layers[l].xv.use_split = m->layers[l].xv.R16q && value != 0;
         }
     } else if (strcmp(name, "session_hop_levels") == 0) {
         if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }

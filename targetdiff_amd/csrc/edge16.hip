@@ -340,7 +340,6 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
 // instruction covers the whole K = 21 (20 Gaussians + the edge-type column; k = 8 g + j for lane group g, slot j) at half the
 // issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds (before or after the products).
 typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
-constexpr int E16P_U4 = 2 * 2 * 3 * 8 * 48;                 // uint4 entries of the piece table [cls][slot][piece][hb][48] (72 KiB)
 
 __device__ __forceinline__ floatx4_t td_mfma16b(uint4 a, uint4 b, floatx4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_16, a), __builtin_bit_cast(bf16x8_16, b), c, 0, 0, 0);
@@ -379,6 +378,92 @@ __device__ __forceinline__ void td_stage_pk4(const float *__restrict__ src, floa
     }
 }
 
+// B operands of the K-packed products for one 16-edge block: the five inputs m[0..4] of the lane's Gaussians (already masked to the
+// source class), exactly split; ctype = the type column's constant for this lane (td_pk4_ctype; 0: no such column).
+//   t0 = (b1 | b2)[k0..k3]   t1 = (b2 | b1)[k0..k3]   t2 = b1[k0..k3] | (p1 p1 p2 p2)[k4]   t3 = b3[k0..k3] | (p1 p3)[k4], type constant
+__device__ __forceinline__ unsigned td_pk4_ctype(int g) { return g == 0 ? 0x3f803f80u : (g == 1 ? 0x00003f80u : 0u); }      // bf16 1.0
+__device__ __forceinline__ void td_pk4_bquads(const float (&m)[5], unsigned ctype, uint4 (&bq)[4]) {
+    unsigned d1a, d2a, d3a, d1b, d2b, d3b;
+    td_split_pair(m[0], m[1], d1a, d2a, d3a);
+    td_split_pair(m[2], m[3], d1b, d2b, d3b);
+    // k4 alone: both halves of a word hold the same piece
+    const unsigned u1 = td_cvt_pk_bf16_e(m[4], m[4]);
+    const float r1 = m[4] - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned u2 = td_cvt_pk_bf16_e(r1, r1);
+    const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
+    const unsigned u3 = td_cvt_pk_bf16_e(r2, r2);
+    const unsigned e13 = __builtin_amdgcn_perm(u3, u1, 0x07060100u);      // low half p1, high half p3
+    bq[0] = make_uint4(d1a, d1b, d2a, d2b);
+    bq[1] = make_uint4(d2a, d2b, d1a, d1b);
+    bq[2] = make_uint4(d1a, d1b, u1, u2);
+    bq[3] = make_uint4(d3a, d3b, e13, ctype);
+}
+// The 4 x 8 x NEB products of one (dst class, source class) table at Rs (LDS; already offset by the lane) into acc.
+// PKR = 1: QA, QB, QC resident (three 16-byte reads per hidden block); PKR = 2: QA, QB, H7 (t3's operand is two 8-byte reads).
+// Twelve steps = 4 pairs of hidden blocks x {QC (t3), QB (t2), QA (t1, t0)}, low-order instructions first within a pair; a step's two
+// A quads feed 4 (8) products on four interleaved accumulator chains.  AH > 0: the quads of step n + AH are read BEFORE step n's
+// products are issued (scheduling barrier) -- left to itself (AH = 0) the compiler keeps two quads live and reads each pair right in
+// front of its products, twelve exposed LDS round trips per row and source class; that is what the key pass's 168 registers allow.
+template <int PKR, int AH, int NEB>
+__device__ __forceinline__ void td_pk4_tiles(const uint4 *__restrict__ Rs, int lane, const uint4 (&bq)[NEB][4], floatx4_t (&acc)[2][8]) {
+    // PKR = 2: the a1 half of QA is read a second time, as the first half of t3's operand, through a pointer the compiler cannot
+    // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
+    const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
+    if constexpr (PKR == 2) asm volatile("" : "+v"(Ra));
+    auto quad = [&](int step, int h2) -> uint4 {
+        const int hb = 2 * (step / 3) + h2, kind = step % 3;
+        if (kind == 2) return Rs[hb * 64];
+        if (kind == 1) return Rs[512 + hb * 64];
+        if constexpr (PKR == 1) return Rs[1024 + hb * 64];
+        else {
+            const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
+            return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+        }
+    };
+    if constexpr (AH == 0) {
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {
+            uint4 ar[2][3];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int kind = 0; kind < 3; ++kind) ar[h2][kind] = quad(3 * hp + kind, h2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kind = t < 2 ? t : 2, tb = 3 - t;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int eb = 0; eb < NEB; ++eb)
+                        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][kind], bq[eb][tb], acc[eb][2 * hp + h2]);
+            }
+        }
+    } else {
+        uint4 ring[AH + 1][2];
+#pragma unroll
+        for (int n = 0; n < AH; ++n) { ring[n][0] = quad(n, 0); ring[n][1] = quad(n, 1); }
+#pragma unroll
+        for (int step = 0; step < 12; ++step) {
+            if (step + AH < 12) {
+                ring[(step + AH) % (AH + 1)][0] = quad(step + AH, 0);
+                ring[(step + AH) % (AH + 1)][1] = quad(step + AH, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int hp = step / 3, kind = step % 3;
+            const uint4 (&aq)[2] = ring[step % (AH + 1)];
+#pragma unroll
+            for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
+                const int tb = kind == 0 ? 3 : (kind == 1 ? 2 : 1 - pass);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int eb = 0; eb < NEB; ++eb)
+                        acc[eb][2 * hp + h2] = td_mfma16b(aq[h2], bq[eb][tb], acc[eb][2 * hp + h2]);
+            }
+        }
+    }
+}
+
 // Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
 // PK = 1 / 2: the K-packed form -- FOUR products per (hidden block, edge block) and source class instead of six: the 21 inputs' six piece
 // products are 123 (piece, piece, k) slot pairs and fit 4 x 32 K slots (pack_pk4_table, api.cpp); lane group g owns the Gaussians
@@ -393,13 +478,12 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // k = 48; the caller tests it, wave-uniform) and costs nothing: no P_i adds, no Gaussians, no products, z = 0 and 1 / sigma = 0.
 // LN_SKIP (NEB = 2 only): the LayerNorm leaves out a second block without edges (z = 0, 1 / sigma = 0) -- what the chunk-walking key pass, which
 // has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB = 2, bool LN_SKIP = false, int PK = 0, int AH = 0, class Hook = TdNoHook>
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB, bool LN_SKIP, int PK, int AH = 0, class Hook = TdNoHook>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ KB,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
                                                        floatx4_t (&acc)[2][8], Edge2 &ed, Hook before_products = Hook()) {
-    const int lo = lane & 15, g = lane >> 4;
-    const int l48 = (g < 3 ? g : 2) * 16 + lo;
+    const int g = lane >> 4;
     const float4 xi = r.xi;
     ed.xi = xi;
     const int cls = xi.w > 0.5f ? 0 : 1;
@@ -421,9 +505,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     if (!PI_LATE) add_pi();
     int slot[NEB];
     bool has[2][NEB];
-    constexpr bool PK4 = PK != 0;
-    constexpr int NGV = PK4 ? 5 : 8;
-    float gv[NEB][NGV];
+    float gv[NEB][5];
     if (NEB == 1) {
         ed.valid[1] = false; ed.any[1] = false;
         ed.rel[1][0] = ed.rel[1][1] = ed.rel[1][2] = 0.f;
@@ -432,8 +514,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         for (int hb = 0; hb < 8; ++hb) acc[1][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
     }
     // g_k(d) = exp(coeff (d - mu_k)^2) = exp2(c2 (d - mu_k)^2): four instructions per entry (the compiler cannot fold the two scale
-    // factors of __expf(coeff * u * u) itself).  offj holds TD_FAR_CENTRE behind the 20 Gaussians, so the unused K slots come out as
-    // exp2(-huge) = 0 without a select; slot k = 20 (lane group 2, j = 4) is the edge-type column, constant 1.  A pad (neighbour
+    // factors of __expf(coeff * u * u) itself); lane group g owns the Gaussians k = 5g .. 5g + 4 (offj[0..4]).  A pad (neighbour
     // index -1, gathered as the row itself) is NOT zeroed: its column of z is finite garbage that the softmax (logit -inf) and the
     // aggregations (alpha = 0, `valid` selects) never let through.
     const float c2 = a.coeff * TD_LOG2E;
@@ -450,154 +531,38 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         has[1][eb] = __ballot(ed.valid[eb] && slot[eb] == 1) != 0ull;
         ed.any[eb] = has[0][eb] || has[1][eb];
 #pragma unroll
-        for (int j = 0; j < NGV; ++j) {
+        for (int j = 0; j < 5; ++j) {
             const float u = dist - offj[j];
             gv[eb][j] = __builtin_amdgcn_exp2f(c2 * (u * u));
         }
-        if (!PK4 && g == 2) gv[eb][4] = 1.f;
     }
     before_products();
-    // K-packed products of source class sl: B quads t0 = (b1 | b2)[k0..k3], t1 = (b2 | b1)[k0..k3], t2 = b1[k0..k3] | (p1 p1 p2 p2)[k4],
-    // t3 = b3[k0..k3] | (p1 p3)[k4], type constant; A quads QA (t0 and t1), QB (t2), QC (t3)
+    // products of source class sl with the edge inputs (B operand: zeros for the edges of the other class)
     auto products4 = [&](int sl) {
-        if constexpr (PK4) {
         uint4 bq[NEB][4];
-        const unsigned ctype = g == 0 ? 0x3f803f80u : (g == 1 ? 0x00003f80u : 0u);       // bf16 1.0 in the type column's slots
+        const unsigned ctype = td_pk4_ctype(g);
 #pragma unroll
         for (int eb = 0; eb < NEB; ++eb) {
             const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
             float m[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) m[j] = keep ? gv[eb][j] : 0.f;
-            unsigned d1a, d2a, d3a, d1b, d2b, d3b;
-            td_split_pair(m[0], m[1], d1a, d2a, d3a);
-            td_split_pair(m[2], m[3], d1b, d2b, d3b);
-            // k4 alone: both halves of a word hold the same piece
-            const unsigned u1 = td_cvt_pk_bf16_e(m[4], m[4]);
-            const float r1 = m[4] - __uint_as_float(u1 & 0xffff0000u);
-            const unsigned u2 = td_cvt_pk_bf16_e(r1, r1);
-            const float r2 = r1 - __uint_as_float(u2 & 0xffff0000u);
-            const unsigned u3 = td_cvt_pk_bf16_e(r2, r2);
-            const unsigned e13 = __builtin_amdgcn_perm(u3, u1, 0x07060100u);      // low half p1, high half p3
-            bq[eb][0] = make_uint4(d1a, d1b, d2a, d2b);
-            bq[eb][1] = make_uint4(d2a, d2b, d1a, d1b);
-            bq[eb][2] = make_uint4(d1a, d1b, u1, u2);
-            bq[eb][3] = make_uint4(d3a, d3b, e13, keep ? ctype : 0u);
+            td_pk4_bquads(m, keep ? ctype : 0u, bq[eb]);
         }
         // PK = 3 (all four tables resident, key pass): the protein-destination tables in the 48-byte form, the ligand-destination ones
         // (one row in 25) in the 40-byte form -- together 88 KiB
-        auto tiles = [&](auto pk_tag, const uint4 *Rs) {
-            constexpr int PKR = decltype(pk_tag)::value;
-            // PKR = 2: the a1 half of QA is read a second time, as the first half of t3's operand, through a pointer the compiler cannot
-            // see through (it would otherwise forward the 16-byte read and assemble the operand with two v_mov per hidden block)
-            const uint2 *Ra = reinterpret_cast<const uint2 *>(Rs);
-            if constexpr (PKR == 2) asm volatile("" : "+v"(Ra));
-            // Twelve steps = 4 pairs of hidden blocks x {QC (t3), QB (t2), QA (t1, t0)}, low-order instructions first within a pair; a
-            // step's two A quads feed 4 (8) products on four interleaved accumulator chains.  The quads of step n + AH are
-            // read BEFORE step n's products are issued (scheduling barrier): left to itself the compiler keeps two quads live and reads
-            // each pair right in front of its products -- twelve exposed LDS round trips per row and source class.
-            auto quad = [&](int step, int h2) -> uint4 {
-                const int hb = 2 * (step / 3) + h2, kind = step % 3;
-                if (kind == 2) return Rs[hb * 64];
-                if (kind == 1) return Rs[512 + hb * 64];
-                if constexpr (PKR == 1) return Rs[1024 + hb * 64];
-                else {
-                    const uint2 lo2 = Ra[hb * 128], hi2 = reinterpret_cast<const uint2 *>(Rs + 1024 - lane)[hb * 64 + lane];
-                    return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
-                }
-            };
-            if constexpr (AH == 0) {          // the compiler's own order (two quads live: what the key pass's 168 registers allow)
-#pragma unroll
-                for (int hp = 0; hp < 4; ++hp) {
-                    uint4 ar[2][3];
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                        for (int kind = 0; kind < 3; ++kind) ar[h2][kind] = quad(3 * hp + kind, h2);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kind = t < 2 ? t : 2, tb = 3 - t;
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                            for (int eb = 0; eb < NEB; ++eb)
-                                acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][kind], bq[eb][tb], acc[eb][2 * hp + h2]);
-                    }
-                }
-                return;
-            }
-            uint4 ring[AH + 1][2];
-#pragma unroll
-            for (int n = 0; n < AH; ++n) { ring[n][0] = quad(n, 0); ring[n][1] = quad(n, 1); }
-#pragma unroll
-            for (int step = 0; step < 12; ++step) {
-                if (step + AH < 12) {
-                    ring[(step + AH) % (AH + 1)][0] = quad(step + AH, 0);
-                    ring[(step + AH) % (AH + 1)][1] = quad(step + AH, 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int hp = step / 3, kind = step % 3;
-                const uint4 (&aq)[2] = ring[step % (AH + 1)];
-#pragma unroll
-                for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
-                    const int tb = kind == 0 ? 3 : (kind == 1 ? 2 : 1 - pass);
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                        for (int eb = 0; eb < NEB; ++eb)
-                            acc[eb][2 * hp + h2] = td_mfma16b(aq[h2], bq[eb][tb], acc[eb][2 * hp + h2]);
-                }
-            }
-        };
         if constexpr (PK == 3) {
             static_assert(PK != 3 || !ONE_CLASS, "PK = 3 holds both destination classes");
-            if (cls) tiles(std::integral_constant<int, 1>(), Rp + 2 * e16q_cs_u4<2>() + (size_t)sl * e16q_cs_u4<1>() + lane);
-            else tiles(std::integral_constant<int, 2>(), Rp + (size_t)sl * e16q_cs_u4<2>() + lane);
+            if (cls) td_pk4_tiles<1, AH, NEB>(Rp + 2 * e16q_cs_u4<2>() + (size_t)sl * e16q_cs_u4<1>() + lane, lane, bq, acc);
+            else td_pk4_tiles<2, AH, NEB>(Rp + (size_t)sl * e16q_cs_u4<2>() + lane, lane, bq, acc);
         } else
-            tiles(std::integral_constant<int, PK>(), Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane);
-        }
-    };
-    // products of source class sl with the edge inputs (B operand: the edge inputs in 3 pieces, zeros for the edges of the other class)
-    auto products = [&](int sl) {
-        if constexpr (!PK4) {
-        uint4 bm[NEB][3];
-#pragma unroll
-        for (int eb = 0; eb < NEB; ++eb) {
-            const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
-            float m[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = keep ? gv[eb][j] : 0.f;
-            td_split_pair(m[0], m[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
-            td_split_pair(m[2], m[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
-            td_split_pair(m[4], m[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
-            td_split_pair(m[6], m[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
-        }
-        const uint4 *Rs = Rp + (size_t)(((ONE_CLASS ? 0 : cls * 2) + sl) * 3) * 8 * 48 + l48;
-#pragma unroll
-        for (int hp = 0; hp < 4; ++hp) {
-            uint4 ar[2][3];                 // A: table pieces of hidden blocks 2hp, 2hp + 1
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) ar[h2][p] = Rs[(p * 8 + 2 * hp + h2) * 48];
-            // lane group 3 (k = 24 .. 31) re-reads group 2's entries: its B slots are all zero, so they contribute nothing
-            // low-order products first; two hidden blocks x two edge blocks interleave four accumulator chains
-#define TD_PROD(pa, pb)                                                                                  \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < NEB; ++eb)    \
-        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][pa], bm[eb][pb], acc[eb][2 * hp + h2]);
-            TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
-#undef TD_PROD
-        }
-        }
+            td_pk4_tiles<PK, AH, NEB>(Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane, lane, bq, acc);
     };
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         bool any_sl = has[sl][0];
         if (NEB == 2) any_sl = any_sl || has[sl][NEB - 1];
-        if (any_sl) {
-            if constexpr (PK4) products4(sl);
-            else products(sl);
-        }
+        if (any_sl) products4(sl);
     }
     if (PI_LATE) add_pi();
     const TdLn ln{a.mlp.ln_c1, a.mlp.ln_c2};
@@ -1637,9 +1602,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 // 32-slot row (a dst node, or a chunk of a node's in-edges on general graphs), first layer on bf16 piece triples (the 18 KiB
 // piece table, bias, LayerNorm affine and output weights in LDS), LayerNorm + ReLU in the transposed layout, then each lane
 // dots its 32 hidden units of an edge with w3 and the four lane groups add up.
-constexpr int G16_WAVES = 4;        // 162 VGPRs: three 4-wave workgroups per CU
-constexpr int G16P_U4 = 3 * 8 * 48;                                     // uint4 entries of the gate's piece table
-constexpr size_t G16_LDS_BYTES = (size_t)G16P_U4 * 16 + (size_t)3 * TD_H * sizeof(float);
+constexpr int G16_WAVES = 4;        // three 4-wave workgroups per CU
+constexpr int G16Q_U4 = e16q_cs_u4<1>();                                // the gate's K-packed table (QA, QB, QC): 24 KiB
+constexpr size_t G16_LDS_BYTES = (size_t)G16Q_U4 * 16 + (size_t)3 * TD_H * sizeof(float);
 
 __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, const float4 *__restrict__ x4,
                                                                      const int32_t *__restrict__ nbr, int64_t N,
@@ -1647,24 +1612,24 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
                                                                      const int32_t *__restrict__ count_ptr,
                                                                      const int32_t *__restrict__ chunk_node, float *__restrict__ ew) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const uint4 *Rp = reinterpret_cast<const uint4 *>(lds);              // [piece][hb][48]
-    float *B0 = lds + G16P_U4 * 4, *BET = B0 + TD_H, *W3 = BET + TD_H;      // bias, beta / |gamma| (folded LayerNorm), output weights
+    const uint4 *Rp = reinterpret_cast<const uint4 *>(lds);
+    float *B0 = lds + G16Q_U4 * 4, *BET = B0 + TD_H, *W3 = BET + TD_H;      // bias, beta / (|gamma| M) (folded LayerNorm), output weights
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
-        td_stage_lds16(reinterpret_cast<const float4 *>(gt.R16p), reinterpret_cast<float4 *>(lds), G16P_U4, tid, G16_WAVES * 64);
+        td_stage_pk4<1>(gt.R16q, lds, 1, tid, G16_WAVES * 64);
         for (int t = tid; t < 3 * TD_H; t += G16_WAVES * 64) {
             const int n = t & (TD_H - 1);
             B0[t] = t < TD_H ? gt.b0[n] : (t < 2 * TD_H ? gt.beta[n] : gt.w3[n]);
         }
     }
-    float offj[8];
+    float offj[5];          // lane group g owns the Gaussians 5g .. 5g + 4 (K-packed products, td_pk4_tiles)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) offj[j] = (8 * g + j) < TD_NG ? gt.offsets[8 * g + j] : 0.f;
+    for (int j = 0; j < 5; ++j) offj[j] = gt.offsets[5 * g + j];
     __syncthreads();
     int64_t begin, end;
     td_node_range16(N, count_ptr, begin, end);
-    const int l48 = (g < 3 ? g : 2) * 16 + lo;
+    const float c2 = gt.coeff * TD_LOG2E;
 
     for (int64_t it = begin + wid; it < end; it += G16_WAVES) {
         const int64_t row = rows ? (int64_t)rows[it] : it;                       // row of nbr / ew
@@ -1674,7 +1639,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
         jn[0] = nbr[row * TD_K + lo];
         jn[1] = nbr[row * TD_K + 16 + lo];
         floatx4_t acc[2][8];
-        uint4 bm[2][3];
+        uint4 bq[2][4];
         bool valid[2];
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
@@ -1682,35 +1647,20 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
             const float4 xj = x4[valid[eb] ? jn[eb] : (int)i];
             const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
             const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
-            float gv[8];
+            float gv[5];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 5; ++j) {
                 const float u = dist - offj[j];
-                gv[j] = (8 * g + j) < TD_NG ? expf(gt.coeff * u * u) : 0.f;
+                gv[j] = __builtin_amdgcn_exp2f(c2 * (u * u));
             }
-            td_split_pair(gv[0], gv[1], bm[eb][0].x, bm[eb][1].x, bm[eb][2].x);
-            td_split_pair(gv[2], gv[3], bm[eb][0].y, bm[eb][1].y, bm[eb][2].y);
-            td_split_pair(gv[4], gv[5], bm[eb][0].z, bm[eb][1].z, bm[eb][2].z);
-            td_split_pair(gv[6], gv[7], bm[eb][0].w, bm[eb][1].w, bm[eb][2].w);
+            td_pk4_bquads(gv, 0u, bq[eb]);          // (no type column: the gate's first layer is the 20 Gaussians)
 #pragma unroll
             for (int hb = 0; hb < 8; ++hb) {
                 const float4 b = *reinterpret_cast<const float4 *>(B0 + 16 * hb + 4 * g);
                 acc[eb][hb][0] = b.x; acc[eb][hb][1] = b.y; acc[eb][hb][2] = b.z; acc[eb][hb][3] = b.w;
             }
         }
-#pragma unroll
-        for (int hp = 0; hp < 4; ++hp) {
-            uint4 ar[2][3];
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) ar[h2][p] = Rp[(p * 8 + 2 * hp + h2) * 48 + l48];
-#define TD_PROD(pa, pb)                                                                                  \
-    _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) _Pragma("unroll") for (int eb = 0; eb < 2; ++eb)      \
-        acc[eb][2 * hp + h2] = td_mfma16b(ar[h2][pa], bm[eb][pb], acc[eb][2 * hp + h2]);
-            TD_PROD(1, 1) TD_PROD(2, 0) TD_PROD(0, 2) TD_PROD(1, 0) TD_PROD(0, 1) TD_PROD(0, 0)
-#undef TD_PROD
-        }
+        td_pk4_tiles<1, 1, 2>(Rp + lane, lane, bq, acc);
         td_ln_relu16<2>(BET, g, acc, TdLn{gt.ln_c1, gt.ln_c2});
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {

@@ -60,10 +60,8 @@ struct TdEdgeMlp {
     const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
     const float *Walt16;   // key MLPs: Wq16[hb][r][jq][lane][4] = W2[8 lo + 4jq + jj][16hb + 4g + r]
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
-    const float *R16p;     // the radial/type table as bf16 piece triples for v_mfma_f32_16x16x32_bf16:
-                           // [2 dst class][2 slot][3 piece][8 hidden block][48 lanes (k group g < 3)] x 8 bf16 (k = 8g + j)
-    const float *R16q;     // the same pieces K-packed for four instead of six products per tile (pack_pk4_table, api.cpp):
-                           // [2 dst class][2 slot][8 hidden block][3 quad][64 lanes] x 8 bf16
+    const float *R16q;     // the radial/type table as exact bf16 piece triples, K-packed for four v_mfma_f32_16x16x32_bf16 per tile
+                           // (pack_pk4_table, api.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, api.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
@@ -107,7 +105,7 @@ struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_tr
     float b3;
     const float *offsets;  // [20]
     float coeff;
-    const float *R16p;     // the 20 x 128 first layer as bf16 piece triples [3 piece][8 hidden block][48 lanes] x 8 bf16 (k = 8g + j)
+    const float *R16q;     // the 20 x 128 first layer as exact bf16 piece triples, K-packed (pack_pk4_table, api.cpp)
     float ln_c1, ln_c2;    // as in TdEdgeMlp
     bool use_split;        // model option "edge_key_split"
 };
