@@ -233,7 +233,7 @@ F_REDUCED_PER_NODE = 24.5e6                          # same, h2x on ligand dst r
 
 def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows):
     """FLOPs the launched kernels execute in one denoiser step, from the rows every launch processes (the same row lists
-    run_backbone in csrc/api.cpp walks).  Stateless forward: every layer runs on every row."""
+    run_backbone in csrc/plan.cpp walks).  Stateless forward: every layer runs on every row."""
     N, Nl, L = n_nodes, n_lig, n_layers
     if session_rows is None:
         x2h_rows = [N] * L

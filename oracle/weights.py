@@ -178,7 +178,7 @@ def time_emb_state_dict(seed: int, ligand_dim=LIGAND_FEATURE_DIM):
 # ------------------------------------------------------------------------------------------ LayerNorm weights of every sign (round 4)
 def ln_signs_state_dict(seed: int):
     """make_state_dict(seed) with the LayerNorm weights of every MLP made adversarial for a fold of the LayerNorm into the neighbouring
-    Linears (the product packs the edge MLPs that way, csrc/api.cpp FoldedMlp): every 7th unit negative, units 5 (mod 31) exactly zero,
+    Linears (the product packs the edge MLPs that way, csrc/pack.cpp FoldedMlp): every 7th unit negative, units 5 (mod 31) exactly zero,
     units 3 (mod 29) tiny (1e-3 of their value).  The seeded weights are 1 +- 0.2, i.e. all positive."""
     sd = make_state_dict(seed)
     for key, w in sd.items():

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(LIBDIR, 'libtargetdiff_hip.so')
-SOURCES = ['api.cpp', 'graph.hip', 'node.hip', 'gate.hip', 'edge16.hip', 'misc.hip', 'likelihood.hip', 'egnn.hip']
+SOURCES = ['entry.cpp', 'pack.cpp', 'plan.cpp', 'forward.cpp', 'session.cpp', 'graph.hip', 'node.hip', 'gate.hip', 'edge16.hip', 'misc.hip', 'likelihood.hip', 'egnn.hip']
 ARCH = 'gfx950'
 # NB: the kNN distance uses __fmul_rn/__fadd_rn explicitly (td_dist2), so the default fp contraction is safe.
 # -fvisibility=hidden: only the extern "C" entry points of include/targetdiff_hip.h (visibility push(default)) are exported
@@ -71,8 +71,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
-        if force or _stale(obj, [sp, os.path.abspath(__file__)] + headers) or (src == 'api.cpp' and tag_changed):
-            cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ([f'-DTD_BUILD_TAG="{tag}"'] if src == 'api.cpp' else []) + ['-c', sp, '-o', obj]
+        if force or _stale(obj, [sp, os.path.abspath(__file__)] + headers) or (src == 'entry.cpp' and tag_changed):
+            cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ([f'-DTD_BUILD_TAG="{tag}"'] if src == 'entry.cpp' else []) + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -223,7 +223,7 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
 }
 
 // LayerNorm + ReLU of an edge MLP in the transposed accumulator layout (a lane owns 32 of an edge's 128 hidden units for each of its
-// two edges; the other 96 sit in the lanes lo + 16 g'), in the folded form the weights are packed for (FoldedMlp, api.cpp): the
+// two edges; the other 96 sit in the lanes lo + 16 g'), in the folded form the weights are packed for (FoldedMlp, pack.cpp): the
 // accumulators hold the CENTRED pre-activation with the sign of gamma applied, KB[n] = beta_n / (|gamma_n| M), and
 //     z''_n = clamp_[0,1](acc_n s + KB[n]),   s = 1 / (sigma M) = rsqrt(sum_n acc_n^2 * ln.c1 + ln.c2)
 // is the normalised activation over |gamma_n| M (M bounds it by 1, so the FMA's output clamp IS the ReLU); |gamma_n| M sits in the second
@@ -359,7 +359,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
     p3 = td_cvt_pk_bf16_e(rx, ry);
 }
 
-// K-packed piece tables (pack_pk4_table, api.cpp): one (dst class, source class) table is QA[hb 8][lane 64] (16 B), QB (16 B), H7 (8 B),
+// K-packed piece tables (pack_pk4_table, pack.cpp): one (dst class, source class) table is QA[hb 8][lane 64] (16 B), QB (16 B), H7 (8 B),
 // QC (16 B) = 28 KiB in global memory; in LDS a kernel keeps QA, QB and either H7 (PK = 2: 20 KiB) or QC (PK = 1: 24 KiB)
 constexpr int E16Q_GLOBAL_CS_U4 = 512 + 512 + 256 + 512;
 template <int PK> constexpr int e16q_cs_u4() { return PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256; }
@@ -466,7 +466,7 @@ __device__ __forceinline__ void td_pk4_tiles(const uint4 *__restrict__ Rs, int l
 
 // Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
 // PK = 1 / 2: the K-packed form -- FOUR products per (hidden block, edge block) and source class instead of six: the 21 inputs' six piece
-// products are 123 (piece, piece, k) slot pairs and fit 4 x 32 K slots (pack_pk4_table, api.cpp); lane group g owns the Gaussians
+// products are 123 (piece, piece, k) slot pairs and fit 4 x 32 K slots (pack_pk4_table, pack.cpp); lane group g owns the Gaussians
 // 5g .. 5g+4 (offj[0..4]; ten exponentials per lane instead of sixteen) and splits five values per edge instead of eight.  PK = 1: the
 // table in LDS holds QA, QB, QC (three 16-byte reads per hidden block); PK = 2: QA, QB, H7 (40 bytes per lane and hidden block; the
 // fourth product's operand is two 8-byte reads, QA's first half and H7).

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
             acc[2] = td_mfma(av, R[s].z, acc[2]);
             acc[3] = td_mfma(av, R[s].w, acc[3]);
         }
-        // LayerNorm in the folded form the gate's weights are packed for (FoldedMlp, api.cpp): the accumulators hold the centred
+        // LayerNorm in the folded form the gate's weights are packed for (FoldedMlp, pack.cpp): the accumulators hold the centred
         // pre-activation times the sign of the LayerNorm weight, bet = beta / (|gamma| M), w3 carries |gamma| M, the ReLU is the FMA's output clamp
         float outv = 0.f;
 #pragma unroll

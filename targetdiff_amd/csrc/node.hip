@@ -59,7 +59,7 @@ __device__ __forceinline__ void gemm128_lds(const float4 (&a)[16], const float4 
 // ---- exact 3-way bf16 splitting of both GEMM operands (model option node_proj_split, default on) ------------------------
 // An fp32 significand (24 bits) is exactly the sum of three bf16 pieces (8 bits each): x = x1 + x2 + x3.  The six largest of
 // the nine piece products (x1y1, x1y2, x2y1, x1y3, x3y1, x2y2) on v_mfma_f32_32x32x16_bf16, accumulated in fp32, reproduce
-// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time (api.cpp pack_B128_split:
+// the fp32 product to ~2e-7 relative at 16/6 of the fp32 MFMA rate.  B is pre-split at pack time (pack.cpp pack_B128_split:
 // chunks of [k-step 4][piece 3][tile 2][lane 64] x 8 bf16, the 8 k-slots of lane half `hi` in k-step s being
 // k = 16s + 8(j >> 2) + 4hi + (j & 3), i.e. exactly the two float4 of the fp32 A tile), A is split once per tile in registers.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

@@ -52,7 +52,7 @@ inline int td_set_lds(TdLdsOnce &once, const void *fn, size_t bytes) {
 //    radial/type table R and a bias;  * the second Linear is stored as per-wave MFMA B fragments.
 struct TdEdgeMlp {
     const float *R;        // [2 dst class][2 slot][12 kstep][64 lane][4 ntile]  first-layer radial+type B fragments
-    // (every table below comes from the MLP with its LayerNorm folded into the two Linears: FoldedMlp, api.cpp)
+    // (every table below comes from the MLP with its LayerNorm folded into the two Linears: FoldedMlp, pack.cpp)
     const float *gamma;    // [128] |LayerNorm weight| (already inside the second Linear's columns; not read by the kernels)
     const float *beta;     // [128] LayerNorm bias / (|LayerNorm weight| M): z'' = clamp_[0,1](centred pre-activation / (sigma M) + beta)
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
@@ -61,8 +61,8 @@ struct TdEdgeMlp {
     const float *Walt16;   // key MLPs: Wq16[hb][r][jq][lane][4] = W2[8 lo + 4jq + jj][16hb + 4g + r]
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
     const float *R16q;     // the radial/type table as exact bf16 piece triples, K-packed for four v_mfma_f32_16x16x32_bf16 per tile
-                           // (pack_pk4_table, api.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
-    float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, api.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
+                           // (pack_pk4_table, pack.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
+    float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
                            // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
@@ -105,7 +105,7 @@ struct TdGate {            // edge_pred_layer MLP(20 -> 128 -> 1) (models/uni_tr
     float b3;
     const float *offsets;  // [20]
     float coeff;
-    const float *R16q;     // the 20 x 128 first layer as exact bf16 piece triples, K-packed (pack_pk4_table, api.cpp)
+    const float *R16q;     // the 20 x 128 first layer as exact bf16 piece triples, K-packed (pack_pk4_table, pack.cpp)
     float ln_c1, ln_c2;    // as in TdEdgeMlp
     bool use_split;        // model option "edge_key_split"
 };

@@ -131,7 +131,7 @@ def test_node_stage_projections(model, state_dict):
             for nm in names[:2]:
                 w0 = state_dict[pre + nm + '.net.0.weight'].double()
                 b0 = state_dict[pre + nm + '.net.0.bias'].double()
-                # the projections come out in the folded form the edge MLPs' LayerNorm is packed for (FoldedMlp, csrc/api.cpp):
+                # the projections come out in the folded form the edge MLPs' LayerNorm is packed for (FoldedMlp, csrc/pack.cpp):
                 # centred over the hidden units, times the sign of the LayerNorm weight
                 sg = torch.where(state_dict[pre + nm + '.net.1.weight'].double() < 0, -1.0, 1.0)
                 fold = lambda p: sg * (p - p.mean(dim=1, keepdim=True))
