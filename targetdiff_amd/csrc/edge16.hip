@@ -420,7 +420,26 @@ __device__ __forceinline__ void td_pk4_tiles(const uint4 *__restrict__ Rs, int l
             return make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
         }
     };
-    if constexpr (AH == 0) {
+    if constexpr (AH < 0) {
+        // one quad ahead (4 more live registers than the compiler's own order): 24 steps of one A quad each, its 2 (4) products on the
+        // two edge blocks' accumulator chains
+        auto quad1 = [&](int st) -> uint4 { return quad(3 * (st / 6) + (st % 6) / 2, st & 1); };
+        uint4 cur = quad1(0);
+#pragma unroll
+        for (int st = 0; st < 24; ++st) {
+            uint4 nxt = cur;
+            if (st + 1 < 24) nxt = quad1(st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int hb = 2 * (st / 6) + (st & 1), kind = (st % 6) / 2;
+#pragma unroll
+            for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
+                const int tb = kind == 0 ? 3 : (kind == 1 ? 2 : 1 - pass);
+#pragma unroll
+                for (int eb = 0; eb < NEB; ++eb) acc[eb][hb] = td_mfma16b(cur, bq[eb][tb], acc[eb][hb]);
+            }
+            cur = nxt;
+        }
+    } else if constexpr (AH == 0) {
 #pragma unroll
         for (int hp = 0; hp < 4; ++hp) {
             uint4 ar[2][3];
@@ -590,6 +609,9 @@ constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per
 #ifndef TD_KEY_PK
 #define TD_KEY_PK 3
 #endif
+#ifndef TD_KEY_AH
+#define TD_KEY_AH -1       // key pass, default graph: the first layer's table quads read one quad ahead (td_pk4_tiles)
+#endif
 constexpr size_t K16S_LDS_BYTES = (size_t)(e16q_u4<TD_KEY_PK>() * 4 + E16_WQ_FLOATS + TD_H + 4 + 32) * sizeof(float);
 static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the row counter, the Gaussian centres
 
@@ -695,7 +717,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
                 td_first_layer_split16<EW, false, false, 1, false, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK, (CHUNKED || XV) ? 0 : TD_KEY_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
