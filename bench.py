@@ -26,8 +26,9 @@ Extra objects on the JSON line:
                launch time from HIP events recorded on the launch stream inside the timed region;
                peak = 157.3 TFLOP/s, the dense fp32 MFMA peak (= fp32 vector peak) -- the dtype the path computes in.
                matrix_bound_as_built is reported beside it: with the radial/type first layer on bf16 piece triples
-               (default) that layer's 6 x 32-deep bf16 products are priced at the 2.5 PFLOP/s dense bf16 peak and
-               everything else at the fp32 peak (= 196 TFLOP/s of the same algorithmic FLOPs for a 32-edge row).
+               (default) that layer's 4 x 32-deep K-packed bf16 products (the six piece products of the 21 inputs fill four
+               instructions' K slots since round 5) are priced at the 2.5 PFLOP/s dense bf16 peak and everything else at
+               the fp32 peak (= 224 TFLOP/s of the same algorithmic FLOPs for a 32-edge row).
   cpu_baseline the oracle restatement (torch CPU, same weights) timed on this host's cores over a bounded
                sample of the same workload (the same pocket, fewer samples, a few steps).
 """
@@ -50,8 +51,9 @@ from targetdiff_amd.models import ScorePosNet3D  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md (dense fp32 MFMA = vector peak)
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: ~2.5 PFLOP/s dense bf16 (2495 measured)
-# first layer of an attention pass on bf16 piece triples: 6 piece products, K padded 21 -> 32, all 32 slots of the row
-FIRST_LAYER_FLOP_BF16_EXECUTED = 6 * 2 * 32 * 128 * 32
+# first layer of an attention pass on bf16 piece triples: the six piece products of the 21 inputs K-packed into four 32-deep instructions
+# (csrc/edge16.hip td_pk4_tiles), all 32 slots of the row
+FIRST_LAYER_FLOP_BF16_EXECUTED = 4 * 2 * 32 * 128 * 32
 PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E ~ 8 TB/s
 # Dominant kernels: edge_value16_kernel (x2h value pass) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
 # identical for the two passes:
@@ -575,7 +577,7 @@ def main():
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
-                'first_layer': 'bf16 x 3 piece triples (v_mfma_f32_16x16x32_bf16)' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
+                'first_layer': 'bf16 x 3 piece triples, K-packed: 4 x v_mfma_f32_16x16x32_bf16 per tile' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
                 'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
