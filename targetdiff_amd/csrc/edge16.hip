@@ -364,7 +364,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 constexpr int E16Q_GLOBAL_CS_U4 = 512 + 512 + 256 + 512;
 template <int PK> constexpr int e16q_cs_u4() { return PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256; }
 template <int PK> constexpr int e16q_u4() { return PK == 3 ? 2 * e16q_cs_u4<2>() + 2 * e16q_cs_u4<1>() : 4 * e16q_cs_u4<PK>(); }   // all four (dst class, source class) tables
-template <int PK> constexpr int e16q_half_u4() { return 2 * e16q_cs_u4<PK>(); }      // one destination class
+template <int PK> constexpr int e16q_half_u4() { return PK == 4 ? e16q_cs_u4<2>() + e16q_cs_u4<1>() : 2 * e16q_cs_u4<PK>(); }      // one destination class
 // stage `ncs` consecutive (dst class, source class) tables from the packed blob into LDS (all waves of the workgroup; the caller's
 // barrier publishes them)
 template <int PK>
@@ -574,6 +574,12 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             static_assert(PK != 3 || !ONE_CLASS, "PK = 3 holds both destination classes");
             if (cls) td_pk4_tiles<1, AH, NEB>(Rp + 2 * e16q_cs_u4<2>() + (size_t)sl * e16q_cs_u4<1>() + lane, lane, bq, acc);
             else td_pk4_tiles<2, AH, NEB>(Rp + (size_t)sl * e16q_cs_u4<2>() + lane, lane, bq, acc);
+        } else if constexpr (PK == 4) {
+            // one destination class resident (12-wave value pass): its ligand-source table (mixed rows only) in the 40-byte form, its
+            // protein-source table in the 48-byte form -- 44 KiB
+            static_assert(PK != 4 || ONE_CLASS, "PK = 4 holds one destination class");
+            if (sl) td_pk4_tiles<1, AH, NEB>(Rp + e16q_cs_u4<2>() + lane, lane, bq, acc);
+            else td_pk4_tiles<2, AH, NEB>(Rp + lane, lane, bq, acc);
         } else
             td_pk4_tiles<PK, AH, NEB>(Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane, lane, bq, acc);
     };
@@ -1511,7 +1517,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 const float4 o0 = op[0], o1 = op[1];
                 offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
             }
-            td_first_layer_split16<false, true, true, 2, false, TD_VALUE_PK, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+            // (P_i joins before the products on the default graph, as in edge_value16t_kernel -- the same bits whichever kernel the row
+            // distribution setting selects; the chunked instantiation hides the P_i loads behind the products instead)
+            td_first_layer_split16<false, true, CHUNKED, 2, false, TD_VALUE_PK, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
@@ -1616,6 +1624,174 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         }
     }
     trace_end();
+}
+
+// ---- the x2h value pass of the default graph at THREE waves per SIMD (round 5) ------------------------------------------------------
+// bf16 first layer, 32-slot rows, rows handed out through the LDS ticket (edge_row_dealing = 2: the default).  Against
+// edge_value16_kernel: no software pipeline across rows (a row's gathers are hidden by the two other waves of its SIMD, as in the key
+// pass), ONE flip tile per wave (the LDS operations of a wave execute in order: the store of block hb + 1 cannot overtake the reads of
+// block hb), the destination class's ligand-source table in the 40-byte form and its protein-source table -- the one every row uses -- in
+// the 48-byte form (PK = 4, 44 KiB): 166 registers, 12 waves x 4.1 KiB of scratch + 44 + 64 KiB of tables = 159.4 KiB.  Same products in
+// the same order per accumulator as the 8-wave kernel: bit-identical h.  Measured in one call, C2: 1.609 -> 1.525 ms per step; the
+// wave count matters (10 / 11 / 12 waves at 40-byte tables: 1.676 / 1.642 / 1.606) and so does the fourth table read (10 waves, 48 vs
+// 40 bytes: 1.589 vs 1.676).
+constexpr int V16T_WAVES = 12;
+constexpr int V16T_PK = 4;
+constexpr int V16T_AH = -1;                               // table quads one quad ahead (td_pk4_tiles)
+constexpr int V16T_WAVE_FLOATS = 8 * V16_ZB_STRIDE;       // 1056 floats: the Zbar half (8 heads x 132) >= one flip tile (704)
+constexpr int V16T_SB_FLOATS = 16;
+constexpr size_t V16T_LDS_BYTES =
+    (size_t)(e16q_half_u4<V16T_PK>() * 4 + V16_W_FLOATS + V16T_WAVES * V16T_WAVE_FLOATS + V16T_WAVES * V16T_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
+static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
+
+__global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
+    constexpr int WAVES = V16T_WAVES;
+    constexpr int RF = e16q_half_u4<V16T_PK>() * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float4 *Wv = reinterpret_cast<const float4 *>(lds + RF);          // [kq 32][n 128] x 4 k
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = lane & 15, g = lane >> 4;
+    float *TB = lds + RF + V16_W_FLOATS + wid * V16T_WAVE_FLOATS;            // wave-private scratch
+    float *SB = lds + RF + V16_W_FLOATS + WAVES * V16T_WAVE_FLOATS + wid * V16T_SB_FLOATS;
+    float *B2 = lds + RF + V16_W_FLOATS + WAVES * V16T_WAVE_FLOATS + WAVES * V16T_SB_FLOATS;
+    const float *KB = B2 + TD_H;
+    // workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0): as in edge_value16_kernel
+    int my_cls = 1, GL = 0;
+    const int64_t n_rows = a.count_ptr ? (int64_t)*a.count_ptr : a.count;
+    {
+        const int64_t G = gridDim.x, nl = a.lig_count, np = n_rows > nl ? n_rows - nl : 0;
+        if (nl > 0) {
+            int64_t nm = a.mixed_count ? (int64_t)*a.mixed_count - nl : (np * 3) / 10;
+            nm = nm < 0 ? 0 : (nm > np ? np : nm);
+            const int64_t wl = TD_ROW_COST_MIXED * nl, wp = TD_ROW_COST_PURE * (np - nm) + TD_ROW_COST_MIXED * nm;
+            GL = (int)((wl * G + (wl + wp) / 2) / (wl + wp));
+            const int cap = (int)G - (np > 0 ? 1 : 0);
+            GL = GL < 1 ? 1 : (GL > cap ? cap : GL);
+        }
+        my_cls = (int)blockIdx.x >= (int)G - GL ? 0 : 1;
+    }
+    const int GP = gridDim.x - GL;
+    if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry
+    {
+        if constexpr (V16T_PK == 4) {
+            td_stage_pk4<2>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 1, tid, WAVES * 64);
+            td_stage_pk4<1>(a.mlp.R16q + (size_t)(my_cls * 2 + 1) * E16Q_GLOBAL_CS_U4 * 4, lds + e16q_cs_u4<2>() * 4, 1, tid, WAVES * 64);
+        } else
+            td_stage_pk4<V16T_PK>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 2, tid, WAVES * 64);
+        td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid, WAVES * 64);
+        if (tid < TD_H) B2[tid] = a.mlp.b2[tid];
+        else if (tid < 2 * TD_H) B2[tid] = a.mlp.beta[tid - TD_H];
+        else if (tid == 2 * TD_H) *reinterpret_cast<int *>(B2 + 2 * TD_H) = 0;
+        else if (tid >= 2 * TD_H + 32 && tid < 2 * TD_H + 64) {
+            const int s8 = tid - (2 * TD_H + 32);
+            B2[2 * TD_H + 4 + s8] = (s8 & 7) < 5 ? a.offsets[5 * (s8 >> 3) + (s8 & 7)] : TD_FAR_CENTRE;
+        }
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    // rows: protein workgroups take single rows dealt to the XCD's workgroups, through the workgroup's LDS ticket; the ligand workgroups
+    // static shares of the ligand row list
+    const int32_t *list = a.rows;
+    int64_t first, end, stride = 1;
+    if (my_cls) td_deal16(n_rows, 1, first, end, stride, GP, (int)blockIdx.x);
+    else {
+        list = a.lig_rows;
+        const int64_t per = (a.lig_count + GL - 1) / GL;
+        first = ((int)blockIdx.x - GP) * per;
+        end = first + per < a.lig_count ? first + per : a.lig_count;
+    }
+    int *row_ctr = reinterpret_cast<int *>(B2 + 2 * TD_H);
+    auto next_row = [&]() -> int64_t {
+        int n = 0;
+        if (lane == 0) n = __hip_atomic_fetch_add(row_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        n = __builtin_amdgcn_readfirstlane(n);
+        const int64_t itx = first + (int64_t)n * stride;
+        return itx < end ? (list ? (int64_t)list[itx] : itx) : -1;
+    };
+    for (int64_t i = next_row(); i >= 0; i = next_row()) {
+        RowIn16 rin;
+        td_row_index16(a, i, i, lane, rin);
+        // a protein workgroup meets the ligand rows of its share as candidates and drops them
+        if (((__builtin_amdgcn_readfirstlane(__float_as_int(rin.xi.w)) > __float_as_int(0.5f)) ? 0 : 1) != my_cls) continue;
+        floatx4_t acc[2][8];
+        td_row_gather16<false>(a, i, i, lane, rin, acc);
+        float al[8];
+        {   // A operand of the aggregation product: alpha[edge 8g + s][head lo]
+            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+            al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
+        }
+        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
+        Edge2 ed;
+        {
+            float offr[8];
+            int dep = 0;
+            asm volatile("" : "+v"(dep));
+            const float4 *op = reinterpret_cast<const float4 *>(B2 + 2 * TD_H + 4 + 8 * g + dep);
+            const float4 o0 = op[0], o1 = op[1];
+            offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
+            td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+        }
+        float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
+        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
+        if (lane < TD_HEADS) SB[lane] = ssum;
+        // Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time through the wave's flip tile
+        floatx4_t zb[8];
+        auto flip_store = [&](int hb) {
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb)
+                *reinterpret_cast<float4 *>(TB + td_tile_row16(16 * eb + lo) + 4 * g) =
+                    make_float4(acc[eb][hb][0], acc[eb][hb][1], acc[eb][hb][2], acc[eb][hb][3]);
+        };
+        auto flip_load = [&](float (&bv)[8]) {
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) bv[sx] = TB[td_tile_row16(8 * g + sx) + lo];
+        };
+        float bvb[2][8];
+        flip_store(0);
+        flip_load(bvb[0]);
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            if (hb + 1 < 8) {
+                flip_store(hb + 1);
+                flip_load(bvb[(hb + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) zb[hb] = td_mfma16(al[sx], bvb[hb & 1][sx], zb[hb]);
+        }
+        // out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs)
+        float *ZB = TB;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((g >> 1) == ph) {
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
+            }
+            const int n = 64 * ph + lane;
+            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
+            asm volatile("" : "+v"(zoff));
+            const float *zrow = lds + zoff;
+            float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll 8
+            for (int kq = 0; kq < 32; ++kq) {
+                const float4 w = Wv[kq * TD_H + n];
+                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
+                o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
+            }
+            o = (o + o1) + (o2 + o3);
+            if (a.out) a.out[(size_t)i * TD_H + n] = o;
+            else a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+        }
+    }
+    if (a.trace) {
+        td_trace_wave_end(a.trace, lane);
+        __syncthreads();
+        if (tid == 0) a.trace[8 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ================================================================================================ edge gate
@@ -1814,6 +1990,11 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
         } else if (gate_m) {
             TD_LDS_ONCE((edge_value16_kernel<true, false, true>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+        } else if (a.deal == 2) {          // (the default) rows through the LDS ticket: the 12-wave kernel
+            TD_LDS_ONCE((edge_value16t_kernel), V16T_LDS_BYTES);
+            int Gt = grid16(count, V16T_WAVES);
+            if (Gt < 2 && a.lig_count > 0) Gt = 2;
+            edge_value16t_kernel<<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
         } else {
             TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
