@@ -58,7 +58,7 @@ def main():
             t0 = st[on].min()
             busy = (en - st)[on]
             span = en[on].max() - t0
-            nw = 12 if p == 0 else 8
+            nw = 12 if p in (0, 1) else 8          # key and (round 5) value pass: 12 waves per workgroup; fused h2x: 8
             stage = (st - t[l, p, :, 4])[on]
             wmean = (en - t[l, p, :, 3] / nw)[on] / busy
             wfirst = (en - t[l, p, :, 2])[on] / busy
