@@ -20,7 +20,7 @@ rank per GPU over RCCL) every rank samples its own pocket replica -- pockets sha
 collective (scripts/batch_sample_diffusion.sh:15-20) -- so scaling is "weak".
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = edge_value16_kernel (x2h value pass; the key pass edge_key16_kernel is its twin and is
+  roofline     dominant kernel = edge_value16t_kernel (x2h value pass; the key pass edge_key16_kernel is its twin and is
                reported under roofline.key_pass);
                achieved = executed algorithmic FLOPs per launch (327,680 per dst node) / mean
                launch time from HIP events recorded on the launch stream inside the timed region;
@@ -55,7 +55,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: ~2.5 PFLOP/s dense bf16 (24
 # (csrc/edge16.hip td_pk4_tiles), all 32 slots of the row
 FIRST_LAYER_FLOP_BF16_EXECUTED = 4 * 2 * 32 * 128 * 32
 PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E ~ 8 TB/s
-# Dominant kernels: edge_value16_kernel (x2h value pass) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
+# Dominant kernels: edge_value16t_kernel (x2h value pass, default graph) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
 # identical for the two passes:
 #   executed  = 2 * (32*128*20 [radial/type first layer] + 128*128 [out = W2v Zbar | U_i = W2k^T q_i]
 #                    + 32*128*16 [Zbar = alpha^T z | logits = z U_i]) = 327,680
@@ -587,10 +587,10 @@ def main():
                 'share_of_step': (p['ms'] / prof_steps) / (sec_per_step * 1e3), 'profiled_steps': prof_steps}
 
     if default_graph:
-        vk, kk = (('edge_value16_kernel<true>', 'edge_key16_kernel<false, 12, 0, 0, true>') if split
+        vk, kk = (('edge_value16t_kernel<12 waves>', 'edge_key16_kernel<false, 12, 0, 0, true>') if split
                   else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, 0, false>'))
     else:
-        vk = 'edge_value16_ragged_kernel'
+        vk = 'edge_value16_kernel<true, true> (chunk-walking)'
         kk = 'edge_key16_kernel<false, 12, 0, 1, true>' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
