@@ -32,7 +32,7 @@ def main():
     from targetdiff_amd import capi
     tag = capi.build_tag()          # the PMC passes and this script run in one gpurun call, on the same library file
     # x2h stage instantiations: value pass; key pass tagged STAGE = 0, not RAW
-    picks = {f'traffic_x2h_value{suffix}.json': [k for k in kernels if k.startswith('edge_value16')]          # edge_value16t_kernel (12 waves) / edge_value16_kernel<..>,
+    picks = {f'traffic_x2h_value{suffix}.json': [k for k in kernels if k.startswith('edge_value16')],     # edge_value16t_kernel (12 waves) / edge_value16_kernel<..>
              f'traffic_x2h_key{suffix}.json': [k for k in kernels if re.match(r'edge_key16_kernel<false, \d+, 0', k)]}
     for fname, names in picks.items():
         if not names:
