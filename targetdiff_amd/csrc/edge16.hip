@@ -337,8 +337,9 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
 // Both operands as exact bf16 piece triples (the table pre-split at pack time, the per-edge Gaussians split in registers),
 // 6 of the 9 piece products, fp32 accumulation: fp32-equivalent (the dropped products are ~2^-24 relative, the size of one fp32
 // rounding; the measured errors against the reference goldens are unchanged, profiles/*_split_error_table.txt).  One
-// instruction covers the whole K = 21 (20 Gaussians + the edge-type column; k = 8 g + j for lane group g, slot j) at half the
-// issue time of the six fp32 k-steps it replaces.  P_i joins the accumulator by vector adds (before or after the products).
+// instruction has 32 K slots; the six kept products of the 21 inputs (20 Gaussians + the edge-type column) are K-PACKED into four
+// instructions per tile (td_pk4_bquads / td_pk4_tiles below; round 4 spent six, one per product, with 11 of every 32 slots empty).
+// P_i joins the accumulator by vector adds (before or after the products).
 typedef __bf16 bf16x8_16 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ floatx4_t td_mfma16b(uint4 a, uint4 b, floatx4_t c) {
@@ -1200,8 +1201,8 @@ constexpr size_t V16S_LDS_BYTES =
     (size_t)(e16q_half_u4<TD_VALUE_PK>() * 4 + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
 static_assert(V16S_LDS_BYTES <= 160 * 1024, "value pass: LDS");
 
-// SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the piece table
-// (36 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
+// SPLIT = true: the first layer on bf16 piece triples.  LDS has room for one destination class of the K-packed piece table
+// (48 KiB), so the workgroups of a launch specialise: the last GL stage the ligand-destination half and walk the ligand
 // rows (a.lig_rows: every ligand atom; the row lists of a forward pass / sampling step always contain them all), 8
 // neighbouring ligand rows at a time per workgroup; the others stage the protein half and walk the protein rows of their
 // contiguous share of the row list.  GL is chosen inside the kernel from the list's length (device-side in a session) and
@@ -1797,9 +1798,10 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
 // ================================================================================================ edge gate
 // e_w = sigmoid(MLP(20 -> 128 -> 1)(GaussianSmearing(dist)))  (models/uni_transformer.py:312-316): the attention passes' tile
 // layout with a bias instead of the node projections and a 128-wide dot product instead of the second product.  One wave per
-// 32-slot row (a dst node, or a chunk of a node's in-edges on general graphs), first layer on bf16 piece triples (the 18 KiB
-// piece table, bias, LayerNorm affine and output weights in LDS), LayerNorm + ReLU in the transposed layout, then each lane
+// 32-slot row (a dst node, or a chunk of a node's in-edges on general graphs), first layer on bf16 piece triples (the 24 KiB
+// K-packed table, bias, LayerNorm affine and output weights in LDS), LayerNorm + ReLU in the transposed layout, then each lane
 // dots its 32 hidden units of an edge with w3 and the four lane groups add up.
+constexpr int TD_GATE_WGS = 1024;   // four 4-wave workgroups per CU (110 VGPRs, 25.5 KiB LDS each): gate 0.043 -> 0.038 ms per C2 step against three
 constexpr int G16_WAVES = 4;        // three 4-wave workgroups per CU
 constexpr int G16Q_U4 = e16q_cs_u4<1>();                                // the gate's K-packed table (QA, QB, QC): 24 KiB
 constexpr size_t G16_LDS_BYTES = (size_t)G16Q_U4 * 16 + (size_t)3 * TD_H * sizeof(float);
@@ -2046,7 +2048,7 @@ int td_launch_gate16(const TdGate &g, const float4 *x4, const int32_t *nbr, int6
     if (N == 0) return TD_OK;
     TD_LDS_ONCE((edge_gate16_kernel), G16_LDS_BYTES);
     int64_t G = (N + G16_WAVES - 1) / G16_WAVES;
-    if (G > 768) G = 768;              // three workgroups per CU
+    if (G > TD_GATE_WGS) G = TD_GATE_WGS;              // workgroups per CU x 256
     edge_gate16_kernel<<<dim3((unsigned)G), dim3(G16_WAVES * 64), G16_LDS_BYTES, s>>>(g, x4, nbr, N, rows, count_ptr, chunk_node, ew);
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
