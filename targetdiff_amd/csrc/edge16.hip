@@ -1185,16 +1185,51 @@ constexpr int V16_WAVES = 8;
 #ifndef TD_VALUE_PK
 #define TD_VALUE_PK 1          // K-packed first layer with QC in LDS (48 bytes per lane and hidden block: the value pass has the room)
 #endif
-constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // W2vK[kq][n][4]
+constexpr int V16_W_FLOATS = 32 * TD_H * 4;               // Wt[d][kq][head][4] (pack.cpp, td_value_out16)
 constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidden + 4]
-constexpr int V16_ZB_STRIDE = 132;
 // Rows 8g .. 8g + 7 of a tile are read by lane group g (ds_read_b32, hidden column lo): with any 16-byte-aligned row stride 8 rows
 // are a multiple of 32 banks, i.e. groups 0 and 1 (and 2, 3) of a half-wave collide two-way (PMC: 10 % conflict cycles).  16 floats of
 // padding after every 8 rows put the odd groups on the other 16 banks.
 constexpr int V16_TILE_FLOATS = 32 * V16_TB_STRIDE + 4 * 16;
 __device__ __forceinline__ int td_tile_row16(int e) { return e * V16_TB_STRIDE + (e >> 3) * 16; }
-constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // 1408 >= 8 * 132: two transpose tiles, later the Zbar half
+constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // two transpose tiles
 constexpr int V16_SB_FLOATS = 48;                         // per wave: S[16 heads] + the 32 edges' 1 / sigma (td_ln_relu16) on their way to the A operand
+// ---- out[n] = W2v[n, :] . Zbar[head(n), :] (n = 8 head + d), the value pass's per-row output product ------------------------------------
+// The aggregation product runs with z as the A operand, so the accumulators hold Zbar^T: zt[hb][r] = Zbar[head lo][hidden 16hb + 4g + r].
+// A lane then owns 32 of its head's 128 Zbar values and needs no exchange through LDS (the form with Zbar in the accumulator rows wrote it
+// out and read every head's row back: 64 ds_write_b32 + 64 ds_read_b128 per row, a quarter of the pass's LDS instructions): eight partial
+// dot products, one per d, against Wt[d][kq = 4hb + g][head lo] (float4 over r; byte address = 16 lane + 8192 d + 1024 hb, conflict-free,
+// one address register), then the four lane groups' partial sums meet in two swap + add steps that transpose on the way:
+// lane (lo, g) ends with the outputs d0 = 2 (g & 1) + (g >> 1) and d0 + 4 of head lo (td_value_out_index16).
+// The order of the sums is fixed here for every value kernel: the row distribution settings select different kernels and stay bit-identical.
+__device__ __forceinline__ int td_value_out_index16(int lo, int g) { return 8 * lo + 2 * (g & 1) + (g >> 1); }
+__device__ __forceinline__ void td_value_out16(const floatx4_t (&zt)[8], const float *Wt_lane, float &o0, float &o1) {
+    const float4 *W = reinterpret_cast<const float4 *>(Wt_lane);          // this lane's column: &Wt[0][g][lo]
+    float p[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) p[d] = 0.f;
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) {
+        float4 w[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) w[d] = W[d * 512 + hb * 64];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            p[d] = fmaf(w[d].x, zt[hb][0], p[d]); p[d] = fmaf(w[d].y, zt[hb][1], p[d]);
+            p[d] = fmaf(w[d].z, zt[hb][2], p[d]); p[d] = fmaf(w[d].w, zt[hb][3], p[d]);
+        }
+    }
+    // lanes 32 .. 63 of p[2m] <-> lanes 0 .. 31 of p[2m + 1]: p[2m] + p[2m + 1] = output 2m + (g >> 1) summed over the groups g, g ^ 2
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
+                 : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+    float s0 = p[0] + p[1], s1 = p[2] + p[3], s2 = p[4] + p[5], s3 = p[6] + p[7];
+    // rows 1, 3 of s[2q] <-> rows 0, 2 of s[2q + 1]: s[2q] + s[2q + 1] = output 4q + 2 (g & 1) + (g >> 1), all four groups in
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+    o0 = s0 + s1;
+    o1 = s2 + s3;
+}
+
 constexpr size_t V16_LDS_BYTES =
     (size_t)(E16_R_FLOATS + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS + 2 * TD_H + 4) * sizeof(float);
 constexpr size_t V16S_LDS_BYTES =
@@ -1226,9 +1261,13 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
-    const float4 *Wv = reinterpret_cast<const float4 *>(lds + RF);          // [kq 32][n 128] x 4 k
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
     const int lo = lane & 15, g = lane >> 4;
+    const int nout = td_value_out_index16(lo, g);         // this lane's outputs: nout, nout + 4
+    // (opaque: as a compile-time constant the table's offset is folded into the immediates of the 64 reads and no longer fits their 16 bits)
+    int woff = RF + 4 * lane;
+    asm volatile("" : "+v"(woff));
+    const float *Wt_lane = lds + woff;
     float *TB = lds + RF + V16_W_FLOATS + wid * V16_WAVE_FLOATS;             // wave-private scratch
     float *SB = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + wid * V16_SB_FLOATS, *RS = SB + 16;
     float *B2 = lds + RF + V16_W_FLOATS + V16_WAVES * V16_WAVE_FLOATS + V16_WAVES * V16_SB_FLOATS;
@@ -1360,8 +1399,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         const float *ap = a.alpha + ((size_t)cx * TD_HEADS + lo) * TD_K + 8 * g;
         const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
         alx[0] = v0.x; alx[1] = v0.y; alx[2] = v0.z; alx[3] = v0.w; alx[4] = v1.x; alx[5] = v1.y; alx[6] = v1.z; alx[7] = v1.w;
-        h0 = a.h[(size_t)ix * TD_H + lane];
-        h1 = a.h[(size_t)ix * TD_H + 64 + lane];
+        h0 = a.h[(size_t)ix * TD_H + nout];
+        h1 = a.h[(size_t)ix * TD_H + nout + 4];
     };
     // General graphs: the protein workgroups of a graph whose protein rows are one chunk wide (`hybrid`: plain k-NN rows, k <= 32)
     // take the software-pipelined single-chunk loop below (chunk index through cptr); everything else walks chunks here.
@@ -1369,7 +1408,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         for (int64_t i = next_row(); i >= 0; i = next_row()) {
             if (SPLIT && dyn && !of_class(a.x4[i])) continue;
             const int c0 = __builtin_amdgcn_readfirstlane(a.cptr[i]), c1 = __builtin_amdgcn_readfirstlane(a.cptr[i + 1]);
-            const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
+            const float hres0 = a.h[(size_t)i * TD_H + nout], hres1 = a.h[(size_t)i * TD_H + nout + 4];
             floatx4_t zb[8];
 #pragma unroll
             for (int hb = 0; hb < 8; ++hb) zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -1435,7 +1474,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int sx = 0; sx < NS; ++sx) zb[hb] = td_mfma16(al[sx], bvb[hb & 1][sx], zb[hb]);
+                        for (int sx = 0; sx < NS; ++sx) zb[hb] = td_mfma16(bvb[hb & 1][sx], al[sx], zb[hb]);
                     }
                 };
                 bool full = true;
@@ -1443,34 +1482,17 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 if (full) chunk_body(std::true_type());
                 else chunk_body(std::false_type());
             }
-            const float ssum = td_sum_groups(asum);
-            if (lane < TD_HEADS) SB[lane] = ssum;
-            float *ZB = TB;
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph) {
-                if ((g >> 1) == ph) {
-#pragma unroll
-                    for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
-                }
-                const int n = 64 * ph + lane;
-                // (the wave's tile sits above 64 KiB: as a compile-time constant the offset does not fit the 16-bit field of ds_read and
-            // every one of the 32 reads of a phase got its own v_add_u32 -- opaque, it is one base register + small immediates)
-            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
-            asm volatile("" : "+v"(zoff));
-            const float *zrow = lds + zoff;
-                // four independent chains (one per k mod 4): a single accumulator makes the 128 FMAs of a phase one dependent chain
-                float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
-#pragma unroll 8
-                for (int kq = 0; kq < 32; ++kq) {
-                    const float4 w = Wv[kq * TD_H + n];
-                    const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                    o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
-                }
-                o = (o + o1) + (o2 + o3);
-                if (a.out) a.out[(size_t)i * TD_H + n] = o;
-                else a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+            const float ssum = td_sum_groups(asum);          // S[head lo] over the node's chunks, in every lane group
+            float o0, o1;
+            td_value_out16(zb, Wt_lane, o0, o1);
+            o0 = fmaf(B2[nout], ssum, o0);
+            o1 = fmaf(B2[nout + 4], ssum, o1);
+            if (a.out) {
+                a.out[(size_t)i * TD_H + nout] = o0;
+                a.out[(size_t)i * TD_H + nout + 4] = o1;
+            } else {
+                a.h[(size_t)i * TD_H + nout] = hres0 + o0;
+                a.h[(size_t)i * TD_H + nout + 4] = hres1 + o1;
             }
         }
         trace_end();
@@ -1543,8 +1565,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             scale_edges(al, gm[0], gm[1]);
         }
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
-        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
-        if (lane < TD_HEADS) SB[lane] = ssum;
+        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges, in every lane group
 
         // ---- Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time: flip z^T (lane = edge) through
         //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
@@ -1576,7 +1597,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             __builtin_amdgcn_sched_barrier(0);
             zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(al[s], bvb[hb & 1][s], zb[hb]);
+            for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(bvb[hb & 1][s], al[s], zb[hb]);
         }
 
         // ---- next row: gathers into the (now free) accumulators, its alpha fragment and residual ---------------------
@@ -1594,34 +1615,17 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         }
         i = inext;
 
-        // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs) -------
-        // zb[hb][r] = Zbar[head 4g + r][hidden 16hb + lo]; heads 8ph .. 8ph+7 sit in lane groups g = 2ph, 2ph + 1
-        float *ZB = TB;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            if ((g >> 1) == ph) {
-#pragma unroll
-                for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
-            }
-            const int n = 64 * ph + lane;
-            // (the wave's tile sits above 64 KiB: as a compile-time constant the offset does not fit the 16-bit field of ds_read and
-            // every one of the 32 reads of a phase got its own v_add_u32 -- opaque, it is one base register + small immediates)
-            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
-            asm volatile("" : "+v"(zoff));
-            const float *zrow = lds + zoff;
-            // four independent chains (one per k mod 4): a single accumulator makes the 128 FMAs of a phase one dependent chain
-            float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
-#pragma unroll 8
-            for (int kq = 0; kq < 32; ++kq) {
-                const float4 w = Wv[kq * TD_H + n];
-                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
-            }
-            o = (o + o1) + (o2 + o3);
-            if (a.out) a.out[(size_t)icur * TD_H + n] = o;
-            else a.h[(size_t)icur * TD_H + n] = (ph == 0 ? hcur0 : hcur1) + o;
+        // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (td_value_out16: outputs nout, nout + 4) -------
+        float o0, o1;
+        td_value_out16(zb, Wt_lane, o0, o1);
+        o0 = fmaf(B2[nout], ssum, o0);
+        o1 = fmaf(B2[nout + 4], ssum, o1);
+        if (a.out) {
+            a.out[(size_t)icur * TD_H + nout] = o0;
+            a.out[(size_t)icur * TD_H + nout + 4] = o1;
+        } else {
+            a.h[(size_t)icur * TD_H + nout] = hcur0 + o0;
+            a.h[(size_t)icur * TD_H + nout + 4] = hcur1 + o1;
         }
     }
     trace_end();
@@ -1630,31 +1634,34 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 // ---- the x2h value pass of the default graph at THREE waves per SIMD (round 5) ------------------------------------------------------
 // bf16 first layer, 32-slot rows, rows handed out through the LDS ticket (edge_row_dealing = 2: the default).  Against
 // edge_value16_kernel: no software pipeline across rows (a row's gathers are hidden by the two other waves of its SIMD, as in the key
-// pass), ONE flip tile per wave (the LDS operations of a wave execute in order: the store of block hb + 1 cannot overtake the reads of
-// block hb), the destination class's ligand-source table in the 40-byte form and its protein-source table -- the one every row uses -- in
-// the 48-byte form (PK = 4, 44 KiB): 166 registers, 12 waves x 4.1 KiB of scratch + 44 + 64 KiB of tables = 159.4 KiB.  Same products in
-// the same order per accumulator as the 8-wave kernel: bit-identical h.  Measured in one call, C2: 1.609 -> 1.525 ms per step; the
-// wave count matters (10 / 11 / 12 waves at 40-byte tables: 1.676 / 1.642 / 1.606) and so does the fourth table read (10 waves, 48 vs
-// 40 bytes: 1.589 vs 1.676).
+// pass) and ONE flip tile per wave (the LDS operations of a wave execute in order: the store of block hb + 1 cannot overtake the reads of
+// block hb).  Same products in the same order per accumulator as the 8-wave kernel: bit-identical h.  Measured in one call each, C2 value
+// pass per step: 8-wave pipelined 1.609 -> 12 waves 1.525 (10 / 11 / 12 waves: 1.676 / 1.642 / 1.606, every wave counts) -> output
+// product without the Zbar exchange (td_value_out16) 1.508 -> 1.440 -> with the 16.5 KiB of scratch that freed, both source-class tables
+// of the workgroup's destination class in the 48-byte form (PK = 1: three 16-byte reads per hidden block) 1.397.  156 registers,
+// 48 + 64 KiB of tables + 12 x 2.75 KiB of scratch = 146.4 KiB.  (Table quads a pair ahead -- 164 registers -- changes nothing: 1.395.)
 constexpr int V16T_WAVES = 12;
-constexpr int V16T_PK = 4;
-constexpr int V16T_AH = -1;                               // table quads one quad ahead (td_pk4_tiles)
-constexpr int V16T_WAVE_FLOATS = 8 * V16_ZB_STRIDE;       // 1056 floats: the Zbar half (8 heads x 132) >= one flip tile (704)
-constexpr int V16T_SB_FLOATS = 16;
+#ifndef TD_VALUET_PK
+#define TD_VALUET_PK 1
+#endif
+constexpr int V16T_PK = TD_VALUET_PK;
+#ifndef TD_VALUET_AH
+#define TD_VALUET_AH -1
+#endif
+constexpr int V16T_AH = TD_VALUET_AH;                               // table quads one quad ahead (td_pk4_tiles)
+constexpr int V16T_WAVE_FLOATS = V16_TILE_FLOATS;         // 704 floats: one flip tile
 constexpr size_t V16T_LDS_BYTES =
-    (size_t)(e16q_half_u4<V16T_PK>() * 4 + V16_W_FLOATS + V16T_WAVES * V16T_WAVE_FLOATS + V16T_WAVES * V16T_SB_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
+    (size_t)(e16q_half_u4<V16T_PK>() * 4 + V16_W_FLOATS + V16T_WAVES * V16T_WAVE_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
 static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
 
 __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
     constexpr int WAVES = V16T_WAVES;
     constexpr int RF = e16q_half_u4<V16T_PK>() * 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const float4 *Wv = reinterpret_cast<const float4 *>(lds + RF);          // [kq 32][n 128] x 4 k
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
     const int lo = lane & 15, g = lane >> 4;
     float *TB = lds + RF + V16_W_FLOATS + wid * V16T_WAVE_FLOATS;            // wave-private scratch
-    float *SB = lds + RF + V16_W_FLOATS + WAVES * V16T_WAVE_FLOATS + wid * V16T_SB_FLOATS;
-    float *B2 = lds + RF + V16_W_FLOATS + WAVES * V16T_WAVE_FLOATS + WAVES * V16T_SB_FLOATS;
+    float *B2 = lds + RF + V16_W_FLOATS + WAVES * V16T_WAVE_FLOATS;
     const float *KB = B2 + TD_H;
     // workgroups [0, GP) serve the protein rows (class 1), [GP, gridDim.x) the ligand rows (class 0): as in edge_value16_kernel
     int my_cls = 1, GL = 0;
@@ -1709,6 +1716,11 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         const int64_t itx = first + (int64_t)n * stride;
         return itx < end ? (list ? (int64_t)list[itx] : itx) : -1;
     };
+    const int nout = td_value_out_index16(lo, g);
+    // (opaque: as a compile-time constant the table's offset is folded into the immediates of the 64 reads and no longer fits their 16 bits)
+    int woff = RF + 4 * lane;
+    asm volatile("" : "+v"(woff));
+    const float *Wt_lane = lds + woff;
     for (int64_t i = next_row(); i >= 0; i = next_row()) {
         RowIn16 rin;
         td_row_index16(a, i, i, lane, rin);
@@ -1722,7 +1734,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
             al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
         }
-        const float hres0 = a.h[(size_t)i * TD_H + lane], hres1 = a.h[(size_t)i * TD_H + 64 + lane];
+        const float hres0 = a.h[(size_t)i * TD_H + nout], hres1 = a.h[(size_t)i * TD_H + nout + 4];
         Edge2 ed;
         {
             float offr[8];
@@ -1734,9 +1746,8 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
-        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges
-        if (lane < TD_HEADS) SB[lane] = ssum;
-        // Zbar[head][k] = sum_e alpha[e][head] z[e][k], one hidden block at a time through the wave's flip tile
+        ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges, in every lane group
+        // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
         floatx4_t zb[8];
         auto flip_store = [&](int hb) {
 #pragma unroll
@@ -1760,32 +1771,19 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             __builtin_amdgcn_sched_barrier(0);
             zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int sx = 0; sx < 8; ++sx) zb[hb] = td_mfma16(al[sx], bvb[hb & 1][sx], zb[hb]);
+            for (int sx = 0; sx < 8; ++sx) zb[hb] = td_mfma16(bvb[hb & 1][sx], al[sx], zb[hb]);
         }
-        // out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (two halves of 64 outputs)
-        float *ZB = TB;
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            if ((g >> 1) == ph) {
-#pragma unroll
-                for (int hb = 0; hb < 8; ++hb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ZB[(4 * (g & 1) + r) * V16_ZB_STRIDE + 16 * hb + lo] = zb[hb][r];
-            }
-            const int n = 64 * ph + lane;
-            int zoff = (int)(ZB - lds) + (lane >> 3) * V16_ZB_STRIDE;
-            asm volatile("" : "+v"(zoff));
-            const float *zrow = lds + zoff;
-            float o = B2[n] * SB[8 * ph + (lane >> 3)], o1 = 0.f, o2 = 0.f, o3 = 0.f;
-#pragma unroll 8
-            for (int kq = 0; kq < 32; ++kq) {
-                const float4 w = Wv[kq * TD_H + n];
-                const float4 z = *reinterpret_cast<const float4 *>(zrow + 4 * kq);
-                o = fmaf(w.x, z.x, o); o1 = fmaf(w.y, z.y, o1); o2 = fmaf(w.z, z.z, o2); o3 = fmaf(w.w, z.w, o3);
-            }
-            o = (o + o1) + (o2 + o3);
-            if (a.out) a.out[(size_t)i * TD_H + n] = o;
-            else a.h[(size_t)i * TD_H + n] = (ph == 0 ? hres0 : hres1) + o;
+        // out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (td_value_out16: this lane's outputs nout, nout + 4)
+        float o0, o1;
+        td_value_out16(zb, Wt_lane, o0, o1);
+        o0 = fmaf(B2[nout], ssum, o0);
+        o1 = fmaf(B2[nout + 4], ssum, o1);
+        if (a.out) {
+            a.out[(size_t)i * TD_H + nout] = o0;
+            a.out[(size_t)i * TD_H + nout + 4] = o1;
+        } else {
+            a.h[(size_t)i * TD_H + nout] = hres0 + o0;
+            a.h[(size_t)i * TD_H + nout + 4] = hres1 + o1;
         }
     }
     if (a.trace) {

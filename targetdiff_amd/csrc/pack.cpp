@@ -269,12 +269,14 @@ EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, 
                             q16[(((((size_t)hb * 4 + r) * 2 + jq) * 64 + lane) * 4) + jj] =
                                 m.w3[(size_t)(8 * head + 4 * jq + jj) * TD_H + k];
                         }
-    } else if (alt == 2) {   // value MLP of x2h: W2vK[k/4][n][k%4]
+    } else if (alt == 2) {   // value MLP of x2h: Wt[d][k/4][head][k%4] = W2v[8 head + d][k] (td_value_out16: a lane reads 16 bytes at 16 lane + 8192 d + 1024 hb)
         o.Walt = pk.alloc((size_t)32 * TD_H * 4);
         float *q = pk.data.data() + o.Walt;
-        for (int kq = 0; kq < 32; ++kq)
-            for (int n = 0; n < TD_H; ++n)
-                for (int kk = 0; kk < 4; ++kk) q[((size_t)kq * TD_H + n) * 4 + kk] = m.w3[(size_t)n * TD_H + 4 * kq + kk];
+        for (int d = 0; d < 8; ++d)
+            for (int kq = 0; kq < 32; ++kq)
+                for (int head = 0; head < TD_HEADS; ++head)
+                    for (int kk = 0; kk < 4; ++kk)
+                        q[((((size_t)d * 32 + kq) * TD_HEADS + head) * 4) + kk] = m.w3[(size_t)(8 * head + d) * TD_H + 4 * kq + kk];
     }
     return o;
 }

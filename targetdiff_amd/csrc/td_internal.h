@@ -59,7 +59,7 @@ struct TdEdgeMlp {
     const float *b2;       // [128] or [16]
     const float *R16;      // [2 dst class][2 slot][6 kstep][64 lane][8 hidden block]  radial/type table for 16x16x4 tiles
     const float *Walt16;   // key MLPs: Wq16[hb][r][jq][lane][4] = W2[8 lo + 4jq + jj][16hb + 4g + r]
-    const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: W2vK[k/4][n][4]
+    const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: Wt[d][k/4][head][4] = W2v[8 head + d][k]
     const float *R16q;     // the radial/type table as exact bf16 piece triples, K-packed for four v_mfma_f32_16x16x32_bf16 per tile
                            // (pack_pk4_table, pack.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
