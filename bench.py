@@ -233,9 +233,12 @@ F_ALG_PER_NODE = 39.35e6                             # can
 F_REDUCED_PER_NODE = 24.5e6                          # same, h2x on ligand dst rows only (section 8d, last bullet)
 
 
-def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows):
+def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows, key_row=KEY_PASS_FLOP_EXECUTED, val_row=KEY_PASS_FLOP_EXECUTED,
+                            chunks=1):
     """FLOPs the launched kernels execute in one denoiser step, from the rows every launch processes (the same row lists
-    run_backbone in csrc/plan.cpp walks).  Stateless forward: every layer runs on every row."""
+    run_backbone in csrc/plan.cpp walks).  Stateless forward: every layer runs on every row.  General graphs: `key_row` / `val_row` =
+    the attention passes' FLOPs per dst row (all its chunks), `chunks` = chunks per row for the gate and the h2x stage; the node
+    projections do not depend on the fan-in."""
     N, Nl, L = n_nodes, n_lig, n_layers
     if session_rows is None:
         x2h_rows = [N] * L
@@ -255,12 +258,12 @@ def executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows):
             proj_rows.append(lvl(e + 2))
         hop1 = lvl(1)
         gate_rows = session_rows['layer0_rows']
-    f = gate_rows * GATE_ROW + Nl * HEAD_ROW
+    f = gate_rows * GATE_ROW * chunks + Nl * HEAD_ROW
     for l in range(L):
         f += proj_rows[l] * 6 * GEMM128                    # k_i, k_j, v_i, v_j, q.net.0, q.net.3
-        f += x2h_rows[l] * 2 * KEY_PASS_FLOP_EXECUTED      # key pass + value pass
+        f += x2h_rows[l] * (key_row + val_row)             # key pass + value pass
         f += hop1 * 2 * GEMM128 + Nl * 4 * GEMM128         # h2x stage: k_j, v_j on the hop rows; k_i, v_i, q.net.0/3 on ligand rows
-        f += Nl * H2X_ROW
+        f += Nl * H2X_ROW * chunks
     return float(f)
 
 
@@ -535,7 +538,10 @@ def main():
     fan_in = args.cap if args.cutoff_mode == 'radius' else args.knn
     cpn = (fan_in + 31) // 32
     flop_key = cpn * KEY_PASS_FLOP_EXECUTED
-    flop_val = cpn * (KEY_PASS_FLOP_EXECUTED - 2 * 128 * 128) + 2 * 128 * 128
+    # (the value pass runs a chunk whose second 16-slot block is all padding -- slots 48 .. 63 at k = 48 -- on its first block only)
+    last = fan_in - 32 * (cpn - 1)
+    slots_val = 32 * (cpn - 1) + (16 if (cpn > 1 and last <= 16 and args.cutoff_mode == 'knn') else 32)
+    flop_val = 2 * (slots_val * 128 * 20 + slots_val * 128 * 16) + 2 * 128 * 128
     split = bool(model._native(dev).get_option('edge_key_split'))
 
     def pass_roofline(cls, kernel, traffic_file):
@@ -597,9 +603,10 @@ def main():
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
     # whole step: FLOPs the launched kernels execute (from the row lists) against the fp32 peak, next to SURVEY 8d's algorithmic
     # figures (which count work the session provably does not need to do: fractions above 1 there only say the eliminations are real)
-    f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows if default_graph else None)
-    if not default_graph:       # per-chunk work scales with the chunks per row (uniform for k-NN / radius; hybrid: protein rows)
-        f_exec *= cpn
+    if default_graph:
+        f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, session_rows)
+    else:                       # per-chunk work scales with the chunks per row (uniform for k-NN / radius; hybrid: the protein rows' count)
+        f_exec = executed_flops_per_step(n_nodes, n_lig, n_layers, None, flop_key, flop_val, cpn)
     if fan_in < 32:             # fewer edges per row: scale the per-edge share (about 80 % of a row's FLOPs) -- an estimate
         f_exec *= 0.2 + 0.8 * fan_in / 32.0
     whole_step = {'executed_flop': f_exec, 'executed_tflops': f_exec / sec_per_step / 1e12,
