@@ -73,5 +73,20 @@ def main():
                       '  '.join(f'{b[x:232:8].mean():.0f}/{b[x:232:8].max():.0f}' for x in range(8)))
 
 
+    # boundaries: last workgroup end of a launch -> first workgroup entry of the next traced launch of the layer
+    print('# boundaries (us): key end -> value entry | value end -> h2x entry (node projections in between) | h2x end -> next key entry')
+    def first_entry(l, p):
+        on = t[l, p, :, 1] > 0
+        return t[l, p, :, 4][on].min() if on.any() else None
+    def last_end(l, p):
+        on = t[l, p, :, 1] > 0
+        return t[l, p, :, 1][on].max() if on.any() else None
+    for l in range(slots):
+        kv = first_entry(l, 1) - last_end(l, 0) if first_entry(l, 1) is not None and last_end(l, 0) is not None else float('nan')
+        vh = first_entry(l, 2) - last_end(l, 1) if first_entry(l, 2) is not None and last_end(l, 1) is not None else float('nan')
+        hk = (first_entry(l + 1, 0) - last_end(l, 2)) if l + 1 < slots and first_entry(l + 1, 0) is not None and last_end(l, 2) is not None else float('nan')
+        print(f'  layer {l}: {kv:7.2f} | {vh:7.2f} | {hk:7.2f}')
+
+
 if __name__ == '__main__':
     main()
