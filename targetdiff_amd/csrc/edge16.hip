@@ -289,7 +289,7 @@ __device__ __forceinline__ void td_first_layer_compute16(const Args16 &a, const 
         const float4 xj = r.xj[eb];
         if (LOAD_EW) ed.ew[eb] = r.ew[eb];
         const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
-        dist[eb] = sqrtf(rx * rx + ry * ry + rz * rz);
+        dist[eb] = td_sqrt_d2(rx * rx + ry * ry + rz * rz);
         ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
@@ -544,7 +544,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         const float4 xj = r.xj[eb];
         if (LOAD_EW) ed.ew[eb] = r.ew[eb];
         const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
-        const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+        const float dist = td_sqrt_d2(rx * rx + ry * ry + rz * rz);
         ed.rel[eb][0] = rx; ed.rel[eb][1] = ry; ed.rel[eb][2] = rz;
         slot[eb] = xj.w > 0.5f ? 0 : 1;
         has[0][eb] = __ballot(ed.valid[eb] && slot[eb] == 0) != 0ull;
@@ -1714,7 +1714,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         if (lane == 0) n = __hip_atomic_fetch_add(row_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         n = __builtin_amdgcn_readfirstlane(n);
         const int64_t itx = first + (int64_t)n * stride;
-        return itx < end ? (list ? (int64_t)list[itx] : itx) : -1;
+        return itx < end ? (int64_t)__builtin_amdgcn_readfirstlane((int)(list ? (int64_t)list[itx] : itx)) : -1;      // (wave-uniform, and said so)
     };
     const int nout = td_value_out_index16(lo, g);
     // (opaque: as a compile-time constant the table's offset is folded into the immediates of the 64 reads and no longer fits their 16 bits)
@@ -1844,7 +1844,7 @@ __global__ __launch_bounds__(G16_WAVES * 64) void edge_gate16_kernel(TdGate gt, 
             valid[eb] = jn[eb] >= 0;
             const float4 xj = x4[valid[eb] ? jn[eb] : (int)i];
             const float rx = xi.x - xj.x, ry = xi.y - xj.y, rz = xi.z - xj.z;
-            const float dist = sqrtf(rx * rx + ry * ry + rz * rz);
+            const float dist = td_sqrt_d2(rx * rx + ry * ry + rz * rz);
             float gv[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {

@@ -24,6 +24,17 @@ __device__ __forceinline__ floatx16 td_mfma(float a, float b, floatx16 c) {
 // becomes two compare + select pairs once the operands are elements of a vector
 __device__ __forceinline__ float td_clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
+// sqrt of a squared distance.  sqrtf() is 14 instructions here (IEEE rounding with denormal scaling); this is v_rsq_f32 and one Heron step in
+// FMAs -- six instructions, correctly rounded except for rare half-ulp ties of the intermediate (every margin of the GPU suite, the 1000-step
+// trajectories included, stayed the same to all printed digits; x2h key / value pass -1 %).  The clamp keeps rsq finite for a pad's d^2 = 0 (the
+// row itself stands in for a missing neighbour): 1e-15 instead of 0, the same Gaussians to the last bit.
+__device__ __forceinline__ float td_sqrt_d2(float x) {
+    x = fmaxf(x, 1e-30f);
+    const float rs = __builtin_amdgcn_rsqf(x);
+    const float y = x * rs, h = 0.5f * rs;
+    return fmaf(fmaf(-y, y, x), h, y);
+}
+
 // ---- cross-lane reductions without LDS round trips (DPP modifiers + gfx950 v_permlane32_swap) -------------
 template <int CTRL>
 __device__ __forceinline__ float td_dpp(float v) {
