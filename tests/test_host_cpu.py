@@ -224,3 +224,18 @@ def test_round4_config_options_are_accepted_or_refused_like_the_reference():
         ScorePosNet3D(dict(cfg, time_emb_dim=8, time_emb_mode='other'), 27, 13)
     with pytest.raises(ValueError):
         ScorePosNet3D(dict(cfg, model_mean_type='x0'), 27, 13)
+
+
+def test_bench_flop_bookkeeping_of_general_graphs():
+    """bench.py's executed FLOPs: on a general graph the attention passes scale with the chunks per row, the node projections and
+    the head do not (a k = 48 line once reported 1.12 of the fp32 peak because the whole step was doubled)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    N, Nl, L = 10000, 400, 9
+    base = bench.executed_flops_per_step(N, Nl, L, None)
+    two = bench.executed_flops_per_step(N, Nl, L, None, 2 * bench.KEY_PASS_FLOP_EXECUTED, 2 * bench.KEY_PASS_FLOP_EXECUTED, 2)
+    proj = L * (N * 6 * bench.GEMM128 + N * 2 * bench.GEMM128 + Nl * 4 * bench.GEMM128) + Nl * bench.HEAD_ROW
+    assert base > proj > 0
+    assert two == pytest.approx(2 * (base - proj) + proj)
+    assert two < 2 * base
