@@ -260,8 +260,11 @@ __global__ __launch_bounds__(256, 2) void node_proj_kernel(NpArgs args, const fl
 // destination from the buffer being read and puts s_waitcnt vmcnt(0) in front of the round's first ds_read: every one of the
 // 24 rounds then starts by waiting out a full L2 round trip (98 us per full-size launch against 33 us of MFMA time, round 2).
 // (Staging through registers instead costs 24 VGPRs the kernel does not have: the chunk lands in scratch.)
-__device__ __forceinline__ void td_glds16_asm(const uint4 *gsrc_lane, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_wave_base) : "memory", "m0");      // m0 named as clobbered: the compiler sets it itself for v_movrel / readlane selects / its own LDS-DMA (clang calls it "reserved" and warns: -Wno-inline-asm)
+// The source is a scalar base + the lane's byte offset: the six copies of a round then need no address arithmetic on the
+// vector unit (with a 64-bit vector address each copy is preceded by a v_lshl_add_u64 into the register pair the previous copy still reads
+// from, and all of it competes for vector issue with the partner wave's products): node projections 0.702 -> 0.696 ms per C2 step, C3 10.48 -> 10.31
+__device__ __forceinline__ void td_glds16_asm_s(const uint4 *gsrc_base, uint32_t lane_bytes, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_bytes), "s"(gsrc_base), "s"(lds_wave_base) : "memory", "m0");      // m0 named as clobbered: the compiler sets it itself for v_movrel / readlane selects / its own LDS-DMA (clang calls it "reserved" and warns: -Wno-inline-asm)
 }
 template <bool ASYNC, bool BPIPE>
 __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, const float *__restrict__ h) {
@@ -360,7 +363,9 @@ __global__ __launch_bounds__(256, 2) void node_proj_split_kernel(NpArgs args, co
                         const uint32_t lbase = __builtin_amdgcn_readfirstlane(
                             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63)));
 #pragma unroll
-                        for (int u = 0; u < NPS_CHUNK_U4 / 256; ++u) td_glds16_asm(src + u * 256 + tid, lbase + u * 256 * 16);
+                        for (int u = 0; u < NPS_CHUNK_U4 / 256; ++u) {
+                            td_glds16_asm_s(src + u * 256, (uint32_t)tid * 16u, lbase + u * 256 * 16);
+                        }
                     }
                 } else if (src) {
                     uint4 *dst = bufs + (cur ^ 1) * NPS_CHUNK_U4 + (tid & ~63);
