@@ -189,3 +189,52 @@ def ln_signs_state_dict(seed: int):
             w = torch.where(n % 31 == 5, torch.zeros_like(w), w)
             sd[key] = w.contiguous()
     return sd
+
+
+# ------------------------------------------------------------------------------------------ dead LayerNorm units, trained-like sets (round 6)
+DEAD_BETAS = (-1.0, 1.0, 3.0)
+
+
+def ln_dead_state_dict(seed: int):
+    """make_state_dict(seed) with, in every MLP, the LayerNorm weight of units 5 (mod 31) exactly 0 and their LayerNorm bias cycling
+    through -1, +1, +3 (a pruned / weight-decayed unit whose constant relu(beta) survives), units 3 (mod 29) tiny with a bias of 0.5,
+    every 7th unit negative, and the first Linear (net.0 weight and bias) scaled by 4 so that the pre-LayerNorm variance is well above
+    one.  The product's LayerNorm fold (csrc/pack.cpp FoldedMlp) divides the bias by |weight|: this is the set that overflowed it."""
+    sd = make_state_dict(seed)
+    for key in list(sd):
+        if key.endswith('.net.1.weight'):
+            w, bkey = sd[key], key[:-len('weight')] + 'bias'
+            b = sd[bkey].clone()
+            n = torch.arange(w.numel())
+            w = torch.where(n % 7 == 0, -w, w)
+            w = torch.where(n % 29 == 3, w * 1e-3, w)
+            b = torch.where(n % 29 == 3, torch.full_like(b, 0.5), b)
+            dead = n % 31 == 5
+            w = torch.where(dead, torch.zeros_like(w), w)
+            cyc = torch.tensor(DEAD_BETAS, dtype=torch.float32)[(n // 31) % len(DEAD_BETAS)]
+            b = torch.where(dead, cyc, b)
+            sd[key], sd[bkey] = w.contiguous(), b.contiguous()
+        elif key.endswith('.net.0.weight') or key.endswith('.net.0.bias'):
+            sd[key] = (sd[key] * 4.0).contiguous()
+    return sd
+
+
+def trained_like_state_dict(seed: int, gain: float):
+    """A weight regime closer to a trained net than make_state_dict's (no checkpoint ships with the reference): every Linear of the
+    MLPs drawn with ``gain`` times nn.Linear's default range (sharper softmaxes, pre-LayerNorm statistics far from unit variance),
+    LayerNorm weights log-uniform in [0.05, 5], LayerNorm biases uniform in [-2, 2].  The atom embeddings, v_inference and the output
+    Linear of the global edge gate keep make_state_dict's range: inputs and the type head stay in their usual range, and the gate stays
+    open (with ``gain`` on its output Linear the sigmoid saturates at 0 on most edges and every message vanishes -- measured: the
+    per-layer feature update drops to 1e-3, which tests nothing).  Per-layer updates with this set: |dh| ~ 1-5, |dx| ~ 0.1-1 A."""
+    sd = make_state_dict(seed, gain=gain)
+    base = make_state_dict(seed)
+    for key in list(sd):
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(('trained/' + key).encode())) % (2 ** 63))
+        if key.endswith('.net.1.weight'):
+            u = torch.rand(sd[key].shape, generator=g, dtype=torch.float32)
+            sd[key] = (0.05 * (100.0 ** u)).contiguous()
+        elif key.endswith('.net.1.bias'):
+            sd[key] = (torch.rand(sd[key].shape, generator=g, dtype=torch.float32) * 4 - 2).contiguous()
+        elif '.net.' not in key or key.startswith('refine_net.edge_pred_layer.net.3.'):
+            sd[key] = base[key]
+    return sd

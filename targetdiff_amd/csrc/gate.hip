@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(TdGate g, const float
         const float4 xi = x4[i];
         const float4 xj = x4[valid ? j : i];
         const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float d = td_sqrt_d2(dx * dx + dy * dy + dz * dz);      // the one distance function of every kernel that feeds Gaussians
         floatx16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -107,7 +107,7 @@ __global__ void layer_gate_kernel(const float *__restrict__ w, const float *__re
     if (j < 0) { ew[t] = 0.f; return; }
     const float4 xi = x4[i], xj = x4[j];
     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float d = td_sqrt_d2(dx * dx + dy * dy + dz * dz);      // the one distance function of every kernel that feeds Gaussians
     // edge type (models/uni_transformer.py:292-297): 0 l<-l, 1 src lig/dst prot, 2 src prot/dst lig, 3 p<-p
     const bool dl = xi.w > 0.5f, sl = xj.w > 0.5f;
     const int type = dl ? (sl ? 0 : 2) : (sl ? 1 : 3);

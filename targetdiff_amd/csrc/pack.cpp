@@ -1,5 +1,6 @@
 // C ABI of libtargetdiff_hip.so, part 2 of 5: the weight blob -- LayerNorm folding, re-packing into the kernels' fragment orders,
 // td_model_create / destroy / options.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -29,29 +30,54 @@ namespace tdapi {
 //    compute neither a mean nor a subtraction;
 //  * beta_n / a_n replaces beta, a_n goes into column n of the second Linear, and 1 / sigma (one number per edge) multiplies the
 //    second layer's per-edge result in the consumer (logit, xv, or the attention weight of the aggregation).
-// Exact algebra.  (gamma_n = 0 is carried as a_n = 1e-20: the unit's constant relu(beta_n) survives.)
+// Exact algebra.
 // Round 5 -- the ReLU as the FMA's own output clamp.  Dividing by sigma M instead of carrying sigma along,
 //     relu(s_n c_n / sigma + beta_n / a_n) / M = clamp_[0,1](s_n c_n (1 / (sigma M)) + beta_n / (a_n M)),
 // holds whenever the left side never exceeds 1: |c_n| <= sqrt(hid) sigma (the c_n are centred and sigma^2 >= their mean square), so
 // M = (sqrt(hid) + max_n beta_n / a_n) (1 + 2^-10) does.  v_fma_f32 has a free clamp-to-[0, 1] output modifier: ONE instruction per hidden
 // value where the round-4 form took an FMA and a max, no per-edge 1 / sigma for the consumers to apply (M a_n goes into column n of the
 // second Linear instead of a_n), and the kernels keep s_e = 1 / (sigma_e M) per edge only as the FMA's multiplier.
+// Round 6 -- dead units.  beta_n / a_n enters M, and the kernels evaluate rsqrt(sum c^2 * M^2 / hid + eps M^2): a unit with a_n -> 0 and
+// beta_n > 0 used to push M to ~1e19 and the radicand past FLT_MAX (rsqrt(inf) = 0: every activation of the edge silently collapsed to
+// its bias term).  A unit whose |gamma_n| is below 2^-30 of the MLP's largest |gamma| is the constant relu(beta_n) to 1e-8 of the live
+// units' scale (|c_n / sigma| <= sqrt(hid)): its constant goes into the second Linear's bias (b3 += w3[:, n] relu(beta_n)), its column of
+// the second Linear is zero, and its FMA constant is -1 so that the clamp gives exactly 0 (|c_n / (sigma M)| < 1).  Its row of the first
+// Linear stays: LayerNorm's mean and variance run over all hidden units.  Dead units stay out of M, so M <= sqrt(hid) + 2^30 max beta /
+// max |gamma|; td_model_create refuses a model whose M^2 could still overflow the radicand (overflow_risk).
 struct FoldedMlp {
-    std::vector<float> w0, b0, g, b, w3;
+    std::vector<float> w0, b0, g, b, w3, b3v;
     const float *b3;
     float ln_c1 = 1.f / 128.f, ln_c2 = 1e-5f;        // the kernels' variance constants (below)
-    FoldedMlp(const MlpSrc &m, int in, int hid, int out) : w0((size_t)hid * in), b0(hid), g(hid), b(hid), w3((size_t)out * hid), b3(m.b3) {
+    int dead_units = 0;
+    bool overflow_risk = false;                      // M^2 * (pre-LayerNorm variance of 1e8) would leave the fp32 range
+    FoldedMlp(const MlpSrc &m, int in, int hid, int out)
+        : w0((size_t)hid * in), b0(hid), g(hid), b(hid), w3((size_t)out * hid), b3v(m.b3, m.b3 + out), b3(nullptr) {
         std::vector<float> sg(hid);
-        double bmax = 0.0;
+        std::vector<char> dead(hid, 0);
+        double bmax = 0.0, amax = 0.0;
+        for (int n = 0; n < hid; ++n) amax = std::max(amax, (double)fabsf(m.g[n]));
+        const double floor_a = amax * (1.0 / 1073741824.0);          // 2^-30 of the largest |gamma|; amax = 0: every unit is dead
         for (int n = 0; n < hid; ++n) {
-            const float a = fabsf(m.g[n]) > 1e-20f ? fabsf(m.g[n]) : 1e-20f;
+            const double a = (double)fabsf(m.g[n]);
             sg[n] = m.g[n] < 0.f ? -1.f : 1.f;
-            g[n] = a;
-            b[n] = m.b[n] / a;
+            if (!(a > floor_a) || !(a > 1e-30)) {
+                dead[n] = 1;
+                ++dead_units;
+                sg[n] = 1.f;
+                g[n] = 0.f;
+                b[n] = -1.f;
+                const double r = m.b[n] > 0.f ? (double)m.b[n] : 0.0;
+                for (int o = 0; o < out; ++o) b3v[o] = (float)((double)b3v[o] + (double)m.w3[(size_t)o * hid + n] * r);
+                continue;
+            }
+            g[n] = (float)a;
+            b[n] = (float)((double)m.b[n] / a);
             if ((double)b[n] > bmax) bmax = (double)b[n];
         }
         const double M = (sqrt((double)hid) + bmax) * (1.0 + 1.0 / 1024.0);
+        overflow_risk = !(M * M * 1e8 < 3.0e38);
         for (int n = 0; n < hid; ++n) {
+            if (dead[n]) continue;
             b[n] = (float)((double)b[n] / M);
             g[n] = (float)((double)g[n] * M);          // what column n of the second Linear carries
         }
@@ -69,6 +95,7 @@ struct FoldedMlp {
         for (int n = 0; n < hid; ++n) b0[n] = (float)((double)sg[n] * ((double)m.b0[n] - mb));
         for (int o = 0; o < out; ++o)
             for (int n = 0; n < hid; ++n) w3[(size_t)o * hid + n] = m.w3[(size_t)o * hid + n] * g[n];
+        b3 = b3v.data();
     }
     MlpSrc src() const { return MlpSrc{w0.data(), b0.data(), g.data(), b.data(), w3.data(), b3}; }
 };
@@ -396,6 +423,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     MlpSrc gate = c.ew_net_type == 0 ? cur.mlp(TD_NG, H, 1) : zc.mlp(TD_NG, H, 1);
     const FoldedMlp fgate(gate, TD_NG, H, 1);          // LayerNorm folded into the two Linears, like the edge MLPs'
     gate = fgate.src();
+    bool fold_overflow = fgate.overflow_risk;
 
     Packer pk;
     // ---- embeddings (+ node indicator column, models/molopt_score_model.py:336-338)
@@ -450,6 +478,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             // the edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
             const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H);
             hk = fhk.src(); hv = fhv.src();
+            fold_overflow = fold_overflow || fhk.overflow_risk || fhv.overflow_risk;
             if (c.ew_net_type != 0) gate_rows(o.ew_x2h, ewx);
             if (ewm) {          // u'_n = sum_o w_m[o] W2v'[o][n] on the FOLDED second Linear (its columns carry |gamma_n|), c = w_m . b2v + b_m
                 o.gate_m = pk.alloc(TD_H + 1);
@@ -483,6 +512,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             if (!cur.ok) break;
             const FoldedMlp fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
             xk = fxk.src(); xv = fxv.src();
+            fold_overflow = fold_overflow || fxk.overflow_risk || fxv.overflow_risk;
             if (c.ew_net_type != 0) gate_rows(o.ew_h2x, ewh);
             o.nh = pack_node_stage(pk, xk, xv, xq, KV);
             o.xk = pack_edge_mlp(pk, fxk, KV, H, 1);
@@ -493,6 +523,11 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     // ---- head
     const float *V0 = cur.take((size_t)H * H), *vb0 = cur.take(H), *V2 = cur.take((size_t)C * H), *vb2 = cur.take(C);
     if (!cur.ok || cur.left != 0) { td_set_error("td_model_create: weight blob layout mismatch"); return TD_EINVAL; }
+    if (fold_overflow) {
+        td_set_error("td_model_create: an edge MLP's LayerNorm has bias / |weight| beyond 1e15 on a unit that is not negligible "
+                     "(|weight| > 2^-30 of the MLP's largest): the folded form would overflow fp32");
+        return TD_EINVAL;
+    }
     size_t oW0T = pk.alloc((size_t)H * H), ohb0 = pack_vec(pk, vb0, H), oW2T = pk.alloc((size_t)H * TD_MAXC),
            ohb2 = pack_vec(pk, vb2, C, TD_MAXC);
     for (int k = 0; k < H; ++k) {

@@ -78,6 +78,9 @@ void free_async_or_sync(void *p, hipStream_t s) {
 }
 
 void session_drop_graph(td_session *S) {
+    // the previous replay may still be in flight on the stream it was launched on (an option change between two steps lands here):
+    // whether destroying an executing graph is deferred depends on the runtime version, so wait for it.  Cold path.
+    if (S->graph_exec) (void)hipStreamSynchronize(S->last_stream);
     if (S->graph_exec) (void)hipGraphExecDestroy(S->graph_exec);
     if (S->graph) (void)hipGraphDestroy(S->graph);
     S->graph_exec = nullptr;
