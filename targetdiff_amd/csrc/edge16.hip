@@ -23,6 +23,46 @@ __device__ __forceinline__ floatx4_t td_mfma16(float a, float b, floatx4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- the second layer on v_mfma_f32_16x16x32_f16 (round 6) -----------------------------------------------------------------------------
+// The per-edge 128-deep products (logits = z . U_i, Zbar = alpha^T z) used to run on v_mfma_f32_16x16x4_f32: 64 instructions of 32 cycles
+// per row -- a quarter of a pass -- on the fp32 matrix path, which IS the vector unit's rate and does not overlap with vector instructions.
+// Both operands now go in as PAIRS of f16 pieces, x = h1 + h2 with h1 = x truncated to f16 and h2 = f16(x - h1) (round to nearest; the
+// residual x - h1 is exact in fp32), and three piece products per tile -- h1 h1', h1 h2', h2 h1' -- replace the fp32 product with fp32
+// accumulation: 24 instructions of 16 cycles on the matrix cores proper.  What it represents: the activations z'' and the attention
+// weights are in [0, 1] by construction (FoldedMlp's clamp; softmax x gate) and U_i is scaled per row by a power of two to below 2^13, so
+// every operand is carried to 22 significant bits, and never worse than 2^-25 of the operand's scale (f16 subnormals, which the
+// instruction honours exactly: tools/microbench/f16_split_probe.hip); the dropped product h2 h2' is below 2^-22 relative.  The fp32 form
+// rounds each of its 128 (32) partial sums to 24 bits, so the two differ by about one fp32 rounding of the result -- measured on the
+// goldens of the real reference incl. its float64 runs (profiles/r06*_second_layer_error.txt).  TD_L2_F16 = 0 builds the fp32 form.
+#ifndef TD_L2_F16
+#define TD_L2_F16 1
+#endif
+typedef _Float16 half8_16 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ floatx4_t td_mfma16h(uint4 a, uint4 b, floatx4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_16, a), __builtin_bit_cast(half8_16, b), c, 0, 0, 0);
+}
+// (x, y) -> packed f16 pairs h1 = (trunc x, trunc y), h2 = (x - h1.x, y - h1.y) rounded to nearest: v_cvt_pkrtz_f16_f32 and one
+// v_fma_mix{lo,hi}_f16 per value (the f16 piece as a source of an fp32 FMA whose result is written back as f16)
+__device__ __forceinline__ void td_split_h2(float x, float y, unsigned &h1, unsigned &h2) {
+    h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h2) : "v"(h1), "v"(x), "v"(y));
+}
+// The same for values in [0, 1] that may sit far below 1 (z'' = activation / (|gamma| M): around 1 / M, and M grows with the largest
+// LayerNorm bias / |weight| of the MLP): the pieces are taken of x S with S = 2^15, exactly, so that 22 bits survive down to x = 2^-18 instead
+// of running into the f16 subnormal floor at 2^-25 -- h1 = f16(x S) (round to nearest), h2 = f16(x S - h1): two v_fma_mix per piece pair
+// member, S as a scalar operand.  The consumer takes 1 / S off its result.
+constexpr float TD_Z_SCALE = 32768.0f;
+__device__ __forceinline__ void td_split_h2_scaled(float x, float y, unsigned &h1, unsigned &h2) {
+    const float S = TD_Z_SCALE;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h1), "=&v"(h2) : "v"(x), "v"(y), "s"(S));
+}
+
 constexpr float TD_ATT_SCALE_16 = 0.35355339059327373f;   // 1/sqrt(8)
 constexpr float TD_LOG2E = 1.4426950408889634f;
 constexpr float TD_FAR_CENTRE = 1.0e4f;                    // "centre" of the K slots behind the 20 Gaussians: exp2(c (d - 1e4)^2) = 0
@@ -149,12 +189,14 @@ __device__ __forceinline__ void td_sum16x4(float (&v)[4]) {
 // softmax over the 32 edges of a row for the four heads 4g + r of the lane group (lg[eb][r] = logit of edge 16eb + lo), times the edge
 // gate: p[eb][r] = exp(x - max) / sum * ew[eb].  A pad's logit is -inf, so its weight is exp(-inf) = 0 without a select; a row without
 // edges gets zeros.  1 / sum is v_rcp_f32 (1 ulp; the correctly rounded __frcp_rn is an 11-instruction sequence per head).
-__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], floatx4_t (&p)[2]) {
+// (scale: 1 / sqrt(8), times whatever power of two the caller's logits carry)
+__device__ __forceinline__ void td_softmax16x4(const floatx4_t (&lg)[2], const bool (&valid)[2], const float (&ew)[2], floatx4_t (&p)[2],
+                                               const float scale = TD_ATT_SCALE_16) {
     float x0[4], x1[4], mx[4], sm[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        x0[r] = valid[0] ? lg[0][r] * TD_ATT_SCALE_16 : -INFINITY;
-        x1[r] = valid[1] ? lg[1][r] * TD_ATT_SCALE_16 : -INFINITY;
+        x0[r] = valid[0] ? lg[0][r] * scale : -INFINITY;
+        x1[r] = valid[1] ? lg[1][r] * scale : -INFINITY;
         mx[r] = fmaxf(x0[r], x1[r]);
     }
     td_max16x4(mx);
@@ -267,6 +309,78 @@ __device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, 
         td_ln_relu16<1>(KB, g, acc, ln);
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) acc[1][hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// The same LayerNorm + ReLU with z'' leaving as f16 piece pairs for the value pass's aggregation product (td_split_h2): word r of
+// z1[hb] / z2[hb] = pieces of hidden unit 16hb + 4g + r for the lane's two edges (low half: edge lo, high half: edge 16 + lo) -- after the
+// flip through the wave's LDS tile a word is two K slots of the A operand.
+__device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
+                                                      uint4 (&z1)[8], uint4 (&z2)[8]) {
+    float sc[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            sa = fmaf(acc[eb][hb][0], acc[eb][hb][0], sa); sb = fmaf(acc[eb][hb][1], acc[eb][hb][1], sb);
+            sa = fmaf(acc[eb][hb][2], acc[eb][hb][2], sa); sb = fmaf(acc[eb][hb][3], acc[eb][hb][3], sb);
+        }
+        sc[eb] = sa + sb;
+    }
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(sc[eb]), ln.c1, ln.c2));
+#pragma unroll
+    for (int hb = 0; hb < 8; ++hb) {
+        const float4 kb4 = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
+        const float kb[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
+        unsigned w1[4], w2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            td_split_h2_scaled(td_clamp01(fmaf(acc[0][hb][r], sc[0], kb[r])), td_clamp01(fmaf(acc[1][hb][r], sc[1], kb[r])), w1[r], w2[r]);
+        z1[hb] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        z2[hb] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+    }
+}
+
+// ... and for the key pass's logits product, where z''^T is the B operand and the K slots run over hidden units: quad t of edge block eb
+// holds the hidden units 16 (2t + j / 4) + 4g + j % 4, j = 0 .. 7 (the two hidden blocks 2t, 2t + 1 of the lane), i.e. the pairs are
+// (r = 0, 1) and (r = 2, 3) of one accumulator tile.
+__device__ __forceinline__ void td_ln_relu16_pairs_k(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
+                                                     uint4 (&z1)[2][4], uint4 (&z2)[2][4]) {
+    float sc[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            sa = fmaf(acc[eb][hb][0], acc[eb][hb][0], sa); sb = fmaf(acc[eb][hb][1], acc[eb][hb][1], sb);
+            sa = fmaf(acc[eb][hb][2], acc[eb][hb][2], sa); sb = fmaf(acc[eb][hb][3], acc[eb][hb][3], sb);
+        }
+        sc[eb] = sa + sb;
+    }
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(sc[eb]), ln.c1, ln.c2));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        unsigned w1[2][4], w2[2][4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int hb = 2 * t + h2;
+            const float4 kb = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) {
+                td_split_h2_scaled(td_clamp01(fmaf(acc[eb][hb][0], sc[eb], kb.x)), td_clamp01(fmaf(acc[eb][hb][1], sc[eb], kb.y)),
+                                   w1[eb][2 * h2], w2[eb][2 * h2]);
+                td_split_h2_scaled(td_clamp01(fmaf(acc[eb][hb][2], sc[eb], kb.z)), td_clamp01(fmaf(acc[eb][hb][3], sc[eb], kb.w)),
+                                   w1[eb][2 * h2 + 1], w2[eb][2 * h2 + 1]);
+            }
+        }
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb) {
+            z1[eb][t] = make_uint4(w1[eb][0], w1[eb][1], w1[eb][2], w1[eb][3]);
+            z2[eb][t] = make_uint4(w2[eb][0], w2[eb][1], w2[eb][2], w2[eb][3]);
+        }
     }
 }
 
@@ -498,7 +612,8 @@ struct TdNoHook { __device__ __forceinline__ void operator()() const {} };
 // k = 48; the caller tests it, wave-uniform) and costs nothing: no P_i adds, no Gaussians, no products, z = 0 and 1 / sigma = 0.
 // LN_SKIP (NEB = 2 only): the LayerNorm leaves out a second block without edges (z = 0, 1 / sigma = 0) -- what the chunk-walking key pass, which
 // has no registers to spare for an NEB = 1 path, still saves on a half-empty chunk.
-template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB, bool LN_SKIP, int PK, int AH = 0, class Hook = TdNoHook>
+// NO_LN: stop in front of the LayerNorm (the caller runs one of the forms that leave z'' as f16 piece pairs: td_ln_relu16_pairs_*).
+template <bool LOAD_EW, bool ONE_CLASS, bool PI_LATE, int NEB, bool LN_SKIP, int PK, int AH = 0, class Hook = TdNoHook, bool NO_LN = false>
 __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const uint4 *__restrict__ Rp,
                                                        const float *__restrict__ KB,
                                                        const float (&offj)[8], const RowIn16 &r, int64_t i, int lane,
@@ -591,6 +706,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
         if (any_sl) products4(sl);
     }
     if (PI_LATE) add_pi();
+    if constexpr (NO_LN) return;
     const TdLn ln{a.mlp.ln_c1, a.mlp.ln_c2};
     if (NEB == 2 && LN_SKIP) td_ln_relu16_skip(KB, g, acc, ln, ed.any);
     else td_ln_relu16<NEB>(KB, g, acc, ln);
@@ -640,6 +756,9 @@ template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
+    // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass of the default graph.  (General graphs and the unfused h2x
+    // key pass keep the fp32 product: their session / stateless / fused forms run different kernels on the same rows and are held bit-identical.)
+    constexpr bool L2H = TD_L2_F16 != 0 && SPLIT && !XV && GRAPH == 0 && STAGE == 0;
     constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -724,7 +843,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
                 td_first_layer_split16<EW, false, false, 1, false, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK, (CHUNKED || XV) ? 0 : TD_KEY_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK, (CHUNKED || XV) ? 0 : TD_KEY_AH, decltype(fetch_q), L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
@@ -810,7 +929,72 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             }
         };
 
-        if (!CHUNKED || nch == 1) {
+        if constexpr (L2H) {
+            // ---- logits on f16 piece pairs: z''^T (B operand, K = hidden units) leaves the LayerNorm as pairs scaled by 2^15; U_i (A operand) is
+            // built eight K slots at a time from a query scaled by a power of two so that |U_i| < 2^13 (|U| <= 8 max |W2k'| max |q|), split, and its
+            // six products (two edge blocks x {h2 h1', h1 h2', h1 h1'}) are issued between the next eight slots' FMAs.  The softmax takes the
+            // two scales off.
+            floatx4_t acc[2][8], lg[2];
+            Edge2 ed;
+            first_layer(i, c0, acc, ed);
+            uint4 zk1[2][4], zk2[2][4];
+            td_ln_relu16_pairs_k(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, zk1, zk2);
+            float4 q0 = qpre0, q1 = qpre1;
+            float qm = fmaxf(fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))),
+                             fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
+            qm = td_max16(qm);                                    // over the row's 128 query entries (16 lanes x 8; every lane group holds them all)
+            int qe = __builtin_amdgcn_frexp_expf(qm * a.mlp.w2_bound);      // the bound is below 2^qe
+            qe = qe < -100 ? -100 : (qe > 100 ? 100 : qe);
+            const float qs = __builtin_amdgcn_ldexpf(1.0f, 13 - qe);
+            q0.x *= qs; q0.y *= qs; q0.z *= qs; q0.w *= qs; q1.x *= qs; q1.y *= qs; q1.z *= qs; q1.w *= qs;
+            floatx4_t lgc[2];
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) { lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; lgc[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f}; }
+            uint4 pu1 = make_uint4(0u, 0u, 0u, 0u), pu2 = pu1;
+            auto product = [&](int t, int m) {                  // product m of K block t: the small ones first, on their own accumulators
+                const int eb = m & 1, kind = m >> 1;
+                if (kind == 0) lgc[eb] = td_mfma16h(pu2, zk1[eb][t], lgc[eb]);
+                else if (kind == 1) lgc[eb] = td_mfma16h(pu1, zk2[eb][t], lgc[eb]);
+                else lg[eb] = td_mfma16h(pu1, zk1[eb][t], lg[eb]);
+            };
+            float4 w0 = Wq[lane], w1 = Wq[64 + lane];
+            float uu[8];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                float4 n0 = w0, n1 = w1;
+                if (kk + 1 < 32) {
+                    n0 = Wq[((kk + 1) * 2 + 0) * 64 + lane];
+                    n1 = Wq[((kk + 1) * 2 + 1) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);         // the reads stay in front of this k-step's arithmetic
+                float u = w0.x * q0.x;
+                u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
+                u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                uu[kk & 7] = u;
+                if (kk >= 8 && (kk & 7) < 6) product((kk >> 3) - 1, kk & 7);
+                if ((kk & 7) == 7) {
+                    unsigned a1[4], a2[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) td_split_h2(uu[2 * m], uu[2 * m + 1], a1[m], a2[m]);
+                    pu1 = make_uint4(a1[0], a1[1], a1[2], a1[3]);
+                    pu2 = make_uint4(a2[0], a2[1], a2[2], a2[3]);
+                }
+                w0 = n0; w1 = n1;
+            }
+#pragma unroll
+            for (int m = 0; m < 6; ++m) product(3, m);
+#pragma unroll
+            for (int eb = 0; eb < 2; ++eb) lg[eb] += lgc[eb];
+            floatx4_t pr[2];
+            td_softmax16x4(lg, ed.valid, ed.ew, pr, __builtin_amdgcn_ldexpf(TD_ATT_SCALE_16 / TD_Z_SCALE, qe - 13));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
+                dst[0] = pr[0][r];
+                dst[16] = pr[1][r];
+            }
+            continue;
+        } else if (!CHUNKED || nch == 1) {
             floatx4_t acc[2][8], lg[2];
             Edge2 ed;
             first_layer(i, c0, acc, ed);
@@ -1259,6 +1443,9 @@ template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
+    // the aggregation product on f16 piece pairs, exactly as in edge_value16t_kernel (the row distribution settings select between the two
+    // kernels and stay bit-identical): the default graph's bf16-first-layer instantiation
+    constexpr bool L2H = TD_L2_F16 != 0 && SPLIT && !CHUNKED && !GATE_M;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
@@ -1396,9 +1583,16 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     auto chunk_of = [&](int64_t ix) -> int64_t { return CHUNKED ? (int64_t)a.cptr[ix] : ix; };
     auto load_side = [&](int64_t ix, int64_t cx, float (&alx)[8], float &h0, float &h1) {
         // A operand of the aggregation product: alpha[edge 8g + s][head lo], s = 0..7 (two 16-byte loads); residual row
-        const float *ap = a.alpha + ((size_t)cx * TD_HEADS + lo) * TD_K + 8 * g;
-        const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
-        alx[0] = v0.x; alx[1] = v0.y; alx[2] = v0.z; alx[3] = v0.w; alx[4] = v1.x; alx[5] = v1.y; alx[6] = v1.z; alx[7] = v1.w;
+        // (L2H: K slots (2m, 2m + 1) = edges 4g + m, 16 + 4g + m)
+        if constexpr (L2H) {
+            const float *ap = a.alpha + ((size_t)cx * TD_HEADS + lo) * TD_K + 4 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 16);
+            alx[0] = v0.x; alx[1] = v1.x; alx[2] = v0.y; alx[3] = v1.y; alx[4] = v0.z; alx[5] = v1.z; alx[6] = v0.w; alx[7] = v1.w;
+        } else {
+            const float *ap = a.alpha + ((size_t)cx * TD_HEADS + lo) * TD_K + 8 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
+            alx[0] = v0.x; alx[1] = v0.y; alx[2] = v0.z; alx[3] = v0.w; alx[4] = v1.x; alx[5] = v1.y; alx[6] = v1.z; alx[7] = v1.w;
+        }
         h0 = a.h[(size_t)ix * TD_H + nout];
         h1 = a.h[(size_t)ix * TD_H + nout + 4];
     };
@@ -1542,7 +1736,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             }
             // (P_i joins before the products on the default graph, as in edge_value16t_kernel -- the same bits whichever kernel the row
             // distribution setting selects; the chunked instantiation hides the P_i loads behind the products instead)
-            td_first_layer_split16<false, true, CHUNKED, 2, false, TD_VALUE_PK, 1>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+            td_first_layer_split16<false, true, CHUNKED, 2, false, TD_VALUE_PK, 1, TdNoHook, L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
@@ -1571,6 +1765,46 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         //      the wave-private tile into the B layout (lane = hidden unit), 8 k-steps over the 32 edges ------------------
         // Two tiles ping-pong so that the flip of block hb + 1 is in flight while block hb feeds the MFMAs.
         floatx4_t zb[8];
+        float out_scale = 1.0f;
+        if constexpr (L2H) {          // see edge_value16t_kernel; two tiles ping-pong here
+            uint4 z1[8], z2[8];
+            td_ln_relu16_pairs_eb(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
+            uint4 aq1, aq2;
+            {
+                unsigned p1[4], p2[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) td_split_h2(al[2 * m] * 1024.0f, al[2 * m + 1] * 1024.0f, p1[m], p2[m]);
+                aq1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                aq2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+            }
+            constexpr int TWS = 20, TWP = 16 * TWS;
+            auto flip_store_h = [&](int hb) {
+                unsigned *TW = reinterpret_cast<unsigned *>(TB + (hb & 1) * V16_TILE_FLOATS);
+                *reinterpret_cast<uint4 *>(TW + lo * TWS + 4 * g) = z1[hb];
+                *reinterpret_cast<uint4 *>(TW + TWP + lo * TWS + 4 * g) = z2[hb];
+            };
+            auto flip_load_h = [&](int hb, uint4 (&zq)[2]) {
+                const unsigned *t = reinterpret_cast<const unsigned *>(TB + (hb & 1) * V16_TILE_FLOATS) + 4 * g * TWS + lo;
+                zq[0] = make_uint4(t[0], t[TWS], t[2 * TWS], t[3 * TWS]);
+                zq[1] = make_uint4(t[TWP], t[TWP + TWS], t[TWP + 2 * TWS], t[TWP + 3 * TWS]);
+            };
+            uint4 zqb[2][2];
+            flip_store_h(0);
+            flip_load_h(0, zqb[0]);
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                if (hb + 1 < 8) {
+                    flip_store_h(hb + 1);
+                    flip_load_h(hb + 1, zqb[(hb + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+                zb[hb] = td_mfma16h(zqb[hb & 1][1], aq1, zb[hb]);
+                zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
+                zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
+            }
+            out_scale = 1.0f / (1024.0f * TD_Z_SCALE);
+        } else {
         auto flip_store = [&](int hb) {
             float *t = TB + (hb & 1) * V16_TILE_FLOATS;
 #pragma unroll
@@ -1600,6 +1834,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             for (int s = 0; s < 8; ++s) zb[hb] = td_mfma16(bvb[hb & 1][s], al[s], zb[hb]);
         }
 
+        }
         // ---- next row: gathers into the (now free) accumulators, its alpha fragment and residual ---------------------
         const int64_t icur = i;
         const float hcur0 = hres0, hcur1 = hres1;
@@ -1618,8 +1853,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         // ---- out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (td_value_out16: outputs nout, nout + 4) -------
         float o0, o1;
         td_value_out16(zb, Wt_lane, o0, o1);
-        o0 = fmaf(B2[nout], ssum, o0);
-        o1 = fmaf(B2[nout + 4], ssum, o1);
+        o0 = fmaf(B2[nout], ssum, o0 * out_scale);
+        o1 = fmaf(B2[nout + 4], ssum, o1 * out_scale);
         if (a.out) {
             a.out[(size_t)icur * TD_H + nout] = o0;
             a.out[(size_t)icur * TD_H + nout + 4] = o1;
@@ -1728,27 +1963,85 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         if (((__builtin_amdgcn_readfirstlane(__float_as_int(rin.xi.w)) > __float_as_int(0.5f)) ? 0 : 1) != my_cls) continue;
         floatx4_t acc[2][8];
         td_row_gather16<false>(a, i, i, lane, rin, acc);
+#if TD_L2_F16
+        // B operand of the aggregation product, K slots (g, 2m) / (g, 2m + 1) = edges 4g + m / 16 + 4g + m (the pairing the flipped z''
+        // words have): alpha[edge][head lo], two 16-byte loads
+        float al[8];
+        {
+            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 4 * g;
+            const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 16);
+            al[0] = v0.x; al[1] = v1.x; al[2] = v0.y; al[3] = v1.y; al[4] = v0.z; al[5] = v1.z; al[6] = v0.w; al[7] = v1.w;
+        }
+#else
         float al[8];
         {   // A operand of the aggregation product: alpha[edge 8g + s][head lo]
             const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
             al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
         }
+#endif
         const float hres0 = a.h[(size_t)i * TD_H + nout], hres1 = a.h[(size_t)i * TD_H + nout + 4];
         Edge2 ed;
+        float offr[8];
         {
-            float offr[8];
             int dep = 0;
             asm volatile("" : "+v"(dep));
             const float4 *op = reinterpret_cast<const float4 *>(B2 + 2 * TD_H + 4 + 8 * g + dep);
             const float4 o0 = op[0], o1 = op[1];
             offr[0] = o0.x; offr[1] = o0.y; offr[2] = o0.z; offr[3] = o0.w; offr[4] = o1.x; offr[5] = o1.y; offr[6] = o1.z; offr[7] = o1.w;
-            td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges, in every lane group
-        // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
         floatx4_t zb[8];
+#if TD_L2_F16
+        // Zbar^T on v_mfma_f32_16x16x32_f16: zb[hb][r] = 2^10 sum_e z''[e][16hb + 4g + r] alpha[e][head lo], K = the row's 32 edges in ONE
+        // instruction per piece product and hidden block.  z'' leaves the LayerNorm as two f16 pieces, the lane's two edges in one word
+        // (td_ln_relu16_pairs_eb); the flip through the wave's tile moves WORDS: lane (edge lo, g) stores its four hidden units 4g .. 4g + 3 of
+        // the block as one 16-byte row segment, lane (hidden lo, g) reads the words of edges 4g .. 4g + 3 in its column -- four K-slot pairs,
+        // the A operand.  Tiles: [16 edge rows][20 words] per piece (the row stride of 20 keeps both the 16-byte stores and the 4-byte reads
+        // conflict-free, as in the fp32 form).  alpha goes in scaled by 2^10 and z'' by 2^15 (exact) so that small weights and
+        // activations keep their 22 bits above the f16 subnormal floor; the scales come off the two outputs.
+        td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+        uint4 z1[8], z2[8];
+        td_ln_relu16_pairs_eb(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
+        uint4 aq1, aq2;
+        {
+            unsigned p1[4], p2[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) td_split_h2(al[2 * m] * 1024.0f, al[2 * m + 1] * 1024.0f, p1[m], p2[m]);
+            aq1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+            aq2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        }
+        unsigned *TW = reinterpret_cast<unsigned *>(TB);
+        constexpr int TWS = 20, TWP = 16 * TWS;                      // row stride and piece stride of the flip tile, words
+        auto flip_store = [&](int hb) {
+            *reinterpret_cast<uint4 *>(TW + lo * TWS + 4 * g) = z1[hb];
+            *reinterpret_cast<uint4 *>(TW + TWP + lo * TWS + 4 * g) = z2[hb];
+        };
+        auto flip_load = [&](uint4 (&zq)[2]) {
+            const unsigned *t = TW + 4 * g * TWS + lo;
+            zq[0] = make_uint4(t[0], t[TWS], t[2 * TWS], t[3 * TWS]);
+            zq[1] = make_uint4(t[TWP], t[TWP + TWS], t[TWP + 2 * TWS], t[TWP + 3 * TWS]);
+        };
+        uint4 zqb[2][2];
+        flip_store(0);
+        flip_load(zqb[0]);
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            if (hb + 1 < 8) {
+                flip_store(hb + 1);
+                flip_load(zqb[(hb + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            zb[hb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
+            zb[hb] = td_mfma16h(zqb[hb & 1][1], aq1, zb[hb]);          // the small products first
+            zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
+            zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
+        }
+        constexpr float OUT_SCALE = 1.0f / (1024.0f * TD_Z_SCALE);
+#else
+        td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+        // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
         auto flip_store = [&](int hb) {
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb)
@@ -1773,11 +2066,13 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
 #pragma unroll
             for (int sx = 0; sx < 8; ++sx) zb[hb] = td_mfma16(bvb[hb & 1][sx], al[sx], zb[hb]);
         }
+        constexpr float OUT_SCALE = 1.0f;
+#endif
         // out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (td_value_out16: this lane's outputs nout, nout + 4)
         float o0, o1;
         td_value_out16(zb, Wt_lane, o0, o1);
-        o0 = fmaf(B2[nout], ssum, o0);
-        o1 = fmaf(B2[nout + 4], ssum, o1);
+        o0 = fmaf(B2[nout], ssum, o0 * OUT_SCALE);
+        o1 = fmaf(B2[nout + 4], ssum, o1 * OUT_SCALE);
         if (a.out) {
             a.out[(size_t)i * TD_H + nout] = o0;
             a.out[(size_t)i * TD_H + nout + 4] = o1;

@@ -197,12 +197,17 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2, w2_bound; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, int alt) {
     const MlpSrc m = fm.src();
     EdgeOff o;
     o.ln_c1 = fm.ln_c1; o.ln_c2 = fm.ln_c2;
+    {
+        float wmax = 0.f;
+        for (size_t t = 0; t < (size_t)out_dim * TD_H; ++t) wmax = std::max(wmax, fabsf(m.w3[t]));
+        o.w2_bound = 8.0f * wmax;
+    }
     o.Walt = 0;
     o.Walt16 = 0;
     // first layer radial / type table: [cls][slot][kstep][lane][ntile]
@@ -558,7 +563,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         D + o.R16q, o.ln_c1, o.ln_c2, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,

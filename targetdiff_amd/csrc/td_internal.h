@@ -63,6 +63,8 @@ struct TdEdgeMlp {
     const float *R16q;     // the radial/type table as exact bf16 piece triples, K-packed for four v_mfma_f32_16x16x32_bf16 per tile
                            // (pack_pk4_table, pack.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
+    float w2_bound;        // key MLPs: 8 max |W2'| (folded second Linear): |U_i[n][head]| = |sum_d W2'[8 head + d][n] q_i[8 head + d]| <= w2_bound max |q_i|
+                           // (the f16 logits product scales the query by a power of two from this bound, edge16.hip)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
                            // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
