@@ -37,6 +37,12 @@ __device__ __forceinline__ floatx4_t td_mfma16(float a, float b, floatx4_t c) {
 #ifndef TD_L2_F16
 #define TD_L2_F16 1
 #endif
+#ifndef TD_ZPLAIN_OFF
+#define TD_ZPLAIN_OFF 0   // 1: every MLP takes the scaled pieces (A/B of the two conversions)
+#endif
+#ifndef TD_ABL
+#define TD_ABL 0          // timing ablations of the key pass (wrong results; EXPERIMENTS.md round 6): 1 no U_i FMAs, 2 no Wq reads, 3 no z'' split, 4 no first-layer products, 5 no P_j gathers, 6 no logits products
+#endif
 typedef _Float16 half8_16 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ floatx4_t td_mfma16h(uint4 a, uint4 b, floatx4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_16, a), __builtin_bit_cast(half8_16, b), c, 0, 0, 0);
@@ -61,6 +67,58 @@ __device__ __forceinline__ void td_split_h2_scaled(float x, float y, unsigned &h
         "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(h1), "=&v"(h2) : "v"(x), "v"(y), "s"(S));
+}
+// Four pairs at once, the sixteen instructions interleaved so that no instruction reads the register the one before it wrote (a pair's four
+// conversions are a dependent chain through the two halves of h1 and h2: issued back to back, as one statement per pair does, every one of
+// them waits out its predecessor's latency -- PMC had 7.6 cycles of SQ_ACTIVE_INST_VALU per added instruction against 4.1 for the rest).
+#ifndef TD_SPLIT_X4
+#define TD_SPLIT_X4 1
+#endif
+__device__ __forceinline__ void td_split_h2_scaled_x4(const float (&x)[4], const float (&y)[4], unsigned (&h1)[4], unsigned (&h2)[4]) {
+#if TD_SPLIT_X4
+    const float S = TD_Z_SCALE;
+    asm("v_fma_mixlo_f16 %0, %8, %16, 0\n\t"
+        "v_fma_mixlo_f16 %1, %9, %16, 0\n\t"
+        "v_fma_mixlo_f16 %2, %10, %16, 0\n\t"
+        "v_fma_mixlo_f16 %3, %11, %16, 0\n\t"
+        "v_fma_mixhi_f16 %0, %12, %16, 0\n\t"
+        "v_fma_mixhi_f16 %1, %13, %16, 0\n\t"
+        "v_fma_mixhi_f16 %2, %14, %16, 0\n\t"
+        "v_fma_mixhi_f16 %3, %15, %16, 0\n\t"
+        "v_fma_mixlo_f16 %4, %8, %16, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %5, %9, %16, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %6, %10, %16, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %7, %11, %16, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %4, %12, %16, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %5, %13, %16, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %6, %14, %16, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %7, %15, %16, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h1[0]), "=&v"(h1[1]), "=&v"(h1[2]), "=&v"(h1[3]), "=&v"(h2[0]), "=&v"(h2[1]), "=&v"(h2[2]), "=&v"(h2[3])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "s"(S));
+#else
+#pragma unroll
+    for (int m = 0; m < 4; ++m) td_split_h2_scaled(x[m], y[m], h1[m], h2[m]);
+#endif
+}
+// (plain form, four pairs: the truncations by the compiler's own v_cvt_pkrtz_f16_f32, the residuals interleaved)
+__device__ __forceinline__ void td_split_h2_x4(const float (&x)[4], const float (&y)[4], unsigned (&h1)[4], unsigned (&h2)[4]) {
+#if TD_SPLIT_X4
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h1[m] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[m], y[m]));
+    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, -1.0, %9 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, -1.0, %11 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, -1.0, %12 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, -1.0, %14 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h2[0]), "=&v"(h2[1]), "=&v"(h2[2]), "=&v"(h2[3])
+        : "v"(h1[0]), "v"(h1[1]), "v"(h1[2]), "v"(h1[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+#else
+#pragma unroll
+    for (int m = 0; m < 4; ++m) td_split_h2(x[m], y[m], h1[m], h2[m]);
+#endif
 }
 
 constexpr float TD_ATT_SCALE_16 = 0.35355339059327373f;   // 1/sqrt(8)
@@ -256,7 +314,7 @@ __device__ __forceinline__ void td_row_gather16(const Args16 &a, int64_t i, int6
         const float *pj = a.P + (size_t)jj * (4 * TD_H) + a.p_off + TD_H + 4 * g;
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) {
-            const float4 v = *reinterpret_cast<const float4 *>(pj + 16 * hb);
+            const float4 v = TD_ABL == 5 ? make_float4(0.1f, 0.2f, -0.1f, 0.3f) : *reinterpret_cast<const float4 *>(pj + 16 * hb);
             acc[eb][hb][0] = v.x; acc[eb][hb][1] = v.y; acc[eb][hb][2] = v.z; acc[eb][hb][3] = v.w;
         }
     }
@@ -315,6 +373,10 @@ __device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, 
 // The same LayerNorm + ReLU with z'' leaving as f16 piece pairs for the value pass's aggregation product (td_split_h2): word r of
 // z1[hb] / z2[hb] = pieces of hidden unit 16hb + 4g + r for the lane's two edges (low half: edge lo, high half: edge 16 + lo) -- after the
 // flip through the wave's LDS tile a word is two K slots of the A operand.
+// SCALED: the pieces are taken of z'' 2^15 (td_split_h2_scaled: four conversions per pair); otherwise of z'' itself (three: a truncation and
+// two residuals, 30 % less conversion time) -- which the caller picks for MLPs whose folded scale M is small (TdEdgeMlp::z_plain, pack.cpp):
+// z'' is around 1 / M, and only above 2^-6 do the pieces of the plain form keep 19 bits or more over the f16 subnormal floor.
+template <bool SCALED>
 __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
                                                       uint4 (&z1)[8], uint4 (&z2)[8]) {
     float sc[2];
@@ -335,9 +397,14 @@ __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ 
         const float4 kb4 = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
         const float kb[4] = {kb4.x, kb4.y, kb4.z, kb4.w};
         unsigned w1[4], w2[4];
+        float za[4], zb[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            td_split_h2_scaled(td_clamp01(fmaf(acc[0][hb][r], sc[0], kb[r])), td_clamp01(fmaf(acc[1][hb][r], sc[1], kb[r])), w1[r], w2[r]);
+        for (int r = 0; r < 4; ++r) {
+            za[r] = td_clamp01(fmaf(acc[0][hb][r], sc[0], kb[r]));
+            zb[r] = td_clamp01(fmaf(acc[1][hb][r], sc[1], kb[r]));
+        }
+        if constexpr (SCALED) td_split_h2_scaled_x4(za, zb, w1, w2);
+        else td_split_h2_x4(za, zb, w1, w2);
         z1[hb] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
         z2[hb] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
     }
@@ -346,6 +413,7 @@ __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ 
 // ... and for the key pass's logits product, where z''^T is the B operand and the K slots run over hidden units: quad t of edge block eb
 // holds the hidden units 16 (2t + j / 4) + 4g + j % 4, j = 0 .. 7 (the two hidden blocks 2t, 2t + 1 of the lane), i.e. the pairs are
 // (r = 0, 1) and (r = 2, 3) of one accumulator tile.
+template <bool SCALED>
 __device__ __forceinline__ void td_ln_relu16_pairs_k(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
                                                      uint4 (&z1)[2][4], uint4 (&z2)[2][4]) {
     float sc[2];
@@ -363,23 +431,20 @@ __device__ __forceinline__ void td_ln_relu16_pairs_k(const float *__restrict__ K
     for (int eb = 0; eb < 2; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(sc[eb]), ln.c1, ln.c2));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        unsigned w1[2][4], w2[2][4];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int hb = 2 * t + h2;
-            const float4 kb = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
-#pragma unroll
-            for (int eb = 0; eb < 2; ++eb) {
-                td_split_h2_scaled(td_clamp01(fmaf(acc[eb][hb][0], sc[eb], kb.x)), td_clamp01(fmaf(acc[eb][hb][1], sc[eb], kb.y)),
-                                   w1[eb][2 * h2], w2[eb][2 * h2]);
-                td_split_h2_scaled(td_clamp01(fmaf(acc[eb][hb][2], sc[eb], kb.z)), td_clamp01(fmaf(acc[eb][hb][3], sc[eb], kb.w)),
-                                   w1[eb][2 * h2 + 1], w2[eb][2 * h2 + 1]);
-            }
-        }
+        const float4 kb0 = *reinterpret_cast<const float4 *>(KB + 16 * (2 * t) + 4 * g), kb1 = *reinterpret_cast<const float4 *>(KB + 16 * (2 * t + 1) + 4 * g);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
-            z1[eb][t] = make_uint4(w1[eb][0], w1[eb][1], w1[eb][2], w1[eb][3]);
-            z2[eb][t] = make_uint4(w2[eb][0], w2[eb][1], w2[eb][2], w2[eb][3]);
+            // pairs (r = 0, 1), (r = 2, 3) of the hidden blocks 2t, 2t + 1: x = the even member, y = the odd one
+            const float x[4] = {td_clamp01(fmaf(acc[eb][2 * t][0], sc[eb], kb0.x)), td_clamp01(fmaf(acc[eb][2 * t][2], sc[eb], kb0.z)),
+                                td_clamp01(fmaf(acc[eb][2 * t + 1][0], sc[eb], kb1.x)), td_clamp01(fmaf(acc[eb][2 * t + 1][2], sc[eb], kb1.z))};
+            const float y[4] = {td_clamp01(fmaf(acc[eb][2 * t][1], sc[eb], kb0.y)), td_clamp01(fmaf(acc[eb][2 * t][3], sc[eb], kb0.w)),
+                                td_clamp01(fmaf(acc[eb][2 * t + 1][1], sc[eb], kb1.y)), td_clamp01(fmaf(acc[eb][2 * t + 1][3], sc[eb], kb1.w))};
+            unsigned w1[4], w2[4];
+            if (TD_ABL == 3) { for (int m = 0; m < 4; ++m) { w1[m] = __float_as_uint(x[m]); w2[m] = __float_as_uint(y[m]); } }
+            else if constexpr (SCALED) td_split_h2_scaled_x4(x, y, w1, w2);
+            else td_split_h2_x4(x, y, w1, w2);
+            z1[eb][t] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+            z2[eb][t] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
         }
     }
 }
@@ -550,7 +615,7 @@ __device__ __forceinline__ void td_pk4_tiles(const uint4 *__restrict__ Rs, int l
             for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
                 const int tb = kind == 0 ? 3 : (kind == 1 ? 2 : 1 - pass);
 #pragma unroll
-                for (int eb = 0; eb < NEB; ++eb) acc[eb][hb] = td_mfma16b(cur, bq[eb][tb], acc[eb][hb]);
+                for (int eb = 0; eb < NEB; ++eb) { if (TD_ABL != 4) acc[eb][hb] = td_mfma16b(cur, bq[eb][tb], acc[eb][hb]); else acc[eb][hb][0] += __uint_as_float(cur.x ^ bq[eb][tb].y); }
             }
             cur = nxt;
         }
@@ -728,7 +793,10 @@ __device__ __forceinline__ void td_first_layer16(const Args16 &a, const float4 *
 constexpr int K16_WAVES = 16;      // key pass: 128 VGPRs -> 4 waves per SIMD, one LDS copy of the weights per CU
 constexpr int XV16_WAVES = 8;      // h2x value pass keeps the edge vectors live: 2 waves per SIMD, no spills
 constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 4) * sizeof(float);       // + the row counter
-constexpr int K16S_WAVES = 12;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
+#ifndef TD_KEY_WAVES
+#define TD_KEY_WAVES 12
+#endif
+constexpr int K16S_WAVES = TD_KEY_WAVES;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
 #ifndef TD_KEY_PK
 #define TD_KEY_PK 3
 #endif
@@ -752,7 +820,8 @@ static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the ro
 //             (max, sum) per head, then every lane re-reads its own entries and writes exp(x - max) / sum * gate.
 //             XV: delta_x accumulates over the chunks (scatter_sum, :139).
 // SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
-template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false>
+// ZPLAIN (f16 logits only): the launcher's reading of TdEdgeMlp::z_plain -- the pieces of z'' are taken unscaled (td_ln_relu16_pairs_k).
+template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false, bool ZPLAIN = false>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
@@ -938,7 +1007,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             Edge2 ed;
             first_layer(i, c0, acc, ed);
             uint4 zk1[2][4], zk2[2][4];
-            td_ln_relu16_pairs_k(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, zk1, zk2);
+            td_ln_relu16_pairs_k<!ZPLAIN>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, zk1, zk2);
             float4 q0 = qpre0, q1 = qpre1;
             float qm = fmaxf(fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))),
                              fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
@@ -953,6 +1022,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             uint4 pu1 = make_uint4(0u, 0u, 0u, 0u), pu2 = pu1;
             auto product = [&](int t, int m) {                  // product m of K block t: the small ones first, on their own accumulators
                 const int eb = m & 1, kind = m >> 1;
+                if (TD_ABL == 6) { lg[eb][0] += __uint_as_float(pu1.x ^ zk1[eb][t].x ^ pu2.y ^ zk2[eb][t].y); return; }
                 if (kind == 0) lgc[eb] = td_mfma16h(pu2, zk1[eb][t], lgc[eb]);
                 else if (kind == 1) lgc[eb] = td_mfma16h(pu1, zk2[eb][t], lgc[eb]);
                 else lg[eb] = td_mfma16h(pu1, zk1[eb][t], lg[eb]);
@@ -962,20 +1032,22 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) {
                 float4 n0 = w0, n1 = w1;
-                if (kk + 1 < 32) {
+                if (kk + 1 < 32 && TD_ABL != 2) {
                     n0 = Wq[((kk + 1) * 2 + 0) * 64 + lane];
                     n1 = Wq[((kk + 1) * 2 + 1) * 64 + lane];
                 }
                 __builtin_amdgcn_sched_barrier(0);         // the reads stay in front of this k-step's arithmetic
                 float u = w0.x * q0.x;
+                if (TD_ABL != 1) {
                 u = fmaf(w0.y, q0.y, u); u = fmaf(w0.z, q0.z, u); u = fmaf(w0.w, q0.w, u);
                 u = fmaf(w1.x, q1.x, u); u = fmaf(w1.y, q1.y, u); u = fmaf(w1.z, q1.z, u); u = fmaf(w1.w, q1.w, u);
+                } else u += w1.w;
                 uu[kk & 7] = u;
                 if (kk >= 8 && (kk & 7) < 6) product((kk >> 3) - 1, kk & 7);
                 if ((kk & 7) == 7) {
                     unsigned a1[4], a2[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) td_split_h2(uu[2 * m], uu[2 * m + 1], a1[m], a2[m]);
+                    const float ux[4] = {uu[0], uu[2], uu[4], uu[6]}, uy[4] = {uu[1], uu[3], uu[5], uu[7]};
+                    td_split_h2_x4(ux, uy, a1, a2);
                     pu1 = make_uint4(a1[0], a1[1], a1[2], a1[3]);
                     pu2 = make_uint4(a2[0], a2[1], a2[2], a2[3]);
                 }
@@ -986,7 +1058,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] += lgc[eb];
             floatx4_t pr[2];
-            td_softmax16x4(lg, ed.valid, ed.ew, pr, __builtin_amdgcn_ldexpf(TD_ATT_SCALE_16 / TD_Z_SCALE, qe - 13));
+            td_softmax16x4(lg, ed.valid, ed.ew, pr, __builtin_amdgcn_ldexpf(ZPLAIN ? TD_ATT_SCALE_16 : TD_ATT_SCALE_16 / TD_Z_SCALE, qe - 13));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
@@ -1439,7 +1511,7 @@ constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // (models/uni_transformer.py:36-37, 62-63).  v_e = W2v z_e + b2v is never formed here; the gate's logit is linear in it, so it is
 // (W2v^T w) . z_e + (w . b2v + b) -- one 128-wide dot product with a vector packed at model creation --, and since the gate multiplies v_e,
 // which enters the output linearly, it multiplies the attention weight instead: alpha_e e_w_e feeds both the aggregation and S.
-template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false>
+template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false, bool ZPLAIN = false>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
@@ -1768,12 +1840,13 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         float out_scale = 1.0f;
         if constexpr (L2H) {          // see edge_value16t_kernel; two tiles ping-pong here
             uint4 z1[8], z2[8];
-            td_ln_relu16_pairs_eb(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
+            td_ln_relu16_pairs_eb<!ZPLAIN>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
             uint4 aq1, aq2;
             {
                 unsigned p1[4], p2[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) td_split_h2(al[2 * m] * 1024.0f, al[2 * m + 1] * 1024.0f, p1[m], p2[m]);
+                const float ax[4] = {al[0] * 1024.0f, al[2] * 1024.0f, al[4] * 1024.0f, al[6] * 1024.0f};
+                const float ay[4] = {al[1] * 1024.0f, al[3] * 1024.0f, al[5] * 1024.0f, al[7] * 1024.0f};
+                td_split_h2_x4(ax, ay, p1, p2);
                 aq1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
                 aq2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
             }
@@ -1803,7 +1876,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
                 zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
             }
-            out_scale = 1.0f / (1024.0f * TD_Z_SCALE);
+            out_scale = ZPLAIN ? 1.0f / 1024.0f : 1.0f / (1024.0f * TD_Z_SCALE);
         } else {
         auto flip_store = [&](int hb) {
             float *t = TB + (hb & 1) * V16_TILE_FLOATS;
@@ -1889,6 +1962,7 @@ constexpr size_t V16T_LDS_BYTES =
     (size_t)(e16q_half_u4<V16T_PK>() * 4 + V16_W_FLOATS + V16T_WAVES * V16T_WAVE_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
 static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
 
+template <bool ZPLAIN>
 __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
     constexpr int WAVES = V16T_WAVES;
     constexpr int RF = e16q_half_u4<V16T_PK>() * 4;
@@ -2003,12 +2077,13 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         // activations keep their 22 bits above the f16 subnormal floor; the scales come off the two outputs.
         td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         uint4 z1[8], z2[8];
-        td_ln_relu16_pairs_eb(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
+        td_ln_relu16_pairs_eb<!ZPLAIN>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
         uint4 aq1, aq2;
         {
             unsigned p1[4], p2[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) td_split_h2(al[2 * m] * 1024.0f, al[2 * m + 1] * 1024.0f, p1[m], p2[m]);
+            const float ax[4] = {al[0] * 1024.0f, al[2] * 1024.0f, al[4] * 1024.0f, al[6] * 1024.0f};
+            const float ay[4] = {al[1] * 1024.0f, al[3] * 1024.0f, al[5] * 1024.0f, al[7] * 1024.0f};
+            td_split_h2_x4(ax, ay, p1, p2);
             aq1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
             aq2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
         }
@@ -2038,7 +2113,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
             zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
         }
-        constexpr float OUT_SCALE = 1.0f / (1024.0f * TD_Z_SCALE);
+        constexpr float OUT_SCALE = ZPLAIN ? 1.0f / 1024.0f : 1.0f / (1024.0f * TD_Z_SCALE);
 #else
         td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
@@ -2225,7 +2300,11 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
             a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
             TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
         } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES); }
-        else { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 0, true, K16S_LDS_BYTES); }
+        else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
+        else if (TD_L2_F16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 0, true, true>), K16S_LDS_BYTES);
+            edge_key16_kernel<false, K16S_WAVES, 0, 0, true, true><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
+        } else TD_KEY_LAUNCH(K16S_WAVES, 0, 0, true, K16S_LDS_BYTES);
     } else {
         if (cptr) { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 1, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 1, false, K16_LDS_BYTES); }
         else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 0, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 0, false, K16_LDS_BYTES); }
@@ -2286,10 +2365,18 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
             TD_LDS_ONCE((edge_value16_kernel<true, false, true>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
         } else if (a.deal == 2) {          // (the default) rows through the LDS ticket: the 12-wave kernel
-            TD_LDS_ONCE((edge_value16t_kernel), V16T_LDS_BYTES);
             int Gt = grid16(count, V16T_WAVES);
             if (Gt < 2 && a.lig_count > 0) Gt = 2;
-            edge_value16t_kernel<<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
+            if (mlp.z_plain && !TD_ZPLAIN_OFF) {
+                TD_LDS_ONCE((edge_value16t_kernel<true>), V16T_LDS_BYTES);
+                edge_value16t_kernel<true><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
+            } else {
+                TD_LDS_ONCE((edge_value16t_kernel<false>), V16T_LDS_BYTES);
+                edge_value16t_kernel<false><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
+            }
+        } else if (TD_L2_F16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
+            TD_LDS_ONCE((edge_value16_kernel<true, false, false, true>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, false, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
         } else {
             TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);

@@ -197,12 +197,15 @@ size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded) {
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2, w2_bound; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2, w2_bound; bool z_plain; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, int alt) {
     const MlpSrc m = fm.src();
     EdgeOff o;
     o.ln_c1 = fm.ln_c1; o.ln_c2 = fm.ln_c2;
+    // ln_c1 = M^2 / hid: the f16 second layer takes the pieces of z'' ~ 1 / M unscaled while M <= 32 (z'' of a typical unit then sits at
+    // 2^-5 or above: 20 bits over the f16 subnormal floor; beyond that the kernels scale by 2^15 first -- td_ln_relu16_pairs_*, edge16.hip)
+    o.z_plain = (double)fm.ln_c1 * TD_H <= 32.0 * 32.0;
     {
         float wmax = 0.f;
         for (size_t t = 0; t < (size_t)out_dim * TD_H; ++t) wmax = std::max(wmax, fabsf(m.w3[t]));
@@ -563,7 +566,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, o.z_plain, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,

@@ -65,6 +65,7 @@ struct TdEdgeMlp {
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     float w2_bound;        // key MLPs: 8 max |W2'| (folded second Linear): |U_i[n][head]| = |sum_d W2'[8 head + d][n] q_i[8 head + d]| <= w2_bound max |q_i|
                            // (the f16 logits product scales the query by a power of two from this bound, edge16.hip)
+    bool z_plain;          // f16 second layer: the folded scale M is at most TD_Z_PLAIN_MAX_M, take the f16 pieces of z'' itself (edge16.hip, td_ln_relu16_pairs_*)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
                            // shares, 1 dealt, 2 dealt + the workgroup's rows handed to its waves through an LDS counter)
