@@ -171,16 +171,21 @@ def seeded_state_dict(model, seed=2021):
     return sd
 
 
-CPU_THREADS = 16       # fastest of 8 / 16 / 32 / 64 / 128 torch threads on the 128-core MI355X host (1.2 / 1.6 / 3.5 / 7.5 s per
+CPU_THREADS = 16       # fastest of 8 / 16 / 32 / 64 / 128 torch threads on the 128-core MI355X host at 4 samples (1.2 / 1.6 / 3.5 / 7.5 s per
                        # step at 32 / 64 / 128: the small per-layer ops do not scale past one socket's worth of cores)
 
 
-def cpu_baseline(pocket, sizes, samples=4, steps=8, extrapolate=True):
-    """Oracle restatement on the host cores; bounded sample of the same workload (about 10 s of CPU work).
-    extrapolate=False: the sample IS a whole configuration (BASELINE config 1: 4 samples x 100 steps) and is reported as run."""
+def cpu_baseline(pocket, sizes, samples=None, steps=2, extrapolate=True, budget_s=20.0):
+    """Oracle restatement on the host cores over a bounded sample of the same workload AT ITS REAL BATCH: all the pocket's samples in one
+    packed batch (C2: 100 samples, 60,708 nodes), one timed reverse step and a second one if the first took under `budget_s` seconds
+    (about 20-60 s of CPU work; the warm-up runs on 4 samples).  The per-step figure is therefore not extrapolated across batch sizes;
+    only the 1000-step run length is.  extrapolate=False: the sample IS a whole configuration (BASELINE config 1: 4 samples x 100 steps)
+    and is reported as run."""
     from oracle import restatement as R
     from oracle import weights
     sd = weights.make_state_dict(2021)
+    if samples is None:
+        samples = len(sizes)
     b = workloads.pack_samples(pocket, samples, sizes[:samples])
     g = torch.Generator().manual_seed(0)
     lpos, lv = workloads.init_ligand(b, generator=g)
@@ -188,36 +193,63 @@ def cpu_baseline(pocket, sizes, samples=4, steps=8, extrapolate=True):
     noises = torch.randn(steps + 1, nl, 3, generator=g)
     unis = torch.rand(steps + 1, nl, 13, generator=g)
     prev = torch.get_num_threads()
-    cores = max(1, min(CPU_THREADS, os.cpu_count() or 1))
+    host_cores = os.cpu_count() or 1
+    cores = max(1, min(CPU_THREADS, host_cores))
     torch.set_num_threads(cores)
     try:
         args = (sd, None, b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos, lv,
                 b.ligand_element_batch)
-        R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)            # warm-up
-        t0 = time.time()
-        R.sample_diffusion(*args, num_steps=steps, noises=noises, uniforms=unis)
-        sec_per_step = (time.time() - t0) / steps
+        if extrapolate:               # warm-up on a small batch of the same pocket (thread pool, allocator)
+            wb = workloads.pack_samples(pocket, 4, sizes[:4])
+            wpos, wv = workloads.init_ligand(wb, generator=torch.Generator().manual_seed(1))
+            wn = wpos.shape[0]
+            R.sample_diffusion(sd, None, wb.protein_pos, wb.protein_atom_feature.float(), wb.protein_element_batch, wpos, wv,
+                               wb.ligand_element_batch, num_steps=1, noises=torch.zeros(2, wn, 3), uniforms=torch.full((2, wn, 13), 0.5))
+            t0 = time.time()
+            R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)
+            first = time.time() - t0
+            timed, total = 1, first
+            if first < budget_s and steps > 1:
+                t0 = time.time()
+                R.sample_diffusion(*args, num_steps=steps - 1, noises=noises, uniforms=unis)
+                total += time.time() - t0
+                timed = steps
+            steps = timed
+            sec_per_step = total / timed
+        else:
+            R.sample_diffusion(*args, num_steps=1, noises=noises, uniforms=unis)            # warm-up
+            t0 = time.time()
+            R.sample_diffusion(*args, num_steps=steps, noises=noises, uniforms=unis)
+            sec_per_step = (time.time() - t0) / steps
     finally:
         torch.set_num_threads(prev)
-    res = {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'kind': 'port',
-           'sample': f'oracle/restatement.py (torch CPU fp32, {cores} threads = the fastest setting on this host), same pocket, '
-                     f'{samples} samples x {steps} steps ({b.protein_pos.shape[0] + nl} nodes), {sec_per_step:.2f} s/step, '
-                     f'extrapolated to 1000 steps'}
+    res = {'value': samples / (1000.0 * sec_per_step), 'unit': 'ligands/s', 'cores': cores, 'cores_of_host': f'{cores} of {host_cores}',
+           'kind': 'port',
+           'sample': f'oracle/restatement.py (torch CPU fp32, {cores} of the host\'s {host_cores} cores = the fastest thread count on the MI355X host), '
+                     f'the same pocket at the workload\'s real batch: {samples} samples in one packed batch ({b.protein_pos.shape[0] + nl} nodes) x '
+                     f'{steps} reverse step(s), {sec_per_step:.2f} s/step; only the run length (1000 steps) is extrapolated'}
     if not extrapolate:
         res['sample'] = (f'BASELINE config 1 in full: oracle/restatement.py (torch CPU fp32, {cores} threads), 1h36 pocket x {samples} '
                          f'samples x {steps} steps run to completion in {sec_per_step * steps:.1f} s ({sec_per_step:.2f} s/step); value = '
                          f'the same rate expressed per 1000-step ligand')
         res['config1_wall_s'] = sec_per_step * steps
     # the REAL reference cannot run on the GPU box (/root/reference is not there): its own timing, taken in the build container
-    # by tools/cpu_reference.py on BASELINE config 1 in full, is quoted beside the port's figure
+    # by tools/cpu_reference.py on BASELINE config 1 in full, is quoted beside the port's figure, and what the port's figure on THIS host
+    # would read for the real reference at the ratio measured there (same host, same inputs) is stated under a name that says so
     ref_path = os.path.join(ROOT, 'profiles', 'r03_cpu_reference_c1.json')
     if os.path.exists(ref_path):
         with open(ref_path) as f:
             rj = json.load(f)
+        ratio = rj.get('port_same_inputs', {}).get('reference_over_port')
         res['reference_cpu'] = {'source': 'profiles/r03_cpu_reference_c1.json (tools/cpu_reference.py, build container)',
                                 'config': rj['config'], 'host': rj['host'], 'threads': rj['threads'], 'wall_s': rj['wall_s'],
                                 's_per_step': rj['s_per_step'], 'ligands_per_s': rj['ligands_per_s_per_1000_step_ligand'],
-                                'reference_over_port_same_host': rj.get('port_same_inputs', {}).get('reference_over_port')}
+                                'reference_over_port_same_host': ratio}
+        if ratio:
+            res['estimated_reference_ligands_per_s'] = res['value'] / ratio
+            res['estimated_reference_note'] = (f'value / {ratio:.2f}: the REAL reference (models/molopt_score_model.py:633-703) took {ratio:.2f} x the '
+                                               'port\'s time on the same host and inputs (build container, BASELINE config 1 in full); the reference tree '
+                                               'does not exist on the GPU box, so this is an estimate, not a measurement')
         res['sample'] += (f"; the REAL reference on the build container's {rj['threads']} threads: config 1 in full in "
                           f"{rj['wall_s']:.0f} s ({rj['s_per_step']:.2f} s/step)")
     return res
@@ -362,16 +394,21 @@ def run_c4(args, model, dev, rank, world, fence):
     mine = workloads.partition_pockets(len(pockets), world, rank)
     total = args.warmup + args.steps
     samplers, nodes = [], 0
+    bs = args.batch_size if args.batch_size and args.batch_size > 0 else spp       # scripts/batch_sample_diffusion.sh:2 runs BATCH_SIZE=50
     for i in mine:
         pdev = workloads.DevicePocket(pockets[i], dev)
-        batch = workloads.pack_samples_device(pdev, spp, sizes)
-        gen = torch.Generator(device='cpu').manual_seed(2021 + i)
-        lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets[i], spp, sizes), generator=gen, spread=args.ligand_spread)
-        samplers.append(model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
-                                             lpos.to(dev), lv.to(dev), batch.ligand_element_batch, num_steps=total,
-                                             center_pos_mode='protein', max_graph_nodes=pockets[i].num_atoms + max(sizes),
-                                             use_session=not args.no_session))
-        nodes += int(batch.protein_pos.shape[0] + lpos.shape[0])
+        # the pocket's samples in batches of `bs`, one after the other as scripts/sample_diffusion.py:38-41 runs them (a session each)
+        for b0 in range(0, spp, bs):
+            nb = min(bs, spp - b0)
+            bsizes = sizes[b0:b0 + nb]
+            batch = workloads.pack_samples_device(pdev, nb, bsizes)
+            gen = torch.Generator(device='cpu').manual_seed(2021 + i + 7919 * b0)
+            lpos, lv = workloads.init_ligand(workloads.pack_samples(pockets[i], nb, bsizes), generator=gen, spread=args.ligand_spread)
+            samplers.append(model.begin_sampling(batch.protein_pos, batch.protein_atom_feature.float(), batch.protein_element_batch,
+                                                 lpos.to(dev), lv.to(dev), batch.ligand_element_batch, num_steps=total,
+                                                 center_pos_mode='protein', max_graph_nodes=pockets[i].num_atoms + max(bsizes),
+                                                 use_session=not args.no_session))
+            nodes += int(batch.protein_pos.shape[0] + lpos.shape[0])
     for sm in samplers:
         for _ in range(args.warmup):
             sm.step()
@@ -398,7 +435,7 @@ def run_c4(args, model, dev, rank, world, fence):
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sec_per_step * 1e3, 'higher_is_better': True,
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic (seeded random weights of the reference architecture; synthetic pockets; k-NN rule parity-unpinned upstream)',
-        'config': {'workload': desc, 'ligand_spread': args.ligand_spread, 'pockets_total': len(pockets),
+        'config': {'workload': desc, 'batch_size': bs, 'batches_per_pocket': (spp + bs - 1) // bs, 'ligand_spread': args.ligand_spread, 'pockets_total': len(pockets),
                    'pockets_this_rank': len(mine), 'nodes_rank0': nodes,
                    'parallelism': f'pocket i -> rank i % {world} (no data-path collective)'},
         'load_balance': {'per_rank_seconds': per_rank, 'max_over_mean': max(per_rank) / (sum(per_rank) / len(per_rank))},
@@ -414,6 +451,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c2', choices=['c1', 'c2', 'c3', 'c4', 'c5'])
+    ap.add_argument('--batch-size', type=int, default=0, help='c4: samples per batch of a pocket (0 = all 100 in one batch; scripts/batch_sample_diffusion.sh '
+                    'runs BATCH_SIZE=50, the signature of sample_diffusion_ligand defaults to 16); the batches of a pocket run one after the other')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-full', action='store_true', help='time the CPU baseline on BASELINE config 1 in full (4 samples x 100 '
                     'steps, ~2-5 min of host time) instead of the bounded sample')
@@ -543,6 +582,7 @@ def main():
     slots_val = 32 * (cpn - 1) + (16 if (cpn > 1 and last <= 16 and args.cutoff_mode == 'knn') else 32)
     flop_val = 2 * (slots_val * 128 * 20 + slots_val * 128 * 16) + 2 * 128 * 128
     split = bool(model._native(dev).get_option('edge_key_split'))
+    l2_f16 = bool(model._native(dev).get_option('edge_second_layer_f16')) and split and default_graph
 
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]
@@ -557,7 +597,12 @@ def main():
         # on piece triples (32-slot rows only; the chunked value pass keeps fp32), the rest at the fp32 peak
         first_alg = 2 * min(fan_in, 32) * 128 * 20 * (cpn if fan_in > 32 else 1)
         split_here = split and (default_graph or cls == 'x2h_k')
-        if split_here:
+        if split_here and l2_f16:
+            # + the second layer (logits / alpha^T z: 2 * 32 * 128 * 16 algorithmic FLOPs) as three f16 piece products at the 16-bit peak
+            second_alg = 2 * min(fan_in, 32) * 128 * 16
+            t_min = (FIRST_LAYER_FLOP_BF16_EXECUTED + 3 * 2 * 32 * 128 * 16) / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg - second_alg) / PEAK_FP32_MFMA_TFLOPS
+            bound = per_row / t_min
+        elif split_here:
             t_min = cpn * FIRST_LAYER_FLOP_BF16_EXECUTED / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
             bound = per_row / t_min
         else:
@@ -584,6 +629,8 @@ def main():
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
                 'first_layer': 'bf16 x 3 piece triples, K-packed: 4 x v_mfma_f32_16x16x32_bf16 per tile' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
+                'second_layer': ('f16 piece pairs (22 bits per operand), 3 x v_mfma_f32_16x16x32_f16 per tile; the per-row 128 x 128 product on the vector unit'
+                                 if (split_here and l2_f16) else 'fp32 (v_mfma_f32_16x16x4_f32); the per-row 128 x 128 product on the vector unit'),
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
                 'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
@@ -593,7 +640,7 @@ def main():
                 'share_of_step': (p['ms'] / prof_steps) / (sec_per_step * 1e3), 'profiled_steps': prof_steps}
 
     if default_graph:
-        vk, kk = (('edge_value16t_kernel<12 waves>', 'edge_key16_kernel<false, 12, 0, 0, true>') if split
+        vk, kk = (('edge_value16t_kernel<L2> (12 waves)', 'edge_key16_kernel<false, 12, 0, 0, true, L2>') if split
                   else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, 0, false>'))
     else:
         vk = 'edge_value16_kernel<true, true> (chunk-walking)'
@@ -627,11 +674,14 @@ def main():
           'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
         + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
            f'(fp32-equivalent: errors against the reference golden unchanged, {split_error_table()})')
-        + ('; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split' if split else '') + ')',
+        + ('; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split' if split else '')
+        + ('; their per-edge second-layer products (logits, alpha^T z) on f16 piece pairs: operands carried to 22 bits, within one to two fp32 '
+           'roundings of the fp32 products (tests/test_gpu_weight_regimes.py holds both forms to the same goldens)' if l2_f16 else '') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
                    'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
+                   'edge_second_layer': 'f16 piece pairs of both operands (22 significant bits each), fp32 accumulate' if l2_f16 else 'fp32 MFMA',
                    'step_launch': step_launch, 'build_tag': capi.build_tag(),
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,

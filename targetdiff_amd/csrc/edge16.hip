@@ -33,10 +33,8 @@ __device__ __forceinline__ floatx4_t td_mfma16(float a, float b, floatx4_t c) {
 // every operand is carried to 22 significant bits, and never worse than 2^-25 of the operand's scale (f16 subnormals, which the
 // instruction honours exactly: tools/microbench/f16_split_probe.hip); the dropped product h2 h2' is below 2^-22 relative.  The fp32 form
 // rounds each of its 128 (32) partial sums to 24 bits, so the two differ by about one fp32 rounding of the result -- measured on the
-// goldens of the real reference incl. its float64 runs (profiles/r06*_second_layer_error.txt).  TD_L2_F16 = 0 builds the fp32 form.
-#ifndef TD_L2_F16
-#define TD_L2_F16 1
-#endif
+// goldens of the real reference incl. its float64 runs (profiles/r06*_second_layer_error.txt).  Model option "edge_second_layer_f16"
+// (default 1; 0 = the fp32 products) selects between the instantiations.
 #ifndef TD_ZPLAIN_OFF
 #define TD_ZPLAIN_OFF 0   // 1: every MLP takes the scaled pieces (A/B of the two conversions)
 #endif
@@ -820,14 +818,17 @@ static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the ro
 //             (max, sum) per head, then every lane re-reads its own entries and writes exp(x - max) / sum * gate.
 //             XV: delta_x accumulates over the chunks (scatter_sum, :139).
 // SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
-// ZPLAIN (f16 logits only): the launcher's reading of TdEdgeMlp::z_plain -- the pieces of z'' are taken unscaled (td_ln_relu16_pairs_k).
-template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false, bool ZPLAIN = false>
+// L2 (x2h key pass of the default graph, bf16 first layer): the logits product -- 0: fp32 (v_mfma_f32_16x16x4_f32), 1: f16 piece pairs
+// with z'' scaled by 2^15, 2: f16 piece pairs of z'' itself (the launcher's reading of TdEdgeMlp::l2_f16 / z_plain).
+template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false, int L2 = 0>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
+    constexpr bool ZPLAIN = L2 == 2;
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
     // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass of the default graph.  (General graphs and the unfused h2x
     // key pass keep the fp32 product: their session / stateless / fused forms run different kernels on the same rows and are held bit-identical.)
-    constexpr bool L2H = TD_L2_F16 != 0 && SPLIT && !XV && GRAPH == 0 && STAGE == 0;
+    constexpr bool L2H = L2 != 0;
+    static_assert(L2 == 0 || (SPLIT && !XV && GRAPH == 0 && STAGE == 0), "f16 logits: x2h key pass of the default graph only");
     constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1511,13 +1512,15 @@ constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // (models/uni_transformer.py:36-37, 62-63).  v_e = W2v z_e + b2v is never formed here; the gate's logit is linear in it, so it is
 // (W2v^T w) . z_e + (w . b2v + b) -- one 128-wide dot product with a vector packed at model creation --, and since the gate multiplies v_e,
 // which enters the output linearly, it multiplies the attention weight instead: alpha_e e_w_e feeds both the aggregation and S.
-template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false, bool ZPLAIN = false>
+template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false, int L2 = 0>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
+    constexpr bool ZPLAIN = L2 == 2;
     constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     // the aggregation product on f16 piece pairs, exactly as in edge_value16t_kernel (the row distribution settings select between the two
     // kernels and stay bit-identical): the default graph's bf16-first-layer instantiation
-    constexpr bool L2H = TD_L2_F16 != 0 && SPLIT && !CHUNKED && !GATE_M;
+    constexpr bool L2H = L2 != 0;
+    static_assert(L2 == 0 || (SPLIT && !CHUNKED && !GATE_M), "f16 aggregation: the default graph's bf16-first-layer instantiation only");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
@@ -1962,8 +1965,10 @@ constexpr size_t V16T_LDS_BYTES =
     (size_t)(e16q_half_u4<V16T_PK>() * 4 + V16_W_FLOATS + V16T_WAVES * V16T_WAVE_FLOATS + 2 * TD_H + 4 + 32) * sizeof(float);
 static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
 
-template <bool ZPLAIN>
+// L2: the aggregation product -- 0 fp32, 1 f16 piece pairs of z'' 2^15, 2 f16 piece pairs of z'' (see edge_key16_kernel)
+template <int L2>
 __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
+    constexpr bool ZPLAIN = L2 == 2;
     constexpr int WAVES = V16T_WAVES;
     constexpr int RF = e16q_half_u4<V16T_PK>() * 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -2037,23 +2042,18 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         if (((__builtin_amdgcn_readfirstlane(__float_as_int(rin.xi.w)) > __float_as_int(0.5f)) ? 0 : 1) != my_cls) continue;
         floatx4_t acc[2][8];
         td_row_gather16<false>(a, i, i, lane, rin, acc);
-#if TD_L2_F16
-        // B operand of the aggregation product, K slots (g, 2m) / (g, 2m + 1) = edges 4g + m / 16 + 4g + m (the pairing the flipped z''
-        // words have): alpha[edge][head lo], two 16-byte loads
         float al[8];
-        {
+        if constexpr (L2 != 0) {
+            // B operand of the aggregation product, K slots (g, 2m) / (g, 2m + 1) = edges 4g + m / 16 + 4g + m (the pairing the flipped z''
+            // words have): alpha[edge][head lo], two 16-byte loads
             const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 4 * g;
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 16);
             al[0] = v0.x; al[1] = v1.x; al[2] = v0.y; al[3] = v1.y; al[4] = v0.z; al[5] = v1.z; al[6] = v0.w; al[7] = v1.w;
-        }
-#else
-        float al[8];
-        {   // A operand of the aggregation product: alpha[edge 8g + s][head lo]
+        } else {   // A operand of the aggregation product: alpha[edge 8g + s][head lo]
             const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
             al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
         }
-#endif
         const float hres0 = a.h[(size_t)i * TD_H + nout], hres1 = a.h[(size_t)i * TD_H + nout + 4];
         Edge2 ed;
         float offr[8];
@@ -2067,7 +2067,8 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         float ssum = ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
         ssum = td_sum_groups(ssum);                    // S[head lo] = sum over the 32 edges, in every lane group
         floatx4_t zb[8];
-#if TD_L2_F16
+        constexpr float OUT_SCALE = L2 == 0 ? 1.0f : (ZPLAIN ? 1.0f / 1024.0f : 1.0f / (1024.0f * TD_Z_SCALE));
+        if constexpr (L2 != 0) {
         // Zbar^T on v_mfma_f32_16x16x32_f16: zb[hb][r] = 2^10 sum_e z''[e][16hb + 4g + r] alpha[e][head lo], K = the row's 32 edges in ONE
         // instruction per piece product and hidden block.  z'' leaves the LayerNorm as two f16 pieces, the lane's two edges in one word
         // (td_ln_relu16_pairs_eb); the flip through the wave's tile moves WORDS: lane (edge lo, g) stores its four hidden units 4g .. 4g + 3 of
@@ -2113,8 +2114,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
             zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
         }
-        constexpr float OUT_SCALE = ZPLAIN ? 1.0f / 1024.0f : 1.0f / (1024.0f * TD_Z_SCALE);
-#else
+        } else {
         td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
         auto flip_store = [&](int hb) {
@@ -2141,8 +2141,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
 #pragma unroll
             for (int sx = 0; sx < 8; ++sx) zb[hb] = td_mfma16(bvb[hb & 1][sx], al[sx], zb[hb]);
         }
-        constexpr float OUT_SCALE = 1.0f;
-#endif
+        }
         // out[n] = W2v[n, :] . Zbar[head(n), :] + b2v[n] S[head(n)];  h_i += out   (td_value_out16: this lane's outputs nout, nout + 4)
         float o0, o1;
         td_value_out16(zb, Wt_lane, o0, o1);
@@ -2301,10 +2300,17 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
             TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
         } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES); }
         else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
-        else if (TD_L2_F16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
-            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 0, true, true>), K16S_LDS_BYTES);
-            edge_key16_kernel<false, K16S_WAVES, 0, 0, true, true><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a);
-        } else TD_KEY_LAUNCH(K16S_WAVES, 0, 0, true, K16S_LDS_BYTES);
+        else {
+#define TD_KEY_LAUNCH_L2(L2V)                                                                                                     \
+            do {                                                                                                                  \
+                TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 0, true, L2V>), K16S_LDS_BYTES);                             \
+                edge_key16_kernel<false, K16S_WAVES, 0, 0, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+            } while (0)
+            if (!mlp.l2_f16) TD_KEY_LAUNCH_L2(0);
+            else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_L2(2);
+            else TD_KEY_LAUNCH_L2(1);
+#undef TD_KEY_LAUNCH_L2
+        }
     } else {
         if (cptr) { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 1, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 1, false, K16_LDS_BYTES); }
         else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 0, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 0, false, K16_LDS_BYTES); }
@@ -2367,16 +2373,21 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
         } else if (a.deal == 2) {          // (the default) rows through the LDS ticket: the 12-wave kernel
             int Gt = grid16(count, V16T_WAVES);
             if (Gt < 2 && a.lig_count > 0) Gt = 2;
-            if (mlp.z_plain && !TD_ZPLAIN_OFF) {
-                TD_LDS_ONCE((edge_value16t_kernel<true>), V16T_LDS_BYTES);
-                edge_value16t_kernel<true><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
-            } else {
-                TD_LDS_ONCE((edge_value16t_kernel<false>), V16T_LDS_BYTES);
-                edge_value16t_kernel<false><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);
-            }
-        } else if (TD_L2_F16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
-            TD_LDS_ONCE((edge_value16_kernel<true, false, false, true>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, false, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+#define TD_V16T_LAUNCH(L2V)                                                                              \
+            do {                                                                                            \
+                TD_LDS_ONCE((edge_value16t_kernel<L2V>), V16T_LDS_BYTES);                                   \
+                edge_value16t_kernel<L2V><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);       \
+            } while (0)
+            if (!mlp.l2_f16) TD_V16T_LAUNCH(0);
+            else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_V16T_LAUNCH(2);
+            else TD_V16T_LAUNCH(1);
+#undef TD_V16T_LAUNCH
+        } else if (mlp.l2_f16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
+            TD_LDS_ONCE((edge_value16_kernel<true, false, false, 2>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, false, false, 2><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+        } else if (mlp.l2_f16) {
+            TD_LDS_ONCE((edge_value16_kernel<true, false, false, 1>), V16S_LDS_BYTES);
+            edge_value16_kernel<true, false, false, 1><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
         } else {
             TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);

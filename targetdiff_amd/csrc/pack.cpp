@@ -566,7 +566,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, o.z_plain, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, m->opt.edge_second_layer_f16 != 0, o.z_plain, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
@@ -629,6 +629,10 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
             m->layers[l].xk.use_split = m->layers[l].xk.R16q && value != 0;
             m->layers[l].xv.use_split = m->layers[l].xv.R16q && value != 0;
         }
+    } else if (strcmp(name, "edge_second_layer_f16") == 0) {
+        m->opt.edge_second_layer_f16 = value != 0;
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l)
+            m->layers[l].hk.l2_f16 = m->layers[l].hv.l2_f16 = m->layers[l].xk.l2_f16 = m->layers[l].xv.l2_f16 = value != 0;
     } else if (strcmp(name, "session_hop_levels") == 0) {
         if (value < 1 || value > TD_HOP_LEVELS) { td_set_error("td_model_set_option: session_hop_levels must be 1..%d", TD_HOP_LEVELS); return TD_EINVAL; }
         m->opt.session_hop_levels = value;
@@ -647,6 +651,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     else if (strcmp(name, "node_proj_bpipe") == 0) *value = m->opt.node_proj_bpipe;
     else if (strcmp(name, "edge_row_dealing") == 0) *value = m->opt.edge_row_dealing;
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
+    else if (strcmp(name, "edge_second_layer_f16") == 0) *value = m->opt.edge_second_layer_f16;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
     else if (strcmp(name, "session_step_lists") == 0) *value = m->opt.session_step_lists;

@@ -414,6 +414,31 @@ def test_sampling_with_fp32_edge_first_layer(state_dict):
     close(torch.stack(res[(1, True)]['pos_traj']), torch.stack(res[(0, True)]['pos_traj']), 5e-5)
 
 
+def test_sampling_with_fp32_second_layer(state_dict):
+    """edge_second_layer_f16 = 0 (logits and alpha^T z on the fp32 matrix instruction instead of f16 piece pairs) stays a tested path: 5 reverse
+    steps through the session and the stateless forward against the default -- same types, positions within the sampling tolerance, session ==
+    stateless bit for bit under either setting.  (That the option is live -- the two settings do not produce identical features -- is asserted in
+    tests/test_gpu_weight_regimes.py::test_forward_weight_regimes_vs_reference.)"""
+    from oracle import draws
+    from oracle.make_golden_r2 import hybrid_small_batch
+    dev = _dev()
+    b, lpos, lv = hybrid_small_batch()
+    bd = b.to(dev)
+    res = {}
+    for l2 in (1, 0):
+        for use_session in (True, False):
+            model = _model(state_dict)
+            assert model._native(dev).get_option('edge_second_layer_f16') == 1            # shipped default
+            model._native(dev).set_option('edge_second_layer_f16', l2)
+            res[(l2, use_session)] = model.sample_diffusion(
+                bd.protein_pos, bd.protein_atom_feature.float(), bd.protein_element_batch, lpos.to(dev), lv.to(dev),
+                bd.ligand_element_batch, num_steps=5, center_pos_mode='protein', noise_source=draws.Source(77, dev),
+                use_session=use_session)
+        assert torch.equal(res[(l2, True)]['pos'], res[(l2, False)]['pos'])
+    assert torch.equal(torch.stack(res[(1, True)]['v_traj']), torch.stack(res[(0, True)]['v_traj']))
+    close(torch.stack(res[(1, True)]['pos_traj']), torch.stack(res[(0, True)]['pos_traj']), 5e-5)
+
+
 @pytest.mark.parametrize('seed,gain', [(7, 1.8), (11, 0.5)])
 def test_forward_other_weight_scales_vs_reference(seed, gain):
     """Parity must not depend on the one seeded weight set the fixtures use: other seeds and weight scales (stronger /
