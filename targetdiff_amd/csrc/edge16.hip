@@ -1450,7 +1450,8 @@ constexpr int V16_TB_STRIDE = 20;                         // [32 edges][16 hidde
 constexpr int V16_TILE_FLOATS = 32 * V16_TB_STRIDE + 4 * 16;
 __device__ __forceinline__ int td_tile_row16(int e) { return e * V16_TB_STRIDE + (e >> 3) * 16; }
 constexpr int V16_WAVE_FLOATS = 2 * V16_TILE_FLOATS;      // two transpose tiles
-constexpr int V16_SB_FLOATS = 48;                         // per wave: S[16 heads] + the 32 edges' 1 / sigma (td_ln_relu16) on their way to the A operand
+constexpr int V16_SB_FLOATS = 48;                         // per wave (8-wave kernel): 16 spare floats + RS[32]: the 32 edges' gates of the GATE_M form (scale_edges) on
+                                                          // their way from the z^T lanes to the A operand's lanes (the folded LayerNorm left no 1 / sigma to carry)
 // ---- out[n] = W2v[n, :] . Zbar[head(n), :] (n = 8 head + d), the value pass's per-row output product ------------------------------------
 // The aggregation product runs with z as the A operand, so the accumulators hold Zbar^T: zt[hb][r] = Zbar[head lo][hidden 16hb + 4g + r].
 // A lane then owns 32 of its head's 128 Zbar values and needs no exchange through LDS (the form with Zbar in the accumulator rows wrote it
@@ -2169,7 +2170,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
 // K-packed table, bias, LayerNorm affine and output weights in LDS), LayerNorm + ReLU in the transposed layout, then each lane
 // dots its 32 hidden units of an edge with w3 and the four lane groups add up.
 constexpr int TD_GATE_WGS = 1024;   // four 4-wave workgroups per CU (110 VGPRs, 25.5 KiB LDS each): gate 0.043 -> 0.038 ms per C2 step against three
-constexpr int G16_WAVES = 4;        // three 4-wave workgroups per CU
+constexpr int G16_WAVES = 4;        // 4-wave workgroups, TD_GATE_WGS / 256 = four of them per CU
 constexpr int G16Q_U4 = e16q_cs_u4<1>();                                // the gate's K-packed table (QA, QB, QC): 24 KiB
 constexpr size_t G16_LDS_BYTES = (size_t)G16Q_U4 * 16 + (size_t)3 * TD_H * sizeof(float);
 

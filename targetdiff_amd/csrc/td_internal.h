@@ -53,7 +53,7 @@ inline int td_set_lds(TdLdsOnce &once, const void *fn, size_t bytes) {
 struct TdEdgeMlp {
     const float *R;        // [2 dst class][2 slot][12 kstep][64 lane][4 ntile]  first-layer radial+type B fragments
     // (every table below comes from the MLP with its LayerNorm folded into the two Linears: FoldedMlp, pack.cpp)
-    const float *gamma;    // [128] |LayerNorm weight| (already inside the second Linear's columns; not read by the kernels)
+    const float *gamma;    // [128] |LayerNorm weight| x the folded scale M (0 for a dead unit): already inside the second Linear's columns; not read by the kernels
     const float *beta;     // [128] LayerNorm bias / (|LayerNorm weight| M): z'' = clamp_[0,1](centred pre-activation / (sigma M) + beta)
     const float *W2;       // out=128: [64 kstep][64 lane][4 ntile];  out=16 (xv): [64 kstep][64 lane] (cols >= 16 zero)
     const float *b2;       // [128] or [16]

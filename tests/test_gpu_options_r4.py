@@ -127,7 +127,7 @@ def test_two_blocks_vs_reference():
 
 def test_layernorm_weights_of_every_sign_vs_reference():
     """The edge MLPs' LayerNorm is folded into their Linears at pack time (csrc/pack.cpp FoldedMlp: centred first Linear, the sign of the
-    LayerNorm weight in its rows, |weight| in the second Linear's columns, 1 / sigma applied by the consumer).  The seeded weights are all
+    LayerNorm weight in its rows, |weight| x the folded scale M in the second Linear's columns, the ReLU as the FMA's clamp: nothing per edge for the consumer).  The seeded weights are all
     positive; this fixture of the real reference (oracle/make_golden_r4.py) has negative, zero and tiny LayerNorm weights in every MLP.
     Both first-layer variants (bf16 piece triples, fp32), the stateless forward and a session's."""
     from oracle import weights
