@@ -128,6 +128,10 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
  *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with
  *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only
+ *   "session_share_pockets"  1 (default): a sampling session on the default graph keeps its static tables (protein-only sorted k-NN keys and lists,
+ *                            cached gate rows, embeddings, layer-0 / layer-1 outputs of the protein-only graph) once per DISTINCT protein block
+ *                            of the batch -- all samples of a pocket carry the same block (scripts/sample_diffusion.py:42) -- found by a hash +
+ *                            bitwise comparison at td_session_create; same results bit for bit; 0 = once per graph
  *   "session_step_lists"     1 (default): the row lists of a session step come from one launch (a workgroup per graph);
  *                            0 = the separate list kernels (also used when a graph exceeds 12288 nodes) */
 int td_model_set_option(td_model *m, const char *name, int32_t value);
@@ -300,7 +304,8 @@ int td_session_step_graph(const td_session *s);
  * displaced protein rows), counts[2 + k] = size of receptive-field level k + 1 of the ligand outputs (level 1 = ligand
  * atoms + their neighbours, level k + 1 = level k + its neighbours; the layer e from the end updates level e + 1 only),
  * -1 for levels the session does not track (k < 4); counts[6] = rows of layer 1 inside the ligand's one-hop forward reach
- * (the others keep the protein-only graph's cached layer-1 output), -1 when off; synchronises */
+ * (the others keep the protein-only graph's cached layer-1 output), -1 when off; counts[7] = rows of the session's static tables and
+ * counts[8] = distinct protein blocks of the batch when the tables are shared per pocket ("session_share_pockets"), -1 otherwise; synchronises */
 int td_session_row_counts(td_session *s, int32_t *host_counts, int32_t n_counts, void *stream);
 
 /* ---- kernel timers (measurement only; process-global: one set of timers for all models and streams of the process.  Launches from

@@ -297,7 +297,7 @@ class NativeModel:
     # ------------------------------------------------------------------------------------------
     @_device_bound
     def set_option(self, name: str, value: int):
-        """Per-model switch (td_model_set_option): 'node_proj_split', 'edge_key_split', 'edge_second_layer_f16', 'h2x_fused', 'session_hop_levels',
+        """Per-model switch (td_model_set_option): 'node_proj_split', 'edge_key_split', 'edge_second_layer_f16', 'h2x_fused', 'session_share_pockets', 'session_hop_levels',
         'session_forward_reach', 'session_step_lists'.  Stored in the native handle; nothing is read from the environment."""
         _check(self.lib.td_model_set_option(self.handle, name.encode(), int(value)), 'td_model_set_option')
 
@@ -561,10 +561,16 @@ class NativeSession:
         v = int(self._counts()[6])
         return v if v >= 0 else None
 
+    def shared_static_tables(self):
+        """(rows of the static tables, distinct protein blocks of the batch) when the session keeps its static tables once per pocket
+        (all samples of a pocket carry the same protein block; model option ``session_share_pockets``), else None."""
+        n = self._counts()
+        return (int(n[7]), int(n[8])) if n[7] >= 0 else None
+
     @_device_bound
     def _counts(self):
-        n = (c_int32 * 8)()
-        _check(self.lib.td_session_row_counts(self.handle, n, 8, _stream(self.device)), 'td_session_row_counts')
+        n = (c_int32 * 10)()
+        _check(self.lib.td_session_row_counts(self.handle, n, 10, _stream(self.device)), 'td_session_row_counts')
         return n
 
     def dirty_rows(self) -> int:

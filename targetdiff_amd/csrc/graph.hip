@@ -218,10 +218,15 @@ int td_launch_knn_static(const float4 *x4, const int32_t *node_ptr, const int32_
 // list.  If no ligand atom beats the 32nd static neighbour the row is unchanged ("clean"): its gate row and its
 // layer-0 output are step-invariant too and are copied from the session cache instead of being recomputed.
 // One wave per protein row.  Ligand rows of a graph are contiguous: [node_ptr[g] + n_prot(g), node_ptr[g+1]).
+// cgraph / cbase (a session that shares its static tables between the replicas of a pocket, session.cpp): graph g's protein block is a bitwise
+// copy of graph cgraph[g]'s (the first such graph of the batch: cgraph[g] <= g), whose rows sit at cbase[g] .. in the COMPACT static tables
+// skeys / snbr / ews / h0 / h1s; row i of graph g reads compact row cbase[g] + (i - ptr[g]) and shifts the node indices it finds there (they
+// are the canonical graph's) by ptr[g] - ptr[cgraph[g]].  nullptr: the tables are indexed by node.
 struct TdMergeArgs {
     const float4 *x4; const int32_t *ptr, *pptr, *gid, *prot_rows; int64_t Np;
     const unsigned long long *skeys; const int32_t *snbr; const float *h0, *h1s, *ews; int32_t *nbr; float *h, *ew;
     uint8_t *clean, *flags2; int k;
+    const int32_t *cgraph, *cbase;
 };
 __device__ __forceinline__ void knn_merge_body(unsigned bid, const TdMergeArgs &ma) {
     const float4 *__restrict__ x4 = ma.x4;
@@ -241,7 +246,14 @@ __device__ __forceinline__ void knn_merge_body(unsigned bid, const TdMergeArgs &
     const int g = gid[i];
     const int lbeg = ptr[g] + (pptr[g + 1] - pptr[g]), lend = ptr[g + 1];
     const float4 xi = x4[i];
-    unsigned long long ks = lane < TD_K ? skeys[i * TD_K + lane] : TD_KEY_MAX;
+    int64_t c = i;                 // row of the static tables
+    int rebase = 0;                // ... and what turns the node indices stored there into this graph's
+    if (ma.cgraph) {
+        rebase = ptr[g] - ptr[ma.cgraph[g]];
+        c = (int64_t)ma.cbase[g] + (i - ptr[g]);
+    }
+    unsigned long long ks = lane < TD_K ? skeys[c * TD_K + lane] : TD_KEY_MAX;
+    if (ks != TD_KEY_MAX) ks += (unsigned long long)(unsigned)rebase;          // the node index is the key's low word (< 2^31: no carry)
     const unsigned long long thr = __shfl(ks, k - 1);             // k-th static neighbour (MAX if fewer exist)
     unsigned long long kl[2] = {TD_KEY_MAX, TD_KEY_MAX};
     bool closer = false;
@@ -329,12 +341,13 @@ __device__ __forceinline__ void knn_merge_body(unsigned bid, const TdMergeArgs &
         const bool lig_in = lane < k && best != TD_KEY_MAX && (int)(unsigned)(best & 0xffffffffull) >= lbeg;
         is_clean = __ballot(lig_in) == 0ull;
     } else if (lane < TD_K) {
-        nbr[i * TD_K + lane] = snbr[i * TD_K + lane];
+        const int32_t sj = snbr[c * TD_K + lane];
+        nbr[i * TD_K + lane] = sj >= 0 ? sj + rebase : -1;
     }
     // prepare the step's node state for this row: h = cached layer-0 output (clean) or the embedding h0 (dirty)
-    const float2 hv = *reinterpret_cast<const float2 *>((is_clean ? h1s : h0) + i * TD_H + 2 * lane);
+    const float2 hv = *reinterpret_cast<const float2 *>((is_clean ? h1s : h0) + c * TD_H + 2 * lane);
     *reinterpret_cast<float2 *>(h + i * TD_H + 2 * lane) = hv;
-    if (is_clean && lane < TD_K) ew[i * TD_K + lane] = ews[i * TD_K + lane];
+    if (is_clean && lane < TD_K) ew[i * TD_K + lane] = ews[c * TD_K + lane];
     if (lane == 0) {
         clean[i] = is_clean ? 1 : 0;
         if (flags2) flags2[i] = 0;             // forward-reach flag of this row, set later in the step
@@ -357,8 +370,8 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
                         uint8_t *clean, uint8_t *flags2, hipStream_t s, int k, const int32_t *lig_rows, int64_t Nl,
-                        int max_graph_nodes) {
-    const TdMergeArgs ma{x4, node_ptr, pptr, gid, prot_rows, Np, skeys, snbr, h0, h1s, ews, nbr, h, ew, clean, flags2, k};
+                        int max_graph_nodes, const int32_t *cgraph, const int32_t *cbase) {
+    const TdMergeArgs ma{x4, node_ptr, pptr, gid, prot_rows, Np, skeys, snbr, h0, h1s, ews, nbr, h, ew, clean, flags2, k, cgraph, cbase};
     const unsigned GA = (unsigned)((Np + 3) / 4), GB = lig_rows ? (unsigned)((Nl + 3) / 4) : 0u;
     if (GA + GB == 0) return TD_OK;
     if (GB == 0) {
@@ -550,21 +563,92 @@ int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_
     return TD_OK;
 }
 
-// h[i] = hs[i] for the listed rows (device-side count)
+// h[i] = hs[i] for the listed rows (device-side count).  cgraph / cbase (see TdMergeArgs): hs is a compact table shared by the replicas of
+// a pocket -- the listed rows are protein rows (a ligand row is always inside the forward reach), row i of graph g reads cbase[g] + (i - ptr[g])
 __global__ void restore_rows_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ count_ptr,
-                                    const float4 *__restrict__ hs, float4 *__restrict__ h) {
+                                    const float4 *__restrict__ hs, float4 *__restrict__ h, const int32_t *__restrict__ gid,
+                                    const int32_t *__restrict__ ptr, const int32_t *__restrict__ cbase) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t a = t >> 5;                 // 32 float4 per row
     if (a >= *count_ptr) return;
     const int64_t i = rows[a];
-    h[i * 32 + (t & 31)] = hs[i * 32 + (t & 31)];
+    int64_t c = i;
+    if (cbase) {
+        const int g = gid[i];
+        c = (int64_t)cbase[g] + (i - ptr[g]);
+    }
+    h[i * 32 + (t & 31)] = hs[c * 32 + (t & 31)];
 }
 
 int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_t max_rows, const float *hs, float *h,
-                           hipStream_t s) {
+                           hipStream_t s, const int32_t *gid, const int32_t *node_ptr, const int32_t *cbase) {
     if (max_rows == 0) return TD_OK;
     restore_rows_kernel<<<dim3((unsigned)((max_rows * 32 + 255) / 256)), dim3(256), 0, s>>>(
-        rows, count_ptr, reinterpret_cast<const float4 *>(hs), reinterpret_cast<float4 *>(h));
+        rows, count_ptr, reinterpret_cast<const float4 *>(hs), reinterpret_cast<float4 *>(h), gid, node_ptr, cbase);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+
+// ---- per-pocket sharing of a session's static tables: which graphs of the batch carry the same protein block --------------------------------
+// One workgroup per graph: a 64-bit hash (FNV-1a over the words, folded per lane and combined in lane order) of its protein positions and
+// feature rows.  The host groups graphs by (atom count, hash) and has pocket_verify_kernel compare every candidate with its group's first
+// graph word by word, so a hash collision costs a graph its sharing, never its results.
+__global__ __launch_bounds__(256) void pocket_hash_kernel(const float *__restrict__ ppos, const float *__restrict__ pv, const int32_t *__restrict__ pptr,
+                                                          int F, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long part[256];
+    const int g = blockIdx.x, p0 = pptr[g], np = pptr[g + 1] - p0;
+    const unsigned *a = reinterpret_cast<const unsigned *>(ppos) + (size_t)p0 * 3, *b = reinterpret_cast<const unsigned *>(pv) + (size_t)p0 * F;
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int64_t t = threadIdx.x; t < (int64_t)np * 3; t += 256) hsh = (hsh ^ a[t]) * 1099511628211ull;
+    for (int64_t t = threadIdx.x; t < (int64_t)np * F; t += 256) hsh = (hsh ^ b[t]) * 1099511628211ull;
+    part[threadIdx.x] = hsh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 1469598103934665603ull;
+        for (int t = 0; t < 256; ++t) acc = (acc ^ part[t]) * 1099511628211ull;
+        out[g] = acc;
+    }
+}
+// flags[g] = 1 unless graph g's protein block equals graph cand[g]'s bit for bit (cand[g] == g: trivially equal)
+__global__ __launch_bounds__(256) void pocket_verify_kernel(const float *__restrict__ ppos, const float *__restrict__ pv, const int32_t *__restrict__ pptr,
+                                                            int F, const int32_t *__restrict__ cand, int32_t *__restrict__ flags) {
+    const int g = blockIdx.x, c = cand[g];
+    if (c == g) return;
+    const int p0 = pptr[g], q0 = pptr[c], np = pptr[g + 1] - p0;
+    bool diff = (pptr[c + 1] - q0) != np;
+    if (!diff) {
+        const unsigned *a = reinterpret_cast<const unsigned *>(ppos), *b = reinterpret_cast<const unsigned *>(pv);
+        for (int64_t t = threadIdx.x; t < (int64_t)np * 3 && !diff; t += 256) diff = a[(size_t)p0 * 3 + t] != a[(size_t)q0 * 3 + t];
+        for (int64_t t = threadIdx.x; t < (int64_t)np * F && !diff; t += 256) diff = b[(size_t)p0 * F + t] != b[(size_t)q0 * F + t];
+    }
+    if (diff) flags[g] = 1;
+}
+int td_launch_pocket_hash(const float *ppos, const float *pv, const int32_t *pptr, int64_t B, int F, unsigned long long *out, hipStream_t s) {
+    pocket_hash_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(ppos, pv, pptr, F, out);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+int td_launch_pocket_verify(const float *ppos, const float *pv, const int32_t *pptr, int64_t B, int F, const int32_t *cand, int32_t *flags,
+                            hipStream_t s) {
+    pocket_verify_kernel<<<dim3((unsigned)B), dim3(256), 0, s>>>(ppos, pv, pptr, F, cand, flags);
+    TD_CHECK_HIP(hipGetLastError());
+    return TD_OK;
+}
+// dst[c] = src[rows[c]] for rows of `row16` 16-byte words (the canonical rows of full-size set-up tables into the compact shared ones)
+__global__ void compact_rows_kernel(const uint4 *__restrict__ src, const int32_t *__restrict__ rows, int64_t n_rows, int row16,
+                                    uint4 *__restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = t / row16;
+    if (c >= n_rows) return;
+    const int w = (int)(t - c * row16);
+    dst[c * row16 + w] = src[(int64_t)rows[c] * row16 + w];
+}
+int td_launch_compact_rows(const void *src, const int32_t *rows, int64_t n_rows, int row_bytes, void *dst, hipStream_t s) {
+    if (n_rows == 0) return TD_OK;
+    const int row16 = row_bytes / 16;
+    const int64_t total = n_rows * row16;
+    compact_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const uint4 *>(src), rows, n_rows, row16,
+                                                                                   reinterpret_cast<uint4 *>(dst));
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

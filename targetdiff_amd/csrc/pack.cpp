@@ -638,6 +638,7 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         m->opt.session_hop_levels = value;
     } else if (strcmp(name, "session_forward_reach") == 0) m->opt.session_forward_reach = value != 0;
     else if (strcmp(name, "session_step_lists") == 0) m->opt.session_step_lists = value != 0;
+    else if (strcmp(name, "session_share_pockets") == 0) m->opt.session_share_pockets = value != 0;
     else { td_set_error("td_model_set_option: unknown option '%s'", name); return TD_EINVAL; }
     ++m->option_epoch;          // sessions re-capture their step graph (the captured nodes copied the old variants' arguments by value)
     return TD_OK;
@@ -655,6 +656,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
     else if (strcmp(name, "session_step_lists") == 0) *value = m->opt.session_step_lists;
+    else if (strcmp(name, "session_share_pockets") == 0) *value = m->opt.session_share_pockets;
     else { td_set_error("td_model_get_option: unknown option '%s'", name); return TD_EINVAL; }
     return TD_OK;
 }

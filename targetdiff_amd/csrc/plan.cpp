@@ -137,7 +137,7 @@ int run_backbone(const td_model *m, Workspace &w, const GraphTab &gt, float *h, 
                 ProfScope ps(PC_NODE, s);
                 if ((rc = td_launch_node_output(L.nodeOut, att_out, h, N, s)) != TD_OK) return rc;
             }
-            if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s)) != TD_OK) return rc;
+            if (use_fwd && (rc = td_launch_restore_rows(fwd->rest, fwd->counts + 1, N, fwd->hs, h, s, w.gid, w.node_ptr, fwd->cbase)) != TD_OK) return rc;
         }
         if (!do_h2x) continue;
         if (sync) {

@@ -45,6 +45,14 @@ struct td_session {
     bool use_fwd;
     uint8_t *clean;
     int graph_nodes_max;         // exact size of the largest graph -- sizes the LDS flags of td_launch_step_lists
+    // Per-pocket sharing of the static tables (CACHING, default graph; model option session_share_pockets): all samples of a pocket carry the
+    // same protein block (scripts/sample_diffusion.py:42 replicates one pocket n_data times), so skeys / snbr / ews / h0 / h1s / h2s are kept
+    // ONCE per distinct block -- `static_rows` compact rows, the canonical graphs' protein atoms back to back -- and graph g reads the rows of
+    // cgraph[g], the first graph of the batch with the same block, from cbase[g] on.  P0 / q0 (the layer-0 projections the attention passes
+    // gather through the neighbour index) stay per node.  nullptr: tables indexed by node.
+    int32_t *cgraph = nullptr, *cbase = nullptr;
+    int64_t static_rows = 0;
+    int pocket_groups = 0;
     bool caching;                // static-protein caching + receptive-field pruning (false: PLAIN)
     bool chunked;                // general graph: the neighbour table lives in `plan`
     GraphPlan plan;
@@ -123,6 +131,60 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     if (S->chunked && (rc = plan_create(m->cfg, hp.data(), hl.data(), B, s, &S->plan)) != TD_OK) { delete S; return rc; }
     const int64_t NC = S->chunked ? S->plan.NC : N;          // 32-slot rows of the neighbour table
     const int KS = S->chunked ? 64 : TD_K;                   // static keys kept per protein row
+    // ---- per-pocket sharing of the static tables: which graphs carry the same protein block (bit for bit)?
+    const bool share = S->caching && !S->chunked && m->opt.session_share_pockets != 0;
+    std::vector<int32_t> cgraph_h, cbase_h, canon_rows_h;
+    int64_t Nc = N;                                          // rows of the static tables (compact: the canonical graphs' protein atoms)
+    if (share) {
+        const int F = m->cfg.protein_feat_dim;
+        char *tg = nullptr;
+        const size_t tg_bytes = align_up((size_t)B * 8) + 2 * align_up((size_t)B * 4);
+        hipError_t te = td_malloc_async(reinterpret_cast<void **>(&tg), tg_bytes, s);
+        if (te != hipSuccess) { td_set_error("td_session_create: hipMallocAsync(%zu) failed: %s", tg_bytes, hipGetErrorString(te)); delete S; return TD_ENOMEM; }
+        unsigned long long *d_hash = reinterpret_cast<unsigned long long *>(tg);
+        int32_t *d_cand = reinterpret_cast<int32_t *>(tg + align_up((size_t)B * 8)), *d_flag = reinterpret_cast<int32_t *>(tg + align_up((size_t)B * 8) + align_up((size_t)B * 4));
+        std::vector<unsigned long long> hash((size_t)B);
+        std::vector<int32_t> flag((size_t)B, 0);
+        cgraph_h.assign((size_t)B, 0); cbase_h.assign((size_t)B, 0);
+        auto bail = [&](int r) { free_async_or_sync(tg, s); delete S; return r; };
+        if ((rc = td_launch_pocket_hash(d_protein_pos, d_protein_v, d_protein_ptr, B, F, d_hash, s)) != TD_OK) return bail(rc);
+        if (hipMemcpyAsync(hash.data(), d_hash, (size_t)B * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            td_set_error("td_session_create: reading the pocket hashes failed"); return bail(TD_EHIP);
+        }
+        {   // candidate = the first graph of the batch with the same (atom count, hash)
+            std::vector<std::pair<std::pair<int32_t, unsigned long long>, int32_t>> seen;
+            for (int64_t g = 0; g < B; ++g) {
+                const std::pair<int32_t, unsigned long long> key(hp[g + 1] - hp[g], hash[(size_t)g]);
+                int32_t c = (int32_t)g;
+                for (const auto &e2 : seen) if (e2.first == key) { c = e2.second; break; }
+                if (c == (int32_t)g) seen.push_back({key, (int32_t)g});
+                cgraph_h[(size_t)g] = c;
+            }
+        }
+        hipError_t e2 = hipMemcpyAsync(d_cand, cgraph_h.data(), (size_t)B * 4, hipMemcpyHostToDevice, s);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(d_flag, 0, (size_t)B * 4, s);
+        if (e2 != hipSuccess) { td_set_error("td_session_create: pocket grouping failed: %s", hipGetErrorString(e2)); return bail(TD_EHIP); }
+        if ((rc = td_launch_pocket_verify(d_protein_pos, d_protein_v, d_protein_ptr, B, F, d_cand, d_flag, s)) != TD_OK) return bail(rc);
+        if (hipMemcpyAsync(flag.data(), d_flag, (size_t)B * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            td_set_error("td_session_create: reading the pocket comparison failed"); return bail(TD_EHIP);
+        }
+        free_async_or_sync(tg, s);
+        Nc = 0;
+        for (int64_t g = 0; g < B; ++g) {
+            if (flag[(size_t)g]) cgraph_h[(size_t)g] = (int32_t)g;          // same hash, different block: keeps its own tables
+            const int32_t c = cgraph_h[(size_t)g];
+            if (c == (int32_t)g) {
+                cbase_h[(size_t)g] = (int32_t)Nc;
+                const int32_t n0 = hp[g] + hl[g], np = hp[g + 1] - hp[g];          // the graph's nodes start at node_ptr[g]; protein atoms first
+                for (int32_t a = 0; a < np; ++a) canon_rows_h.push_back(n0 + a);
+                Nc += np;
+                ++S->pocket_groups;
+            } else {
+                cbase_h[(size_t)g] = cbase_h[(size_t)c];
+            }
+        }
+        S->static_rows = Nc;
+    }
 
     // ---- one device block: [workspace | session-static buffers]
     const size_t ws_bytes = carve(nullptr, N, B, N_l).bytes;
@@ -130,15 +192,17 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     auto reserve = [&](size_t n) { size_t o = off; off += align_up(n ? n : 4); return o; };
     const size_t n = (size_t)N, nc = (size_t)NC;
     const bool C = S->caching;
+    const size_t ns = share ? (size_t)Nc : n, ncs = share ? (size_t)Nc : nc;          // rows of the static tables
     const size_t o_prot = reserve((size_t)N_p * 4), o_pptr = reserve((size_t)(B + 1) * 4), o_lptr = reserve((size_t)(B + 1) * 4),
-                 o_h0 = reserve(n * TD_H * 4), o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8),
-                 o_snbr = reserve(C ? nc * TD_K * 4 : 0), o_skeys = reserve(C ? n * KS * 8 : 0), o_ews = reserve(C ? nc * TD_K * 4 : 0),
-                 o_h1s = reserve(C ? n * TD_H * 4 : 0), o_h2s = reserve(C ? n * TD_H * 4 : 0), o_f2 = reserve(C ? n : 0),
+                 o_h0 = reserve(ns * TD_H * 4), o_tmp_lpos = reserve((size_t)N_l * 12), o_tmp_lv = reserve((size_t)N_l * 8),
+                 o_snbr = reserve(C ? ncs * TD_K * 4 : 0), o_skeys = reserve(C ? ns * KS * 8 : 0), o_ews = reserve(C ? ncs * TD_K * 4 : 0),
+                 o_h1s = reserve(C ? ns * TD_H * 4 : 0), o_h2s = reserve(C ? ns * TD_H * 4 : 0), o_f2 = reserve(C ? n : 0),
                  o_frows = reserve(C ? n * 4 : 0), o_frest = reserve(C ? n * 4 : 0), o_fcnt = reserve(256),
                  o_P0 = reserve(C ? n * 4 * TD_H * 4 : 0), o_q0 = reserve(C ? n * TD_H * 4 : 0), o_clean = reserve(C ? n : 0),
                  o_dirty = reserve(C ? n * 4 : 0), o_dcnt = reserve(256), o_hop = reserve(C ? n * 4 * TD_HOP_LEVELS : 0),
                  o_hcnt = reserve(256), o_dchunks = reserve(C && S->chunked ? nc * 4 : 0),
-                 o_ppos = reserve((size_t)N_l * 3 * 4), o_pv = reserve((size_t)N_l * TD_MAXC * 4);
+                 o_ppos = reserve((size_t)N_l * 3 * 4), o_pv = reserve((size_t)N_l * TD_MAXC * 4),
+                 o_cg = reserve(share ? (size_t)B * 4 : 0), o_cb = reserve(share ? (size_t)B * 4 : 0), o_crows = reserve(share ? (size_t)Nc * 4 : 0);
     hipError_t e = td_malloc_async(reinterpret_cast<void **>(&S->block), off, s);
     if (e != hipSuccess) {
         td_set_error("td_session_create: hipMallocAsync(%zu) failed: %s", off, hipGetErrorString(e));
@@ -172,6 +236,12 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     S->dirty_chunks = reinterpret_cast<int32_t *>(b + o_dchunks);
     S->pred_pos = reinterpret_cast<float *>(b + o_ppos);
     S->pred_v = reinterpret_cast<float *>(b + o_pv);
+    int32_t *canon_rows = nullptr;
+    if (share) {
+        S->cgraph = reinterpret_cast<int32_t *>(b + o_cg);
+        S->cbase = reinterpret_cast<int32_t *>(b + o_cb);
+        canon_rows = reinterpret_cast<int32_t *>(b + o_crows);
+    }
     {
         // receptive-field levels tracked per step (each prunes one more layer from the end)
         int lv = m->opt.session_hop_levels;
@@ -190,14 +260,46 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     TD_TRY_HIP(hipMemcpyAsync(S->lptr, d_ligand_ptr, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s));
     TD_TRY_HIP(hipMemsetAsync(tmp_lpos, 0, (size_t)N_l * 12, s));
     TD_TRY_HIP(hipMemsetAsync(tmp_lv, 0, (size_t)N_l * 8, s));
+    // Sharing: the set-up below runs on the canonical graphs' protein rows only, into full-size (node-indexed) scratch tables that live in one
+    // stream-ordered block until their canonical rows have been copied into the compact shared tables
+    char *scratch = nullptr;
+    float *h0_f = S->h0, *h1_f = S->h1s, *h2_f = S->h2s, *ews_f = S->ews;
+    int32_t *snbr_f = S->snbr;
+    unsigned long long *skeys_f = S->skeys;
+    const int32_t *set_rows = S->prot_node;          // (assigned below for chunked plans)
+    int64_t set_count = N_p;
+    auto fail2 = [&](int r) { free_async_or_sync(scratch, s); return fail(r); };
+    if (share) {
+        const size_t b_keys = align_up(n * TD_K * 8), b_nbr = align_up(n * TD_K * 4), b_h = align_up(n * TD_H * 4);
+        const size_t sb = b_keys + 2 * b_nbr + 3 * b_h;
+        hipError_t se = td_malloc_async(reinterpret_cast<void **>(&scratch), sb, s);
+        if (se != hipSuccess) { td_set_error("td_session_create: hipMallocAsync(%zu) failed: %s", sb, hipGetErrorString(se)); scratch = nullptr; return fail(TD_ENOMEM); }
+        skeys_f = reinterpret_cast<unsigned long long *>(scratch);
+        snbr_f = reinterpret_cast<int32_t *>(scratch + b_keys);
+        ews_f = reinterpret_cast<float *>(scratch + b_keys + b_nbr);
+        h0_f = reinterpret_cast<float *>(scratch + b_keys + 2 * b_nbr);
+        h1_f = reinterpret_cast<float *>(scratch + b_keys + 2 * b_nbr + b_h);
+        h2_f = reinterpret_cast<float *>(scratch + b_keys + 2 * b_nbr + 2 * b_h);
+        hipError_t ue = hipMemcpyAsync(S->cgraph, cgraph_h.data(), (size_t)B * 4, hipMemcpyHostToDevice, s);
+        if (ue == hipSuccess) ue = hipMemcpyAsync(S->cbase, cbase_h.data(), (size_t)B * 4, hipMemcpyHostToDevice, s);
+        if (ue == hipSuccess) ue = hipMemcpyAsync(canon_rows, canon_rows_h.data(), (size_t)Nc * 4, hipMemcpyHostToDevice, s);
+        if (ue == hipSuccess) ue = hipStreamSynchronize(s);          // (the host vectors go out of scope with this call)
+        if (ue != hipSuccess) { td_set_error("td_session_create: uploading the pocket groups failed: %s", hipGetErrorString(ue)); return fail2(TD_EHIP); }
+    }
+#undef TD_TRY
+#undef TD_TRY_HIP
+#define TD_TRY(expr) do { if ((rc = (expr)) != TD_OK) return fail2(rc); } while (0)
+#define TD_TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { td_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); return fail2(TD_EHIP); } } while (0)
     // embeddings + packed order (ligand rows are placeholders until the first step), protein row list
     int32_t *prot_out = S->chunked ? S->plan.prot_node : S->prot_node;
-    TD_TRY(td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, tmp_lpos, tmp_lv, S->lptr, N_l, B, S->h0, w.x4a,
+    TD_TRY(td_launch_compose(m, d_protein_pos, d_protein_v, S->pptr, N_p, tmp_lpos, tmp_lv, S->lptr, N_l, B, h0_f, w.x4a,
                              w.node_ptr, w.gid, w.lig_node, prot_out, s));
     if (S->chunked) {
         S->prot_node = S->plan.prot_node;
         TD_TRY(plan_layout(S->plan, w.node_ptr, w.gid, s));
     }
+    set_rows = share ? canon_rows : S->prot_node;
+    set_count = share ? Nc : N_p;
     TD_TRY_HIP(hipMemcpyAsync(w.x4b, w.x4a, n * sizeof(float4), hipMemcpyDeviceToDevice, s));
     if (!S->caching) {
         *out = S;
@@ -206,8 +308,8 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
     // ---- protein-only graph, its gate rows, layer-0 projections / queries, layer-0 x2h output
     GraphTab gt = session_tab(S);                  // the step's table (alpha is scratch here)
     GraphTab st = gt;                              // the static table
-    st.nbr = S->snbr; st.ew = S->ews;
-    TD_TRY_HIP(hipMemsetAsync(S->snbr, 0xff, nc * TD_K * 4, s));
+    st.nbr = snbr_f; st.ew = ews_f;
+    TD_TRY_HIP(hipMemsetAsync(snbr_f, 0xff, nc * TD_K * 4, s));
     if (S->chunked) {
         TD_TRY(td_launch_knn_general_static(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, N_p, m->cfg.knn, gmax, S->plan.cptr,
                                             S->snbr, S->skeys, s));
@@ -218,20 +320,30 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
         if (m->cfg.cutoff_mode == TD_CUTOFF_HYBRID)
             TD_TRY(td_launch_hybrid_ligand_half(w.node_ptr, S->pptr, w.gid, w.lig_node, N_l, S->plan.cptr, S->plan.cnbr, s));
     } else {
-        TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, S->prot_node, N_p, max_graph_nodes, S->snbr, S->skeys, s, m->cfg.knn));
-        TD_TRY(td_launch_gate(m->gate, w.x4a, S->snbr, N_p, S->prot_node, nullptr, S->ews, s));
+        TD_TRY(td_launch_knn_static(w.x4a, w.node_ptr, w.gid, set_rows, set_count, max_graph_nodes, snbr_f, skeys_f, s, m->cfg.knn));
+        TD_TRY(td_launch_gate(m->gate, w.x4a, snbr_f, set_count, set_rows, nullptr, ews_f, s));
     }
     const TdLayer &L0 = m->layers[0];
-    TD_TRY(td_launch_node_proj(L0.nodeX2h, S->h0, N, nullptr, 0x1f, S->P0, S->q0, s));
-    TD_TRY(key_pass(L0.hk, L0, w.x4a, st, st.ew, st.nbr, S->P0, S->q0, S->prot_node, nullptr, N_p, gt.alpha, s));
-    TD_TRY_HIP(hipMemcpyAsync(S->h1s, S->h0, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-    TD_TRY(value_pass(L0.hv, L0, w.x4a, st, st.nbr, S->P0, S->prot_node, nullptr, N_p, S->h1s, gt.alpha, nullptr, 0, s));
+    TD_TRY(td_launch_node_proj(L0.nodeX2h, h0_f, N, nullptr, 0x1f, S->P0, S->q0, s));
+    TD_TRY(key_pass(L0.hk, L0, w.x4a, st, st.ew, st.nbr, S->P0, S->q0, set_rows, nullptr, set_count, gt.alpha, s));
+    TD_TRY_HIP(hipMemcpyAsync(h1_f, h0_f, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
+    TD_TRY(value_pass(L0.hv, L0, w.x4a, st, st.nbr, S->P0, set_rows, nullptr, set_count, h1_f, gt.alpha, nullptr, 0, s));
     if (S->use_fwd) {      // layer-1 x2h output of the protein-only graph (valid wherever the ligand is two hops away)
         const TdLayer &L1 = m->layers[1];
-        TD_TRY(td_launch_node_proj(L1.nodeX2h, S->h1s, N, nullptr, 0x1f, w.P, w.q, s));
-        TD_TRY(key_pass(L1.hk, L1, w.x4a, st, st.ew, st.nbr, w.P, w.q, S->prot_node, nullptr, N_p, gt.alpha, s));
-        TD_TRY_HIP(hipMemcpyAsync(S->h2s, S->h1s, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
-        TD_TRY(value_pass(L1.hv, L1, w.x4a, st, st.nbr, w.P, S->prot_node, nullptr, N_p, S->h2s, gt.alpha, nullptr, 0, s));
+        TD_TRY(td_launch_node_proj(L1.nodeX2h, h1_f, N, nullptr, 0x1f, w.P, w.q, s));
+        TD_TRY(key_pass(L1.hk, L1, w.x4a, st, st.ew, st.nbr, w.P, w.q, set_rows, nullptr, set_count, gt.alpha, s));
+        TD_TRY_HIP(hipMemcpyAsync(h2_f, h1_f, n * TD_H * 4, hipMemcpyDeviceToDevice, s));
+        TD_TRY(value_pass(L1.hv, L1, w.x4a, st, st.nbr, w.P, set_rows, nullptr, set_count, h2_f, gt.alpha, nullptr, 0, s));
+    }
+    if (share) {           // the canonical rows of the scratch tables -> the compact shared tables; the scratch block goes back in stream order
+        TD_TRY(td_launch_compact_rows(skeys_f, canon_rows, Nc, TD_K * 8, S->skeys, s));
+        TD_TRY(td_launch_compact_rows(snbr_f, canon_rows, Nc, TD_K * 4, S->snbr, s));
+        TD_TRY(td_launch_compact_rows(ews_f, canon_rows, Nc, TD_K * 4, S->ews, s));
+        TD_TRY(td_launch_compact_rows(h0_f, canon_rows, Nc, TD_H * 4, S->h0, s));
+        TD_TRY(td_launch_compact_rows(h1_f, canon_rows, Nc, TD_H * 4, S->h1s, s));
+        if (S->use_fwd) TD_TRY(td_launch_compact_rows(h2_f, canon_rows, Nc, TD_H * 4, S->h2s, s));
+        free_async_or_sync(scratch, s);
+        scratch = nullptr;
     }
 #undef TD_TRY
 #undef TD_TRY_HIP
@@ -312,7 +424,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
             // the protein rows' merge and the ligand rows' full search: independent, one launch
             if ((rc = td_launch_knn_merge(w.x4a, w.node_ptr, S->pptr, w.gid, S->prot_node, Np, S->skeys, S->snbr, S->h0,
                                           S->h1s, S->ews, w.nbr, w.h, w.ew, S->clean, S->use_fwd ? S->flags2 : nullptr, s, m->cfg.knn,
-                                          w.lig_node, Nl, S->max_graph_nodes)) != TD_OK) return rc;
+                                          w.lig_node, Nl, S->max_graph_nodes, S->cgraph, S->cbase)) != TD_OK) return rc;
             // every row list of the step (dirty rows, forward reach, receptive-field levels) in one launch, one workgroup per graph;
             // graphs too large for its LDS flags take the separate kernels
             rc = (m->opt.session_step_lists && S->graph_nodes_max > 0) ? td_launch_step_lists(S->clean, w.x4a, w.nbr, w.node_ptr, N, S->B, S->graph_nodes_max, lists, s)
@@ -349,7 +461,7 @@ extern "C" int td_session_forward(td_session *S, const float *d_ligand_pos, cons
     // rows the last layer still has to update (S->clean is free again after the dirty-row compaction: reuse as flags)
     if (!lists_done && (rc = td_launch_hop_levels(w.lig_node, Nl, w.nbr, N, S->clean, S->hop_rows, S->hop_count, S->hop_levels, s, true)) != TD_OK) return rc;
     float4 *xf = nullptr;
-    const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s};
+    const FwdReach fwd{S->fwd_rows, S->fwd_rest, S->fwd_counts, S->h2s, S->cbase};
     if ((rc = run_backbone(m, w, gt, w.h, N, Nl, 0, &xf, s, false, true, S->hop_rows, S->hop_count, S->hop_levels,
                            S->use_fwd ? &fwd : nullptr)) != TD_OK) return rc;
     ProfScope ps(PC_HEAD, s);
@@ -431,6 +543,9 @@ extern "C" int td_session_row_counts(td_session *S, int32_t *host_counts, int32_
     if (lv > 0) TD_CHECK_HIP(hipMemcpyAsync(host_counts + 2, S->hop_count, sizeof(int32_t) * (size_t)lv, hipMemcpyDeviceToHost, s));
     if (n_counts > 2 + TD_HOP_LEVELS && S->use_fwd)
         TD_CHECK_HIP(hipMemcpyAsync(host_counts + 2 + TD_HOP_LEVELS, S->fwd_counts, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // rows of the static tables and distinct protein blocks of the batch (per-pocket sharing; -1: tables indexed by node)
+    if (n_counts > 3 + TD_HOP_LEVELS) host_counts[3 + TD_HOP_LEVELS] = S->cgraph ? (int32_t)S->static_rows : -1;
+    if (n_counts > 4 + TD_HOP_LEVELS) host_counts[4 + TD_HOP_LEVELS] = S->cgraph ? (int32_t)S->pocket_groups : -1;
     TD_CHECK_HIP(hipStreamSynchronize(s));
     return TD_OK;
 }

@@ -138,6 +138,7 @@ struct GraphTab {
 struct FwdReach {
     const int32_t *rows, *rest, *counts;     // counts[0] = |rows|, counts[1] = |rest|
     const float *hs;
+    const int32_t *cbase = nullptr;          // hs is a compact per-pocket table (session.cpp): row i of graph g = cbase[g] + (i - node_ptr[g])
 };
 
 // ------------------------------------------------------------------------------------------ general graphs

@@ -159,6 +159,8 @@ struct TdOptions {
     int node_proj_bpipe = 0;       // split node GEMMs: register double-buffering of the B fragments (LDS reads ahead of the MFMAs; measured
                                    // slower at C2: 0.848 vs 0.817 ms per step, profiles/r03b_*; kept as a switch)
     int node_proj_async = 1;    // split node GEMMs: B chunks by inline-asm global_load_lds + an explicit wait per round (0: the builtin, which the compiler serialises)
+    int session_share_pockets = 1; // a session's static tables (protein-only k-NN keys / lists, cached gate rows, embeddings, layer-0 / layer-1 outputs of the
+                                   // protein-only graph) once per distinct pocket of the batch instead of once per graph (default graph; 0: per graph)
     int session_step_lists = 1;    // a step's row lists from one launch (a workgroup per graph; 0: the separate kernels, which
                                    // graphs too large for its LDS flags use anyway)
 };
@@ -197,13 +199,18 @@ int td_launch_knn_merge(const float4 *x4, const int32_t *node_ptr, const int32_t
                         const int32_t *prot_rows, int64_t Np, const unsigned long long *skeys, const int32_t *snbr,
                         const float *h0, const float *h1s, const float *ews, int32_t *nbr, float *h, float *ew,
                         uint8_t *clean, uint8_t *flags2, hipStream_t s, int k = TD_K, const int32_t *lig_rows = nullptr, int64_t Nl = 0,
-                        int max_graph_nodes = 0);
+                        int max_graph_nodes = 0, const int32_t *cgraph = nullptr, const int32_t *cbase = nullptr);
+// per-pocket sharing of a session's static tables (graph.hip, session.cpp)
+int td_launch_pocket_hash(const float *ppos, const float *pv, const int32_t *pptr, int64_t B, int F, unsigned long long *out, hipStream_t s);
+int td_launch_pocket_verify(const float *ppos, const float *pv, const int32_t *pptr, int64_t B, int F, const int32_t *cand, int32_t *flags,
+                            hipStream_t s);
+int td_launch_compact_rows(const void *src, const int32_t *rows, int64_t n_rows, int row_bytes, void *dst, hipStream_t s);
 int td_launch_compact_dirty(const uint8_t *clean, const float4 *x4, int64_t N, int32_t *rows, int32_t *count,
                             hipStream_t s);
 int td_launch_forward_reach(const uint8_t *clean, const float4 *x4, const int32_t *nbr, int64_t N, uint8_t *flags2,
                             int32_t *rows_on, int32_t *rows_off, int32_t *counts2, uint8_t *clean_to_zero, hipStream_t s);
 int td_launch_restore_rows(const int32_t *rows, const int32_t *count_ptr, int64_t max_rows, const float *hs, float *h,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t *gid = nullptr, const int32_t *node_ptr = nullptr, const int32_t *cbase = nullptr);
 constexpr int TD_HOP_LEVELS = 4;
 int td_launch_hop_levels(const int32_t *lig_node, int64_t Nl, const int32_t *nbr, int64_t N, uint8_t *flags,
                          int32_t *rows, int32_t *counts, int levels, hipStream_t s, bool zeroed = false);

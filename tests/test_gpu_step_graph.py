@@ -187,6 +187,49 @@ def test_session_equals_stateless_10_steps_at_c5_size(state_dict, graph):
     _consecutive_steps_equal(m, [pocket], 256, [30] * 256, 10, 2.0, 7400)
 
 
+def test_static_tables_are_shared_per_pocket(state_dict):
+    """All samples of a pocket carry the same protein block (scripts/sample_diffusion.py:42): a session keeps its static tables (protein-only k-NN
+    keys and lists, cached gate rows, embeddings, layer-0 / layer-1 outputs) once per DISTINCT block of the batch.  A ragged pack of nine graphs --
+    pocket A five times and pocket B three times, interleaved, and one graph whose block differs from A's in one coordinate by 1e-3 A -- has three
+    blocks; the samples equal, bit for bit, those of a session that keeps tables per graph (session_share_pockets = 0) and those of the
+    stateless forward."""
+    from oracle import draws, weights
+    from targetdiff_amd import workloads
+    from targetdiff_amd.models import ScorePosNet3D
+    dev = _dev()
+    pa, pb = workloads.synthetic_pocket(301, 90, 3.0, 9.0), workloads.synthetic_pocket(302, 61, 3.0, 8.0)
+    pos_c = pa.pos.copy()
+    pos_c[17, 1] += np.float32(1e-3)            # (after centring on the protein centroid one ulp of a raw coordinate can round away)
+    pc = workloads.Pocket(pos_c, pa.feat, 'pa_one_atom_moved')
+    order = [pa, pa, pb, pa, pc, pb, pa, pb, pa]
+    sizes = [7, 9, 6, 8, 7, 10, 9, 6, 8]
+    batch = workloads.pack_samples(order, 1, sizes)
+    lpos, lv = workloads.init_ligand(batch, generator=torch.Generator().manual_seed(31), spread=2.0)
+    res, shared = {}, {}
+    for share, use_session in ((1, True), (0, True), (1, False)):
+        m = ScorePosNet3D(dict(weights.DEFAULT_MODEL_CONFIG), 27, 13)
+        m.load_state_dict(state_dict, strict=False)
+        m = m.to(dev).eval()
+        nat = m._native(dev)
+        assert nat.get_option('session_share_pockets') == 1            # shipped default
+        nat.set_option('session_share_pockets', share)
+        b = batch.to(dev)
+        smp = m.begin_sampling(b.protein_pos, b.protein_atom_feature.float(), b.protein_element_batch, lpos.to(dev), lv.to(dev),
+                               b.ligand_element_batch, num_steps=6, center_pos_mode='protein', noise_source=draws.Source(7700, dev),
+                               use_session=use_session)
+        while not smp.done:
+            smp.step()
+        if smp.session is not None:
+            shared[share] = smp.session.shared_static_tables()
+        res[(share, use_session)] = smp.finish()
+    assert shared[1] == (90 + 61 + 90, 3), shared            # pa, pb, pc: three blocks (pc differs from pa in one coordinate), 241 rows instead of 9 graphs' 739
+    assert shared[0] is None
+    for key in ('pos_traj', 'v_traj', 'v0_traj', 'vt_traj'):
+        a = torch.stack(res[(1, True)][key])
+        assert torch.equal(a, torch.stack(res[(0, True)][key])), key
+        assert torch.equal(a, torch.stack(res[(1, False)][key])), key
+
+
 # ------------------------------------------------------------------------------------------ error paths
 def test_failing_allocations_leak_nothing(model):
     """Fault injection (td_debug_fail_alloc): the n-th stream-ordered allocation of an entry point fails -- it must report
