@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -151,15 +152,10 @@ extern "C" int td_session_create(const td_model *m, const float *d_protein_pos, 
         if (hipMemcpyAsync(hash.data(), d_hash, (size_t)B * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
             td_set_error("td_session_create: reading the pocket hashes failed"); return bail(TD_EHIP);
         }
-        {   // candidate = the first graph of the batch with the same (atom count, hash)
-            std::vector<std::pair<std::pair<int32_t, unsigned long long>, int32_t>> seen;
-            for (int64_t g = 0; g < B; ++g) {
-                const std::pair<int32_t, unsigned long long> key(hp[g + 1] - hp[g], hash[(size_t)g]);
-                int32_t c = (int32_t)g;
-                for (const auto &e2 : seen) if (e2.first == key) { c = e2.second; break; }
-                if (c == (int32_t)g) seen.push_back({key, (int32_t)g});
-                cgraph_h[(size_t)g] = c;
-            }
+        {   // candidate = the first graph of the batch with the same (atom count, hash): an ordered map, B log B for any mix of pockets
+            std::map<std::pair<int32_t, unsigned long long>, int32_t> first;
+            for (int64_t g = 0; g < B; ++g)
+                cgraph_h[(size_t)g] = first.emplace(std::make_pair(hp[g + 1] - hp[g], hash[(size_t)g]), (int32_t)g).first->second;
         }
         hipError_t e2 = hipMemcpyAsync(d_cand, cgraph_h.data(), (size_t)B * 4, hipMemcpyHostToDevice, s);
         if (e2 == hipSuccess) e2 = hipMemsetAsync(d_flag, 0, (size_t)B * 4, s);
