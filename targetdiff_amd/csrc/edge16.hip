@@ -825,10 +825,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
-    // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass of the default graph.  (General graphs and the unfused h2x
-    // key pass keep the fp32 product: their session / stateless / fused forms run different kernels on the same rows and are held bit-identical.)
+    // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass of the default graph and of the one-chunk protein rows of a
+    // `hybrid` graph.  (The chunk walk and the unfused h2x key pass keep the fp32 product: their session / stateless / fused forms run
+    // different kernels on the same rows and are held bit-identical.)
     constexpr bool L2H = L2 != 0;
-    static_assert(L2 == 0 || (SPLIT && !XV && GRAPH == 0 && STAGE == 0), "f16 logits: x2h key pass of the default graph only");
+    static_assert(L2 == 0 || (SPLIT && !XV && GRAPH != 1 && STAGE == 0), "f16 logits: x2h key pass, rows of one chunk only");
     constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1967,7 +1968,9 @@ constexpr size_t V16T_LDS_BYTES =
 static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
 
 // L2: the aggregation product -- 0 fp32, 1 f16 piece pairs of z'' 2^15, 2 f16 piece pairs of z'' (see edge_key16_kernel)
-template <int L2>
+// VIA (`hybrid` graphs: protein rows of one chunk, found through cptr): the launcher passes no ligand rows -- every workgroup serves the
+// protein class and drops the ligand rows it meets; those are walked chunk by chunk by edge_value16_kernel<true, true> in a second launch.
+template <int L2, bool VIA = false>
 __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
     constexpr int WAVES = V16T_WAVES;
@@ -2038,20 +2041,21 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
     const float *Wt_lane = lds + woff;
     for (int64_t i = next_row(); i >= 0; i = next_row()) {
         RowIn16 rin;
-        td_row_index16(a, i, i, lane, rin);
+        const int64_t c = VIA ? (int64_t)__builtin_amdgcn_readfirstlane(a.cptr[i]) : i;          // the row of nbr / alpha
+        td_row_index16(a, i, c, lane, rin);
         // a protein workgroup meets the ligand rows of its share as candidates and drops them
         if (((__builtin_amdgcn_readfirstlane(__float_as_int(rin.xi.w)) > __float_as_int(0.5f)) ? 0 : 1) != my_cls) continue;
         floatx4_t acc[2][8];
-        td_row_gather16<false>(a, i, i, lane, rin, acc);
+        td_row_gather16<false>(a, i, c, lane, rin, acc);
         float al[8];
         if constexpr (L2 != 0) {
             // B operand of the aggregation product, K slots (g, 2m) / (g, 2m + 1) = edges 4g + m / 16 + 4g + m (the pairing the flipped z''
             // words have): alpha[edge][head lo], two 16-byte loads
-            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 4 * g;
+            const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 4 * g;
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 16);
             al[0] = v0.x; al[1] = v1.x; al[2] = v0.y; al[3] = v1.y; al[4] = v0.z; al[5] = v1.z; al[6] = v0.w; al[7] = v1.w;
         } else {   // A operand of the aggregation product: alpha[edge 8g + s][head lo]
-            const float *ap = a.alpha + ((size_t)i * TD_HEADS + lo) * TD_K + 8 * g;
+            const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 8 * g;
             const float4 v0 = *reinterpret_cast<const float4 *>(ap), v1 = *reinterpret_cast<const float4 *>(ap + 4);
             al[0] = v0.x; al[1] = v0.y; al[2] = v0.z; al[3] = v0.w; al[4] = v1.x; al[5] = v1.y; al[6] = v1.z; al[7] = v1.w;
         }
@@ -2295,10 +2299,20 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(a.count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
     } while (0)
     if (mlp.use_split) {                      // first layer on bf16 piece triples
-        if (cptr && !h2x && cpn_p == 1 && lig_rows && lig_count > 0) {
-            TD_KEY_LAUNCH(K16S_WAVES, 0, 2, true, K16S_LDS_BYTES);
-            a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
-            TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
+        if (cptr && !h2x && cpn_p == 1) {
+#define TD_KEY_LAUNCH_VIA(L2V)                                                                                                    \
+            do {                                                                                                                  \
+                TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 2, true, L2V>), K16S_LDS_BYTES);                             \
+                edge_key16_kernel<false, K16S_WAVES, 0, 2, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+            } while (0)
+            if (!mlp.l2_f16) TD_KEY_LAUNCH_VIA(0);
+            else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_VIA(2);
+            else TD_KEY_LAUNCH_VIA(1);
+#undef TD_KEY_LAUNCH_VIA
+            if (lig_rows && lig_count > 0) {
+                a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
+                TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
+            }
         } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES); }
         else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
         else {
@@ -2365,7 +2379,27 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     if (mlp.use_split) {
         a.lig_rows = lig_rows; a.lig_count = lig_rows ? lig_count : 0;
         if (G < 2 && a.lig_count > 0) G = 2;       // a workgroup for each destination class
-        if (cptr) {
+        if (cptr && a.cpn_p == 1) {
+            // `hybrid`: the protein rows (one chunk, plain k-NN) through the 12-wave kernel of the default graph, whatever edge_row_dealing says;
+            // the ligand rows (several chunks) in a second, chunk-walking launch over the ligand row list
+            int Gt = grid16(count, V16T_WAVES);
+            a.lig_rows = nullptr; a.lig_count = 0;
+#define TD_V16T_LAUNCH_VIA(L2V)                                                                          \
+            do {                                                                                            \
+                TD_LDS_ONCE((edge_value16t_kernel<L2V, true>), V16T_LDS_BYTES);                             \
+                edge_value16t_kernel<L2V, true><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a); \
+            } while (0)
+            if (!mlp.l2_f16) TD_V16T_LAUNCH_VIA(0);
+            else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_V16T_LAUNCH_VIA(2);
+            else TD_V16T_LAUNCH_VIA(1);
+#undef TD_V16T_LAUNCH_VIA
+            if (lig_rows && lig_count > 0) {
+                a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.lig_rows = lig_rows; a.lig_count = lig_count;
+                a.mixed_count = nullptr; a.trace = nullptr;
+                TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
+                edge_value16_kernel<true, true><<<dim3(grid16(lig_count, V16_WAVES)), block, V16S_LDS_BYTES, s>>>(a);
+            }
+        } else if (cptr) {
             TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
             edge_value16_kernel<true, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
         } else if (gate_m) {
