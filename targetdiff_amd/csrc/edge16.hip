@@ -374,12 +374,13 @@ __device__ __forceinline__ void td_ln_relu16_skip(const float *__restrict__ KB, 
 // SCALED: the pieces are taken of z'' 2^15 (td_split_h2_scaled: four conversions per pair); otherwise of z'' itself (three: a truncation and
 // two residuals, 30 % less conversion time) -- which the caller picks for MLPs whose folded scale M is small (TdEdgeMlp::z_plain, pack.cpp):
 // z'' is around 1 / M, and only above 2^-6 do the pieces of the plain form keep 19 bits or more over the f16 subnormal floor.
-template <bool SCALED>
+// (NEB = 1, the chunk walk's half-empty chunk: the second block's halves of the words are zero)
+template <bool SCALED, int NEB = 2>
 __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
                                                       uint4 (&z1)[8], uint4 (&z2)[8]) {
-    float sc[2];
+    float sc[2] = {0.f, 0.f};
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) {
+    for (int eb = 0; eb < NEB; ++eb) {
         float sa = 0.f, sb = 0.f;
 #pragma unroll
         for (int hb = 0; hb < 8; ++hb) {
@@ -389,7 +390,7 @@ __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ 
         sc[eb] = sa + sb;
     }
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(sc[eb]), ln.c1, ln.c2));
+    for (int eb = 0; eb < NEB; ++eb) sc[eb] = __frsqrt_rn(fmaf(td_sum_groups(sc[eb]), ln.c1, ln.c2));
 #pragma unroll
     for (int hb = 0; hb < 8; ++hb) {
         const float4 kb4 = *reinterpret_cast<const float4 *>(KB + 16 * hb + 4 * g);
@@ -399,7 +400,7 @@ __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             za[r] = td_clamp01(fmaf(acc[0][hb][r], sc[0], kb[r]));
-            zb[r] = td_clamp01(fmaf(acc[1][hb][r], sc[1], kb[r]));
+            zb[r] = NEB == 2 ? td_clamp01(fmaf(acc[1][hb][r], sc[1], kb[r])) : 0.f;
         }
         if constexpr (SCALED) td_split_h2_scaled_x4(za, zb, w1, w2);
         else td_split_h2_x4(za, zb, w1, w2);
@@ -411,9 +412,10 @@ __device__ __forceinline__ void td_ln_relu16_pairs_eb(const float *__restrict__ 
 // ... and for the key pass's logits product, where z''^T is the B operand and the K slots run over hidden units: quad t of edge block eb
 // holds the hidden units 16 (2t + j / 4) + 4g + j % 4, j = 0 .. 7 (the two hidden blocks 2t, 2t + 1 of the lane), i.e. the pairs are
 // (r = 0, 1) and (r = 2, 3) of one accumulator tile.
-template <bool SCALED>
+// SKIP1 (chunk walk): `any1` = false (wave-uniform) leaves the second block -- all padding -- out: its pieces are zero.
+template <bool SCALED, bool SKIP1 = false>
 __device__ __forceinline__ void td_ln_relu16_pairs_k(const float *__restrict__ KB, int g, const floatx4_t (&acc)[2][8], const TdLn ln,
-                                                     uint4 (&z1)[2][4], uint4 (&z2)[2][4]) {
+                                                     uint4 (&z1)[2][4], uint4 (&z2)[2][4], bool any1 = true) {
     float sc[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
@@ -432,6 +434,11 @@ __device__ __forceinline__ void td_ln_relu16_pairs_k(const float *__restrict__ K
         const float4 kb0 = *reinterpret_cast<const float4 *>(KB + 16 * (2 * t) + 4 * g), kb1 = *reinterpret_cast<const float4 *>(KB + 16 * (2 * t + 1) + 4 * g);
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb) {
+            if (SKIP1 && eb == 1 && !any1) {
+                z1[eb][t] = make_uint4(0u, 0u, 0u, 0u);
+                z2[eb][t] = make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
             // pairs (r = 0, 1), (r = 2, 3) of the hidden blocks 2t, 2t + 1: x = the even member, y = the odd one
             const float x[4] = {td_clamp01(fmaf(acc[eb][2 * t][0], sc[eb], kb0.x)), td_clamp01(fmaf(acc[eb][2 * t][2], sc[eb], kb0.z)),
                                 td_clamp01(fmaf(acc[eb][2 * t + 1][0], sc[eb], kb1.x)), td_clamp01(fmaf(acc[eb][2 * t + 1][2], sc[eb], kb1.z))};
@@ -794,6 +801,9 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 
 #ifndef TD_KEY_WAVES
 #define TD_KEY_WAVES 12
 #endif
+#ifndef TD_KEY_WALK_F16
+#define TD_KEY_WALK_F16 0          // f16 logits in the chunk-walking key pass: measured slower (td_launch_edge_key16)
+#endif
 constexpr int K16S_WAVES = TD_KEY_WAVES;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
 #ifndef TD_KEY_PK
 #define TD_KEY_PK 3
@@ -825,11 +835,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
-    // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass of the default graph and of the one-chunk protein rows of a
-    // `hybrid` graph.  (The chunk walk and the unfused h2x key pass keep the fp32 product: their session / stateless / fused forms run
-    // different kernels on the same rows and are held bit-identical.)
+    // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass on rows of one chunk (the default graph, the protein rows of a
+    // `hybrid` graph); the chunk walk can (TD_KEY_WALK_F16) and does not: measured slower.  (The unfused h2x key pass keeps the fp32
+    // product: the fused and the unfused form of that stage run different kernels on the same rows and are held bit-identical.)
     constexpr bool L2H = L2 != 0;
-    static_assert(L2 == 0 || (SPLIT && !XV && GRAPH != 1 && STAGE == 0), "f16 logits: x2h key pass, rows of one chunk only");
+    static_assert(L2 == 0 || (SPLIT && !XV && STAGE == 0), "f16 logits: x2h key pass, bf16 first layer");
     constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1000,17 +1010,18 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             }
         };
 
-        if constexpr (L2H) {
-            // ---- logits on f16 piece pairs: z''^T (B operand, K = hidden units) leaves the LayerNorm as pairs scaled by 2^15; U_i (A operand) is
-            // built eight K slots at a time from a query scaled by a power of two so that |U_i| < 2^13 (|U| <= 8 max |W2k'| max |q|), split, and its
-            // six products (two edge blocks x {h2 h1', h1 h2', h1 h1'}) are issued between the next eight slots' FMAs.  The softmax takes the
-            // two scales off.
-            floatx4_t acc[2][8], lg[2];
-            Edge2 ed;
-            first_layer(i, c0, acc, ed);
+        // ---- logits on f16 piece pairs: z''^T (B operand, K = hidden units) leaves the LayerNorm as pairs scaled by 2^15; U_i (A operand) is
+        // built eight K slots at a time from a query scaled by a power of two so that |U_i| < 2^13 (|U| <= 8 max |W2k'| max |q|), split, and its
+        // six products (two edge blocks x {h2 h1', h1 h2', h1 h1'}) are issued between the next eight slots' FMAs.  Returns the factor that
+        // takes the two scales off (and applies the attention scale).
+        auto logits_h = [&](const floatx4_t (&acc)[2][8], floatx4_t (&lg)[2], const Edge2 &ed) -> float {
             uint4 zk1[2][4], zk2[2][4];
-            td_ln_relu16_pairs_k<!ZPLAIN>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, zk1, zk2);
-            float4 q0 = qpre0, q1 = qpre1;
+            td_ln_relu16_pairs_k<!ZPLAIN, CHUNKED>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, zk1, zk2, ed.any[1]);
+            float4 q0, q1;
+            if constexpr (CHUNKED) {
+                q0 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo);
+                q1 = *reinterpret_cast<const float4 *>(a.q + (size_t)i * TD_H + 8 * lo + 4);
+            } else { q0 = qpre0; q1 = qpre1; }
             float qm = fmaxf(fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w))),
                              fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
             qm = td_max16(qm);                                    // over the row's 128 query entries (16 lanes x 8; every lane group holds them all)
@@ -1025,6 +1036,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             auto product = [&](int t, int m) {                  // product m of K block t: the small ones first, on their own accumulators
                 const int eb = m & 1, kind = m >> 1;
                 if (TD_ABL == 6) { lg[eb][0] += __uint_as_float(pu1.x ^ zk1[eb][t].x ^ pu2.y ^ zk2[eb][t].y); return; }
+                if (CHUNKED && eb == 1 && !ed.any[1]) return;          // an all-pad second block is skipped
                 if (kind == 0) lgc[eb] = td_mfma16h(pu2, zk1[eb][t], lgc[eb]);
                 else if (kind == 1) lgc[eb] = td_mfma16h(pu1, zk2[eb][t], lgc[eb]);
                 else lg[eb] = td_mfma16h(pu1, zk1[eb][t], lg[eb]);
@@ -1059,8 +1071,17 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             for (int m = 0; m < 6; ++m) product(3, m);
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] += lgc[eb];
+            return __builtin_amdgcn_ldexpf(ZPLAIN ? TD_ATT_SCALE_16 : TD_ATT_SCALE_16 / TD_Z_SCALE, qe - 13);
+        };
+
+        if constexpr (L2H) {
+            if constexpr (!CHUNKED) {          // (the chunk walk takes its two sweeps for a row of one chunk as well: a second copy of the products spills)
+            floatx4_t acc[2][8], lg[2];
+            Edge2 ed;
+            first_layer(i, c0, acc, ed);
+            const float sc = logits_h(acc, lg, ed);
             floatx4_t pr[2];
-            td_softmax16x4(lg, ed.valid, ed.ew, pr, __builtin_amdgcn_ldexpf(ZPLAIN ? TD_ATT_SCALE_16 : TD_ATT_SCALE_16 / TD_Z_SCALE, qe - 13));
+            td_softmax16x4(lg, ed.valid, ed.ew, pr, sc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float *dst = a.alpha + ((size_t)c0 * TD_HEADS + 4 * g + r) * TD_K + lo;
@@ -1068,6 +1089,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
                 dst[16] = pr[1][r];
             }
             continue;
+            }
         } else if (!CHUNKED || nch == 1) {
             floatx4_t acc[2][8], lg[2];
             Edge2 ed;
@@ -1095,9 +1117,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             floatx4_t acc[2][8], lg[2];
             Edge2 ed;
             first_layer(i, c, acc, ed);
-            logits(acc, lg, ed);
+            float sc0 = TD_ATT_SCALE_16;
+            if constexpr (L2H) sc0 = logits_h(acc, lg, ed);
+            else logits(acc, lg, ed);
+            const float sc1 = sc0;
             float x0[4], x1[4], mn[4], ps[4];
-            const float sc0 = TD_ATT_SCALE_16, sc1 = TD_ATT_SCALE_16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 x0[r] = ed.valid[0] ? lg[0][r] * sc0 : -INFINITY;
@@ -1520,9 +1544,9 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     // the aggregation product on f16 piece pairs, exactly as in edge_value16t_kernel (the row distribution settings select between the two
-    // kernels and stay bit-identical): the default graph's bf16-first-layer instantiation
+    // kernels and stay bit-identical): the bf16-first-layer instantiations, chunk walk included
     constexpr bool L2H = L2 != 0;
-    static_assert(L2 == 0 || (SPLIT && !CHUNKED && !GATE_M), "f16 aggregation: the default graph's bf16-first-layer instantiation only");
+    static_assert(L2 == 0 || (SPLIT && !GATE_M), "f16 aggregation: the bf16-first-layer instantiations");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
@@ -1703,6 +1727,57 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 // k = 48): first layer, flips and products of the first block only, k-step j = edge 4g + j.
                 auto chunk_body = [&](auto full_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;
+                    if constexpr (L2H) {
+                        // f16 piece pairs (see edge_value16t_kernel): K slots (g, 2m) / (g, 2m + 1) = edges 4g + m / 16 + 4g + m of the chunk; a
+                        // half-empty chunk runs the first layer of its first block only and carries zeros in the second block's K slots
+                        float al[8];
+                        {
+                            const float *ap = a.alpha + ((size_t)c * TD_HEADS + lo) * TD_K + 4 * g;
+                            const float4 v0 = *reinterpret_cast<const float4 *>(ap);
+                            float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if constexpr (FULL) v1 = *reinterpret_cast<const float4 *>(ap + 16);
+                            al[0] = v0.x; al[1] = v1.x; al[2] = v0.y; al[3] = v1.y; al[4] = v0.z; al[5] = v1.z; al[6] = v0.w; al[7] = v1.w;
+                        }
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK, 0, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
+                        asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
+                        uint4 z1[8], z2[8];
+                        td_ln_relu16_pairs_eb<!ZPLAIN, FULL ? 2 : 1>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
+                        uint4 aq1, aq2;
+                        {
+                            unsigned p1[4], p2[4];
+                            const float ax[4] = {al[0] * 1024.0f, al[2] * 1024.0f, al[4] * 1024.0f, al[6] * 1024.0f};
+                            const float ay[4] = {al[1] * 1024.0f, al[3] * 1024.0f, al[5] * 1024.0f, al[7] * 1024.0f};
+                            td_split_h2_x4(ax, ay, p1, p2);
+                            aq1 = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+                            aq2 = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+                        }
+                        constexpr int TWS = 20, TWP = 16 * TWS;
+                        auto flip_store_h = [&](int hb) {
+                            unsigned *TW = reinterpret_cast<unsigned *>(TB + (hb & 1) * V16_TILE_FLOATS);
+                            *reinterpret_cast<uint4 *>(TW + lo * TWS + 4 * g) = z1[hb];
+                            *reinterpret_cast<uint4 *>(TW + TWP + lo * TWS + 4 * g) = z2[hb];
+                        };
+                        auto flip_load_h = [&](int hb, uint4 (&zq)[2]) {
+                            const unsigned *t = reinterpret_cast<const unsigned *>(TB + (hb & 1) * V16_TILE_FLOATS) + 4 * g * TWS + lo;
+                            zq[0] = make_uint4(t[0], t[TWS], t[2 * TWS], t[3 * TWS]);
+                            zq[1] = make_uint4(t[TWP], t[TWP + TWS], t[TWP + 2 * TWS], t[TWP + 3 * TWS]);
+                        };
+                        uint4 zqb[2][2];
+                        flip_store_h(0);
+                        flip_load_h(0, zqb[0]);
+#pragma unroll
+                        for (int hb = 0; hb < 8; ++hb) {
+                            if (hb + 1 < 8) {
+                                flip_store_h(hb + 1);
+                                flip_load_h(hb + 1, zqb[(hb + 1) & 1]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            zb[hb] = td_mfma16h(zqb[hb & 1][1], aq1, zb[hb]);          // (accumulates over the row's chunks)
+                            zb[hb] = td_mfma16h(zqb[hb & 1][0], aq2, zb[hb]);
+                            zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
+                        }
+                        return;
+                    } else {
                     constexpr int NS = FULL ? 8 : 4;
                     float al[NS];
                     {   // A operand of the aggregation product: alpha[edge][head lo] of this chunk
@@ -1747,6 +1822,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 #pragma unroll
                         for (int sx = 0; sx < NS; ++sx) zb[hb] = td_mfma16(bvb[hb & 1][sx], al[sx], zb[hb]);
                     }
+                    }
                 };
                 bool full = true;
                 if (SPLIT) full = __ballot(rcur.j[1] >= 0) != 0ull;        // (the fp32 first layer has no one-block path)
@@ -1754,10 +1830,11 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                 else chunk_body(std::false_type());
             }
             const float ssum = td_sum_groups(asum);          // S[head lo] over the node's chunks, in every lane group
+            constexpr float OUT_SCALE = L2 == 0 ? 1.0f : (ZPLAIN ? 1.0f / 1024.0f : 1.0f / (1024.0f * TD_Z_SCALE));
             float o0, o1;
             td_value_out16(zb, Wt_lane, o0, o1);
-            o0 = fmaf(B2[nout], ssum, o0);
-            o1 = fmaf(B2[nout + 4], ssum, o1);
+            o0 = fmaf(B2[nout], ssum, o0 * OUT_SCALE);
+            o1 = fmaf(B2[nout + 4], ssum, o1 * OUT_SCALE);
             if (a.out) {
                 a.out[(size_t)i * TD_H + nout] = o0;
                 a.out[(size_t)i * TD_H + nout + 4] = o1;
@@ -2298,6 +2375,23 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
         edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(a.count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
     } while (0)
+#define TD_KEY_LAUNCH_WALK_L2(L2V)                                                                                            \
+    do {                                                                                                                  \
+        TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V>), K16S_LDS_BYTES);                             \
+        edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+    } while (0)
+    // the chunk walk's key pass keeps the fp32 logits: on f16 piece pairs (TD_KEY_WALK_F16 = 1: 9 spilled registers at the 168 budget, the
+    // row's query and U_i rebuilt per chunk as before) C5 k = 48 / k = 64 key pass 11.16 -> 11.40 / 12.78 -> 12.89 ms per step, one call
+#if TD_KEY_WALK_F16
+#define TD_KEY_LAUNCH_WALK()                                                        \
+    do {                                                                            \
+        if (!mlp.l2_f16) TD_KEY_LAUNCH_WALK_L2(0);                                  \
+        else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_WALK_L2(2);           \
+        else TD_KEY_LAUNCH_WALK_L2(1);                                              \
+    } while (0)
+#else
+#define TD_KEY_LAUNCH_WALK() TD_KEY_LAUNCH_WALK_L2(0)
+#endif
     if (mlp.use_split) {                      // first layer on bf16 piece triples
         if (cptr && !h2x && cpn_p == 1) {
 #define TD_KEY_LAUNCH_VIA(L2V)                                                                                                    \
@@ -2311,9 +2405,9 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 #undef TD_KEY_LAUNCH_VIA
             if (lig_rows && lig_count > 0) {
                 a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
-                TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES);
+                TD_KEY_LAUNCH_WALK();
             }
-        } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH(K16S_WAVES, 0, 1, true, K16S_LDS_BYTES); }
+        } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH_WALK(); }
         else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
         else {
 #define TD_KEY_LAUNCH_L2(L2V)                                                                                                     \
@@ -2331,6 +2425,8 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         else { if (h2x) TD_KEY_LAUNCH(K16_WAVES, 1, 0, false, K16_LDS_BYTES); else TD_KEY_LAUNCH(K16_WAVES, 0, 0, false, K16_LDS_BYTES); }
     }
 #undef TD_KEY_LAUNCH
+#undef TD_KEY_LAUNCH_WALK
+#undef TD_KEY_LAUNCH_WALK_L2
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -2376,6 +2472,17 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     const dim3 block(V16_WAVES * 64);
     a.trace = wg_trace_slot(1);
     a.deal = mlp.deal_rows;
+#define TD_V16_LAUNCH_WALK_L2(L2V)                                                                       \
+    do {                                                                                                \
+        TD_LDS_ONCE((edge_value16_kernel<true, true, false, L2V>), V16S_LDS_BYTES);                     \
+        edge_value16_kernel<true, true, false, L2V><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);          \
+    } while (0)
+#define TD_V16_LAUNCH_WALK()                                                        \
+    do {                                                                            \
+        if (!mlp.l2_f16) TD_V16_LAUNCH_WALK_L2(0);                                  \
+        else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_V16_LAUNCH_WALK_L2(2);           \
+        else TD_V16_LAUNCH_WALK_L2(1);                                              \
+    } while (0)
     if (mlp.use_split) {
         a.lig_rows = lig_rows; a.lig_count = lig_rows ? lig_count : 0;
         if (G < 2 && a.lig_count > 0) G = 2;       // a workgroup for each destination class
@@ -2396,12 +2503,11 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
             if (lig_rows && lig_count > 0) {
                 a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.lig_rows = lig_rows; a.lig_count = lig_count;
                 a.mixed_count = nullptr; a.trace = nullptr;
-                TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
-                edge_value16_kernel<true, true><<<dim3(grid16(lig_count, V16_WAVES)), block, V16S_LDS_BYTES, s>>>(a);
+                G = grid16(lig_count, V16_WAVES);
+                TD_V16_LAUNCH_WALK();
             }
         } else if (cptr) {
-            TD_LDS_ONCE((edge_value16_kernel<true, true>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+            TD_V16_LAUNCH_WALK();
         } else if (gate_m) {
             TD_LDS_ONCE((edge_value16_kernel<true, false, true>), V16S_LDS_BYTES);
             edge_value16_kernel<true, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
