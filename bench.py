@@ -582,7 +582,10 @@ def main():
     slots_val = 32 * (cpn - 1) + (16 if (cpn > 1 and last <= 16 and args.cutoff_mode == 'knn') else 32)
     flop_val = 2 * (slots_val * 128 * 20 + slots_val * 128 * 16) + 2 * 128 * 128
     split = bool(model._native(dev).get_option('edge_key_split'))
-    l2_f16 = bool(model._native(dev).get_option('edge_second_layer_f16')) and split and default_graph
+    # second layer on f16 piece pairs: the value pass on every graph, the key pass on rows of one chunk (the default graph; the protein rows of
+    # `hybrid` / k < 32 / capped-radius graphs, which run the default graph's kernels through the chunk index); the chunk-walking key pass: fp32
+    l2_f16 = bool(model._native(dev).get_option('edge_second_layer_f16')) and split
+    l2_key = l2_f16 and (default_graph or cpn == 1)
 
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]
@@ -594,13 +597,16 @@ def main():
                    else (flop_key if cls == 'x2h_k' else flop_val))
         achieved = per_row * rows_per_launch / (ms * 1e-3) / 1e12
         # matrix-pipe bound of the kernel as built (algorithmic TFLOP/s): the first layer's share at the bf16 peak when it runs
-        # on piece triples (32-slot rows only; the chunked value pass keeps fp32), the rest at the fp32 peak
-        first_alg = 2 * min(fan_in, 32) * 128 * 20 * (cpn if fan_in > 32 else 1)
-        split_here = split and (default_graph or cls == 'x2h_k')
-        if split_here and l2_f16:
-            # + the second layer (logits / alpha^T z: 2 * 32 * 128 * 16 algorithmic FLOPs) as three f16 piece products at the 16-bit peak
-            second_alg = 2 * min(fan_in, 32) * 128 * 16
-            t_min = (FIRST_LAYER_FLOP_BF16_EXECUTED + 3 * 2 * 32 * 128 * 16) / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg - second_alg) / PEAK_FP32_MFMA_TFLOPS
+        # on piece triples, the second layer's at the 16-bit peak when it runs on f16 piece pairs, the rest at the fp32 peak
+        chunks = cpn if fan_in > 32 else 1
+        first_alg = 2 * min(fan_in, 32) * 128 * 20 * chunks
+        split_here = split
+        l2_here = l2_key if cls == 'x2h_k' else l2_f16
+        if split_here and l2_here:
+            # + the second layer (logits / alpha^T z: 2 * 32 * 128 * 16 algorithmic FLOPs per chunk) as three f16 piece products at the 16-bit peak
+            second_alg = 2 * (min(fan_in, 32) if fan_in <= 32 else (32 * cpn if cls == 'x2h_k' else slots_val)) * 128 * 16
+            t_min = (chunks * (FIRST_LAYER_FLOP_BF16_EXECUTED + 3 * 2 * 32 * 128 * 16) / PEAK_BF16_MFMA_TFLOPS
+                     + (per_row - first_alg - second_alg) / PEAK_FP32_MFMA_TFLOPS)
             bound = per_row / t_min
         elif split_here:
             t_min = cpn * FIRST_LAYER_FLOP_BF16_EXECUTED / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
@@ -630,7 +636,7 @@ def main():
                 'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
                 'first_layer': 'bf16 x 3 piece triples, K-packed: 4 x v_mfma_f32_16x16x32_bf16 per tile' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
                 'second_layer': ('f16 piece pairs (22 bits per operand), 3 x v_mfma_f32_16x16x32_f16 per tile; the per-row 128 x 128 product on the vector unit'
-                                 if (split_here and l2_f16) else 'fp32 (v_mfma_f32_16x16x4_f32); the per-row 128 x 128 product on the vector unit'),
+                                 if (split_here and l2_here) else 'fp32 (v_mfma_f32_16x16x4_f32); the per-row 128 x 128 product on the vector unit'),
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
                 # secondary bound: HBM bytes actually moved per launch (PMC) against the 8 TB/s roofline
                 'hbm_gbs': (traffic / (ms * 1e-3) / 1e9) if traffic else None,
@@ -642,9 +648,12 @@ def main():
     if default_graph:
         vk, kk = (('edge_value16t_kernel<L2> (12 waves)', 'edge_key16_kernel<false, 12, 0, 0, true, L2>') if split
                   else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, 0, false>'))
+    elif split and cpn == 1:      # one chunk per protein row: the default graph's kernels through the chunk index, the ligand rows in a second launch
+        vk = 'edge_value16t_kernel<L2, true> (12 waves; protein rows) + edge_value16_kernel<true, true, false, L2> (chunk-walking; ligand rows)'
+        kk = 'edge_key16_kernel<false, 12, 0, 2, true, L2> (protein rows) + edge_key16_kernel<false, 12, 0, 1, true, 0> (chunk-walking; ligand rows)'
     else:
-        vk = 'edge_value16_kernel<true, true> (chunk-walking)'
-        kk = 'edge_key16_kernel<false, 12, 0, 1, true>' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
+        vk = 'edge_value16_kernel<true, true, false, L2> (chunk-walking)' if split else 'edge_value16_kernel<false, true> (chunk-walking)'
+        kk = 'edge_key16_kernel<false, 12, 0, 1, true, 0>' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')
@@ -681,7 +690,8 @@ def main():
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
                    'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
-                   'edge_second_layer': 'f16 piece pairs of both operands (22 significant bits each), fp32 accumulate' if l2_f16 else 'fp32 MFMA',
+                   'edge_second_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate'
+                                          + ('' if l2_key else '; the chunk-walking key pass: fp32 MFMA')) if l2_f16 else 'fp32 MFMA'),
                    'step_launch': step_launch, 'build_tag': capi.build_tag(),
                    'parallelism': f'pocket-sharded x{world} (no data-path collective)'},
         'roofline': roofline,

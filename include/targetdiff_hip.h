@@ -121,10 +121,13 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *   "edge_key_split"         1 (default): the 21-wide radial / edge-type first layer of the attention passes on 32-slot rows
  *                            (x2h key and value passes, the h2x stage), of the chunked key pass and of the edge gate on v_mfma_f32_16x16x32_bf16
  *                            with the same exact three-piece split of both operands; 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
- *   "edge_second_layer_f16"  1 (default): the per-edge 128-deep products of the x2h key / value passes on the default k <= 32 graph
- *                            (logits = z . U_i, alpha^T z) on v_mfma_f32_16x16x32_f16, both operands as pairs of f16 pieces (22 significant
- *                            bits each, scaled by exact powers of two; three piece products, fp32 accumulation): within one to two fp32
- *                            roundings of the fp32 products; 0 = v_mfma_f32_16x16x4_f32 on the fp32 values
+ *   "edge_second_layer_f16"  1 (default): the per-edge 128-deep products of the x2h key / value passes (logits = z . U_i, alpha^T z) on
+ *                            v_mfma_f32_16x16x32_f16, both operands as pairs of f16 pieces (22 significant bits each, scaled by exact
+ *                            powers of two; three piece products, fp32 accumulation): within one to two fp32 roundings of the fp32
+ *                            products; 0 = v_mfma_f32_16x16x4_f32 on the fp32 values.  Applies to the value pass
+ *                            on every graph and to the key pass on rows of one 32-slot chunk (the default k = 32 graph; the protein rows
+ *                            of `hybrid`, k < 32 and capped-radius graphs); the key pass of rows that span several chunks (k > 32, the
+ *                            ligand rows of `hybrid`) computes fp32 logits under either setting
  *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
  *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with
  *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only

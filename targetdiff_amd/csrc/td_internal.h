@@ -65,7 +65,7 @@ struct TdEdgeMlp {
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     float w2_bound;        // key MLPs: 8 max |W2'| (folded second Linear): |U_i[n][head]| = |sum_d W2'[8 head + d][n] q_i[8 head + d]| <= w2_bound max |q_i|
                            // (the f16 logits product scales the query by a power of two from this bound, edge16.hip)
-    bool l2_f16;           // x2h passes of the default graph: logits / alpha^T z on v_mfma_f32_16x16x32_f16 with f16 piece pairs (model option "edge_second_layer_f16")
+    bool l2_f16;           // x2h passes: logits (rows of one chunk) / alpha^T z (every graph) on v_mfma_f32_16x16x32_f16 with f16 piece pairs (model option "edge_second_layer_f16")
     bool z_plain;          // f16 second layer: the folded scale M is at most TD_Z_PLAIN_MAX_M, take the f16 pieces of z'' itself (edge16.hip, td_ln_relu16_pairs_*)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
@@ -150,12 +150,13 @@ struct TdOptions {
     int h2x_fused = 1;             // one launch for the h2x stage's key + value halves (0: two launches, alpha through memory)
     int node_proj_split = 1;       // node-side GEMMs on exact bf16 x 3 operand pieces with fp32 accumulation (0: fp32 MFMA)
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
-    int edge_second_layer_f16 = 1; // x2h passes, default graph: logits / alpha^T z on f16 piece pairs (0: fp32 MFMA products)
+    int edge_second_layer_f16 = 1; // x2h passes: logits / alpha^T z on f16 piece pairs (0: fp32 MFMA products; the chunk-walking key pass is fp32 either way)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
     int edge_row_dealing = 2;      // x2h key / value passes: units of rows dealt round-robin to an XCD's workgroups (0: one
                                    // contiguous share per workgroup; 1: a fixed row sequence per wave; 2: the workgroup's rows
-                                   // handed to its waves one at a time through an LDS counter)
+                                   // handed to its waves one at a time through an LDS counter; the value pass's protein rows on a
+                                   // general graph with one chunk per protein row always take 2: the 12-wave kernel has no other form)
     int node_proj_bpipe = 0;       // split node GEMMs: register double-buffering of the B fragments (LDS reads ahead of the MFMAs; measured
                                    // slower at C2: 0.848 vs 0.817 ms per step, profiles/r03b_*; kept as a switch)
     int node_proj_async = 1;    // split node GEMMs: B chunks by inline-asm global_load_lds + an explicit wait per round (0: the builtin, which the compiler serialises)

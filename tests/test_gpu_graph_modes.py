@@ -414,10 +414,13 @@ def test_sampling_with_fp32_edge_first_layer(state_dict):
     close(torch.stack(res[(1, True)]['pos_traj']), torch.stack(res[(0, True)]['pos_traj']), 5e-5)
 
 
-def test_sampling_with_fp32_second_layer(state_dict):
+@pytest.mark.parametrize('cfg', [dict(), dict(cutoff_mode='hybrid'), dict(knn=48)], ids=['knn32', 'hybrid', 'knn48'])
+def test_sampling_with_fp32_second_layer(state_dict, cfg):
     """edge_second_layer_f16 = 0 (logits and alpha^T z on the fp32 matrix instruction instead of f16 piece pairs) stays a tested path: 5 reverse
     steps through the session and the stateless forward against the default -- same types, positions within the sampling tolerance, session ==
-    stateless bit for bit under either setting.  (That the option is live -- the two settings do not produce identical features -- is asserted in
+    stateless bit for bit under either setting.  On the default graph, on a `hybrid` graph (protein rows through the default graph's kernels,
+    ligand rows through the chunk walk) and at k = 48 (chunk walk: the value pass follows the option, the key pass is fp32 either way).  (That
+    the option is live -- the two settings do not produce identical features -- is asserted in
     tests/test_gpu_weight_regimes.py::test_forward_weight_regimes_vs_reference.)"""
     from oracle import draws
     from oracle.make_golden_r2 import hybrid_small_batch
@@ -427,7 +430,7 @@ def test_sampling_with_fp32_second_layer(state_dict):
     res = {}
     for l2 in (1, 0):
         for use_session in (True, False):
-            model = _model(state_dict)
+            model = _model(state_dict, **cfg)
             assert model._native(dev).get_option('edge_second_layer_f16') == 1            # shipped default
             model._native(dev).set_option('edge_second_layer_f16', l2)
             res[(l2, use_session)] = model.sample_diffusion(

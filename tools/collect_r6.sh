@@ -19,6 +19,7 @@ python bench.py --workload c4 > $OUT/bench_c4_1gpu.json 2>/dev/null
 python bench.py --workload c5 --no-cpu-baseline --knn 64 > $OUT/bench_c5_knn64.json 2>/dev/null
 python bench.py --workload c5 --no-cpu-baseline --cutoff-mode hybrid > $OUT/bench_c5_hybrid.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-full-run --no-sweep --no-stateless --option edge_second_layer_f16=0 > $OUT/bench_c2_fp32_second_layer.json 2>/dev/null
+bash tools/prof_general_graphs.sh $OUT > /dev/null 2>&1; cd "${GRAFT_REPO_ROOT:-.}"
 python - <<PY
 import json
 for n in ('bench_c4_1gpu_b50', 'bench_c4_1gpu', 'bench_c5_knn64', 'bench_c5_hybrid', 'bench_c2_fp32_second_layer'):
