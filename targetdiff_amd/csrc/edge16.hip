@@ -547,7 +547,7 @@ __device__ __forceinline__ void td_split_pair(float x, float y, unsigned &p1, un
 // K-packed piece tables (pack_pk4_table, pack.cpp): one (dst class, source class) table is QA[hb 8][lane 64] (16 B), QB (16 B), H7 (8 B),
 // QC (16 B) = 28 KiB in global memory; in LDS a kernel keeps QA, QB and either H7 (PK = 2: 20 KiB) or QC (PK = 1: 24 KiB)
 constexpr int E16Q_GLOBAL_CS_U4 = 512 + 512 + 256 + 512;
-template <int PK> constexpr int e16q_cs_u4() { return PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256; }
+template <int PK> constexpr int e16q_cs_u4() { return PK == 5 ? 512 + 512 : (PK == 1 ? 512 + 512 + 512 : 512 + 512 + 256); }     // (PK = 5: the f16 piece-pair table, pack_h2_table)
 template <int PK> constexpr int e16q_u4() { return PK == 3 ? 2 * e16q_cs_u4<2>() + 2 * e16q_cs_u4<1>() : 4 * e16q_cs_u4<PK>(); }   // all four (dst class, source class) tables
 template <int PK> constexpr int e16q_half_u4() { return PK == 4 ? e16q_cs_u4<2>() + e16q_cs_u4<1>() : 2 * e16q_cs_u4<PK>(); }      // one destination class
 // stage `ncs` consecutive (dst class, source class) tables from the packed blob into LDS (all waves of the workgroup; the caller's
@@ -668,6 +668,57 @@ __device__ __forceinline__ void td_pk4_tiles(const uint4 *__restrict__ Rs, int l
     }
 }
 
+// ---- PK = 5: the first layer on f16 piece PAIRS (pack_h2_table, pack.cpp; the x2h key pass) -- two products per tile instead of four, two
+// 16-byte table reads per hidden block instead of three.  B operands of the NEB edge blocks: the five inputs m[eb][0..4] of the lane's
+// Gaussians (masked to the source class) as h1 = truncation to f16, h2 = f16 of the exact residual; ct[eb]: f16 1.0 in the high half (the type
+// column's input) or 0.
+//   I0 x (b1_0 b1_1 | b1_2 b1_3 | b1_0 b1_1 | b1_2 b1_3)      I1 x (b2_0 b2_1 | b2_2 b2_3 | b1_4 b2_4 | b1_4 1)
+template <int NEB>
+__device__ __forceinline__ void td_h2_bquads(const float (&m)[NEB][5], const unsigned (&ct)[NEB], uint4 (&bq)[NEB][2]) {
+    if constexpr (NEB == 2) {
+        const float x[4] = {m[0][0], m[0][2], m[1][0], m[1][2]}, y[4] = {m[0][1], m[0][3], m[1][1], m[1][3]};
+        unsigned a1[4], a2[4], u1, u2;
+        td_split_h2_x4(x, y, a1, a2);
+        td_split_h2(m[0][4], m[1][4], u1, u2);          // k4 of the two blocks share a word
+        bq[0][0] = make_uint4(a1[0], a1[1], a1[0], a1[1]);
+        bq[1][0] = make_uint4(a1[2], a1[3], a1[2], a1[3]);
+        bq[0][1] = make_uint4(a2[0], a2[1], __builtin_amdgcn_perm(u2, u1, 0x05040100u), __builtin_amdgcn_perm(ct[0], u1, 0x07060100u));
+        bq[1][1] = make_uint4(a2[2], a2[3], __builtin_amdgcn_perm(u2, u1, 0x07060302u), __builtin_amdgcn_perm(ct[1], u1, 0x07060302u));
+    } else {
+        unsigned a1[2], a2[2], u1, u2;
+        td_split_h2(m[0][0], m[0][1], a1[0], a2[0]);
+        td_split_h2(m[0][2], m[0][3], a1[1], a2[1]);
+        td_split_h2(m[0][4], 0.f, u1, u2);
+        bq[0][0] = make_uint4(a1[0], a1[1], a1[0], a1[1]);
+        bq[0][1] = make_uint4(a2[0], a2[1], __builtin_amdgcn_perm(u2, u1, 0x05040100u), __builtin_amdgcn_perm(ct[0], u1, 0x07060100u));
+    }
+}
+// the 2 x 8 x NEB products of one (dst class, source class) table at Rs (LDS, offset by the lane): I0[hb][lane] at Rs[hb * 64], I1 at
+// Rs[512 + hb * 64].  AHEAD: the quad of step n + 1 is read before step n's products are issued (as td_pk4_tiles<.., AH < 0>).
+template <bool AHEAD, int NEB>
+__device__ __forceinline__ void td_h2_tiles(const uint4 *__restrict__ Rs, const uint4 (&bq)[NEB][2], floatx4_t (&acc)[2][8]) {
+    auto quad = [&](int st) -> uint4 { return Rs[((st & 1) ? 0 : 512) + (st >> 1) * 64]; };      // I1 (the small products) first
+    if constexpr (AHEAD) {
+        uint4 cur = quad(0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            uint4 nxt = cur;
+            if (st + 1 < 16) nxt = quad(st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int eb = 0; eb < NEB; ++eb) acc[eb][st >> 1] = td_mfma16h(cur, bq[eb][(st & 1) ? 0 : 1], acc[eb][st >> 1]);
+            cur = nxt;
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const uint4 q = quad(st);
+#pragma unroll
+            for (int eb = 0; eb < NEB; ++eb) acc[eb][st >> 1] = td_mfma16h(q, bq[eb][(st & 1) ? 0 : 1], acc[eb][st >> 1]);
+        }
+    }
+}
+
 // Rp: the piece table in LDS -- all of it, or (ONE_CLASS) the half of the one destination class the workgroup serves.
 // PK = 1 / 2: the K-packed form -- FOUR products per (hidden block, edge block) and source class instead of six: the 21 inputs' six piece
 // products are 123 (piece, piece, k) slot pairs and fit 4 x 32 K slots (pack_pk4_table, pack.cpp); lane group g owns the Gaussians
@@ -744,6 +795,21 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
     before_products();
     // products of source class sl with the edge inputs (B operand: zeros for the edges of the other class)
     auto products4 = [&](int sl) {
+        if constexpr (PK == 5) {
+            float mm[NEB][5];
+            unsigned ct[NEB];
+            uint4 bh[NEB][2];
+#pragma unroll
+            for (int eb = 0; eb < NEB; ++eb) {
+                const bool keep = !has[1 - sl][eb] || slot[eb] == sl;       // edges of the other class contribute nothing
+#pragma unroll
+                for (int j = 0; j < 5; ++j) mm[eb][j] = keep ? gv[eb][j] : 0.f;
+                ct[eb] = keep ? 0x3c000000u : 0u;                           // f16 1.0: the type column's input
+            }
+            td_h2_bquads<NEB>(mm, ct, bh);
+            td_h2_tiles<AH != 0, NEB>(Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<5>() + lane, bh, acc);
+            return;
+        } else {
         uint4 bq[NEB][4];
         const unsigned ctype = td_pk4_ctype(g);
 #pragma unroll
@@ -768,6 +834,7 @@ __device__ __forceinline__ void td_first_layer_split16(const Args16 &a, const ui
             else td_pk4_tiles<2, AH, NEB>(Rp + lane, lane, bq, acc);
         } else
             td_pk4_tiles<PK, AH, NEB>(Rp + (size_t)((ONE_CLASS ? 0 : cls * 2) + sl) * e16q_cs_u4<PK>() + lane, lane, bq, acc);
+        }
     };
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
@@ -830,7 +897,9 @@ static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the ro
 // SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
 // L2 (x2h key pass of the default graph, bf16 first layer): the logits product -- 0: fp32 (v_mfma_f32_16x16x4_f32), 1: f16 piece pairs
 // with z'' scaled by 2^15, 2: f16 piece pairs of z'' itself (the launcher's reading of TdEdgeMlp::l2_f16 / z_plain).
-template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false, int L2 = 0>
+// FL (x2h key pass, bf16-class first layer): 1 = the first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h; model option
+// "edge_first_layer_f16"), 0 = on the exact bf16 piece triples
+template <bool XV, int WAVES, int STAGE, int GRAPH = 0, bool SPLIT = false, int L2 = 0, int FL = 0>
 __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
@@ -840,7 +909,11 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     // product: the fused and the unfused form of that stage run different kernels on the same rows and are held bit-identical.)
     constexpr bool L2H = L2 != 0;
     static_assert(L2 == 0 || (SPLIT && !XV && STAGE == 0), "f16 logits: x2h key pass, bf16 first layer");
-    constexpr int RF = SPLIT ? e16q_u4<TD_KEY_PK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
+    // the x2h key pass's first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h); the h2x key / value halves keep the bf16 piece triples
+    // (they are held bit-identical to the fused h2x kernel)
+    static_assert(FL == 0 || (SPLIT && !XV && STAGE == 0), "f16 first layer: x2h key pass, bf16-class instantiations");
+    constexpr int KPK = FL ? 5 : TD_KEY_PK;
+    constexpr int RF = SPLIT ? e16q_u4<KPK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float4 *Rt = reinterpret_cast<const float4 *>(lds);
@@ -851,7 +924,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         if (SPLIT) {
-            if constexpr (TD_KEY_PK == 3) {
+            if constexpr (KPK == 5)
+                td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16h), reinterpret_cast<float4 *>(lds), e16q_u4<5>(), tid, WAVES * 64);
+            else if constexpr (TD_KEY_PK == 3) {
                 td_stage_pk4<2>(a.mlp.R16q, lds, 2, tid, WAVES * 64);
                 td_stage_pk4<1>(a.mlp.R16q + (size_t)2 * E16Q_GLOBAL_CS_U4 * 4, lds + 2 * e16q_cs_u4<2>() * 4, 2, tid, WAVES * 64);
             } else
@@ -922,9 +997,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
             // a chunk whose second block is all padding (wave-uniform): the xv pass (8 waves, 256 registers) has room for a path without
             // it; the key pass at 168 registers does not (126 spilled registers) and only leaves the block out of its LayerNorm and logits
             if (XV && CHUNKED && __ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<EW, false, false, 1, false, TD_KEY_PK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 1, false, KPK>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
             else
-                td_first_layer_split16<EW, false, false, 2, CHUNKED, TD_KEY_PK, (CHUNKED || XV) ? 0 : TD_KEY_AH, decltype(fetch_q), L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
+                td_first_layer_split16<EW, false, false, 2, CHUNKED, KPK, (CHUNKED || XV) ? 0 : TD_KEY_AH, decltype(fetch_q), L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed, fetch_q);
         } else
             td_first_layer16<EW, CHUNKED>(a, Rt, KB, offk, i, lane, acc, ed, c);
     };
@@ -1538,10 +1613,13 @@ constexpr int TD_ROW_COST_PURE = 100, TD_ROW_COST_MIXED = 122;
 // (models/uni_transformer.py:36-37, 62-63).  v_e = W2v z_e + b2v is never formed here; the gate's logit is linear in it, so it is
 // (W2v^T w) . z_e + (w . b2v + b) -- one 128-wide dot product with a vector packed at model creation --, and since the gate multiplies v_e,
 // which enters the output linearly, it multiplies the attention weight instead: alpha_e e_w_e feeds both the aggregation and S.
-template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false, int L2 = 0>
+// FL: 1 = the first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h; see edge_key16_kernel)
+template <bool SPLIT, bool CHUNKED = false, bool GATE_M = false, int L2 = 0, int FL = 0>
 __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
-    constexpr int RF = SPLIT ? e16q_half_u4<TD_VALUE_PK>() * 4 : E16_R_FLOATS;
+    static_assert(FL == 0 || SPLIT, "f16 first layer: the bf16-class instantiations");
+    constexpr int VPK = FL ? 5 : TD_VALUE_PK;
+    constexpr int RF = SPLIT ? e16q_half_u4<VPK>() * 4 : E16_R_FLOATS;
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     // the aggregation product on f16 piece pairs, exactly as in edge_value16t_kernel (the row distribution settings select between the two
     // kernels and stay bit-identical): the bf16-first-layer instantiations, chunk walk included
@@ -1589,7 +1667,12 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
     const int GP = gridDim.x - GL;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
-        if (SPLIT) td_stage_pk4<TD_VALUE_PK>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 2, tid, V16_WAVES * 64);
+        if (SPLIT) {
+            if constexpr (VPK == 5)
+                td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16h) + (size_t)my_cls * 2 * e16q_cs_u4<5>(), reinterpret_cast<float4 *>(lds), 2 * e16q_cs_u4<5>(), tid, V16_WAVES * 64);
+            else
+                td_stage_pk4<TD_VALUE_PK>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 2, tid, V16_WAVES * 64);
+        }
         else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(lds), RF / 4, tid, V16_WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt), reinterpret_cast<float4 *>(lds + RF), V16_W_FLOATS / 4, tid,
                        V16_WAVES * 64);
@@ -1738,7 +1821,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                             if constexpr (FULL) v1 = *reinterpret_cast<const float4 *>(ap + 16);
                             al[0] = v0.x; al[1] = v1.x; al[2] = v0.y; al[3] = v1.y; al[4] = v0.z; al[5] = v1.z; al[6] = v0.w; al[7] = v1.w;
                         }
-                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK, 0, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, VPK, 0, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
                         asum += ((al[0] + al[1]) + (al[2] + al[3])) + ((al[4] + al[5]) + (al[6] + al[7]));
                         uint4 z1[8], z2[8];
                         td_ln_relu16_pairs_eb<!ZPLAIN, FULL ? 2 : 1>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
@@ -1790,7 +1873,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
                         }
                     }
                     if constexpr (SPLIT)
-                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, TD_VALUE_PK, 0>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
+                        td_first_layer_split16<false, true, false, FULL ? 2 : 1, false, VPK, 0>(a, reinterpret_cast<const uint4 *>(lds), KB, offk, rcur, i, lane, acc, ed);
                     else
                         td_first_layer_compute16<false, true>(a, Rt, KB, offk, rcur, lane, acc, ed);
                     float part = (al[0] + al[1]) + (al[2] + al[3]);
@@ -1890,7 +1973,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
             }
             // (P_i joins before the products on the default graph, as in edge_value16t_kernel -- the same bits whichever kernel the row
             // distribution setting selects; the chunked instantiation hides the P_i loads behind the products instead)
-            td_first_layer_split16<false, true, CHUNKED, 2, false, TD_VALUE_PK, 1, TdNoHook, L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+            td_first_layer_split16<false, true, CHUNKED, 2, false, VPK, 1, TdNoHook, L2H>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         }
         else
             td_first_layer_compute16<false>(a, Rt, KB, offk, rin, lane, acc, ed);
@@ -2047,11 +2130,13 @@ static_assert(V16T_LDS_BYTES <= 160 * 1024, "value pass (12 waves): LDS");
 // L2: the aggregation product -- 0 fp32, 1 f16 piece pairs of z'' 2^15, 2 f16 piece pairs of z'' (see edge_key16_kernel)
 // VIA (`hybrid` graphs: protein rows of one chunk, found through cptr): the launcher passes no ligand rows -- every workgroup serves the
 // protein class and drops the ligand rows it meets; those are walked chunk by chunk by edge_value16_kernel<true, true> in a second launch.
-template <int L2, bool VIA = false>
+// FL: 1 = the first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h; see edge_key16_kernel)
+template <int L2, bool VIA = false, int FL = 0>
 __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a) {
     constexpr bool ZPLAIN = L2 == 2;
     constexpr int WAVES = V16T_WAVES;
-    constexpr int RF = e16q_half_u4<V16T_PK>() * 4;
+    constexpr int VPK = FL ? 5 : V16T_PK;
+    constexpr int RF = e16q_half_u4<VPK>() * 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;          // lds + RF: Wt[d 8][kq 32][head 16] x 4 k (td_value_out16)
     const int lo = lane & 15, g = lane >> 4;
@@ -2076,7 +2161,9 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
     const int GP = gridDim.x - GL;
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry
     {
-        if constexpr (V16T_PK == 4) {
+        if constexpr (VPK == 5)
+            td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16h) + (size_t)my_cls * 2 * e16q_cs_u4<5>(), reinterpret_cast<float4 *>(lds), 2 * e16q_cs_u4<5>(), tid, WAVES * 64);
+        else if constexpr (V16T_PK == 4) {
             td_stage_pk4<2>(a.mlp.R16q + (size_t)my_cls * 2 * E16Q_GLOBAL_CS_U4 * 4, lds, 1, tid, WAVES * 64);
             td_stage_pk4<1>(a.mlp.R16q + (size_t)(my_cls * 2 + 1) * E16Q_GLOBAL_CS_U4 * 4, lds + e16q_cs_u4<2>() * 4, 1, tid, WAVES * 64);
         } else
@@ -2158,7 +2245,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
         // the A operand.  Tiles: [16 edge rows][20 words] per piece (the row stride of 20 keeps both the 16-byte stores and the 4-byte reads
         // conflict-free, as in the fp32 form).  alpha goes in scaled by 2^10 and z'' by 2^15 (exact) so that small weights and
         // activations keep their 22 bits above the f16 subnormal floor; the scales come off the two outputs.
-        td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+        td_first_layer_split16<false, true, false, 2, false, VPK, V16T_AH, TdNoHook, true>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         uint4 z1[8], z2[8];
         td_ln_relu16_pairs_eb<!ZPLAIN>(KB, g, acc, TdLn{a.mlp.ln_c1, a.mlp.ln_c2}, z1, z2);
         uint4 aq1, aq2;
@@ -2197,7 +2284,7 @@ __global__ __launch_bounds__(V16T_WAVES * 64) void edge_value16t_kernel(Args16 a
             zb[hb] = td_mfma16h(zqb[hb & 1][0], aq1, zb[hb]);
         }
         } else {
-        td_first_layer_split16<false, true, false, 2, false, V16T_PK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
+        td_first_layer_split16<false, true, false, 2, false, VPK, V16T_AH>(a, reinterpret_cast<const uint4 *>(lds), KB, offr, rin, i, lane, acc, ed);
         // Zbar^T: zb[hb][r] = sum_e z[e][16hb + 4g + r] alpha[e][head lo], one hidden block at a time through the wave's flip tile
         auto flip_store = [&](int hb) {
 #pragma unroll
@@ -2375,11 +2462,18 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         TD_LDS_ONCE((edge_key16_kernel<false, WAVES, STAGE, CH, SP>), BYTES);                                 \
         edge_key16_kernel<false, WAVES, STAGE, CH, SP><<<dim3(grid16(a.count, WAVES)), dim3(WAVES * 64), BYTES, s>>>(a); \
     } while (0)
-#define TD_KEY_LAUNCH_WALK_L2(L2V)                                                                                            \
+    // (GR: the kernel's GRAPH; L2V: its second-layer variant; the first-layer variant follows TdEdgeMlp::l1_f16)
+#define TD_KEY_LAUNCH_X2H(GR, L2V)                                                                                            \
     do {                                                                                                                  \
-        TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V>), K16S_LDS_BYTES);                             \
-        edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+        if (mlp.l1_f16) {                                                                                                 \
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, GR, true, L2V, 1>), K16S_LDS_BYTES);                      \
+            edge_key16_kernel<false, K16S_WAVES, 0, GR, true, L2V, 1><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+        } else {                                                                                                          \
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, GR, true, L2V, 0>), K16S_LDS_BYTES);                      \
+            edge_key16_kernel<false, K16S_WAVES, 0, GR, true, L2V, 0><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+        }                                                                                                                 \
     } while (0)
+#define TD_KEY_LAUNCH_WALK_L2(L2V) TD_KEY_LAUNCH_X2H(1, L2V)
     // the chunk walk's key pass keeps the fp32 logits: on f16 piece pairs (TD_KEY_WALK_F16 = 1: 9 spilled registers at the 168 budget, the
     // row's query and U_i rebuilt per chunk as before) C5 k = 48 / k = 64 key pass 11.16 -> 11.40 / 12.78 -> 12.89 ms per step, one call
 #if TD_KEY_WALK_F16
@@ -2394,11 +2488,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 #endif
     if (mlp.use_split) {                      // first layer on bf16 piece triples
         if (cptr && !h2x && cpn_p == 1) {
-#define TD_KEY_LAUNCH_VIA(L2V)                                                                                                    \
-            do {                                                                                                                  \
-                TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 2, true, L2V>), K16S_LDS_BYTES);                             \
-                edge_key16_kernel<false, K16S_WAVES, 0, 2, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
-            } while (0)
+#define TD_KEY_LAUNCH_VIA(L2V) TD_KEY_LAUNCH_X2H(2, L2V)
             if (!mlp.l2_f16) TD_KEY_LAUNCH_VIA(0);
             else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_VIA(2);
             else TD_KEY_LAUNCH_VIA(1);
@@ -2410,11 +2500,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH_WALK(); }
         else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
         else {
-#define TD_KEY_LAUNCH_L2(L2V)                                                                                                     \
-            do {                                                                                                                  \
-                TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 0, true, L2V>), K16S_LDS_BYTES);                             \
-                edge_key16_kernel<false, K16S_WAVES, 0, 0, true, L2V><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
-            } while (0)
+#define TD_KEY_LAUNCH_L2(L2V) TD_KEY_LAUNCH_X2H(0, L2V)
             if (!mlp.l2_f16) TD_KEY_LAUNCH_L2(0);
             else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_L2(2);
             else TD_KEY_LAUNCH_L2(1);
@@ -2427,6 +2513,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 #undef TD_KEY_LAUNCH
 #undef TD_KEY_LAUNCH_WALK
 #undef TD_KEY_LAUNCH_WALK_L2
+#undef TD_KEY_LAUNCH_X2H
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -2472,11 +2559,28 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
     const dim3 block(V16_WAVES * 64);
     a.trace = wg_trace_slot(1);
     a.deal = mlp.deal_rows;
-#define TD_V16_LAUNCH_WALK_L2(L2V)                                                                       \
-    do {                                                                                                \
-        TD_LDS_ONCE((edge_value16_kernel<true, true, false, L2V>), V16S_LDS_BYTES);                     \
-        edge_value16_kernel<true, true, false, L2V><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);          \
+    // (the 8-wave kernel, bf16-class first layer: CH = chunk walk, GM = gate from the value vector, L2V / TdEdgeMlp::l1_f16 = the layers' variants)
+#define TD_V16_LAUNCH(CH, GM, L2V)                                                                            \
+    do {                                                                                                     \
+        if (mlp.l1_f16) {                                                                                    \
+            TD_LDS_ONCE((edge_value16_kernel<true, CH, GM, L2V, 1>), V16S_LDS_BYTES);                        \
+            edge_value16_kernel<true, CH, GM, L2V, 1><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);             \
+        } else {                                                                                             \
+            TD_LDS_ONCE((edge_value16_kernel<true, CH, GM, L2V, 0>), V16S_LDS_BYTES);                        \
+            edge_value16_kernel<true, CH, GM, L2V, 0><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);             \
+        }                                                                                                    \
     } while (0)
+#define TD_V16T_LAUNCH_ANY(L2V, VIAV)                                                                         \
+    do {                                                                                                     \
+        if (mlp.l1_f16) {                                                                                    \
+            TD_LDS_ONCE((edge_value16t_kernel<L2V, VIAV, 1>), V16T_LDS_BYTES);                               \
+            edge_value16t_kernel<L2V, VIAV, 1><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);   \
+        } else {                                                                                             \
+            TD_LDS_ONCE((edge_value16t_kernel<L2V, VIAV, 0>), V16T_LDS_BYTES);                               \
+            edge_value16t_kernel<L2V, VIAV, 0><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);   \
+        }                                                                                                    \
+    } while (0)
+#define TD_V16_LAUNCH_WALK_L2(L2V) TD_V16_LAUNCH(true, false, L2V)
 #define TD_V16_LAUNCH_WALK()                                                        \
     do {                                                                            \
         if (!mlp.l2_f16) TD_V16_LAUNCH_WALK_L2(0);                                  \
@@ -2491,11 +2595,7 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
             // the ligand rows (several chunks) in a second, chunk-walking launch over the ligand row list
             int Gt = grid16(count, V16T_WAVES);
             a.lig_rows = nullptr; a.lig_count = 0;
-#define TD_V16T_LAUNCH_VIA(L2V)                                                                          \
-            do {                                                                                            \
-                TD_LDS_ONCE((edge_value16t_kernel<L2V, true>), V16T_LDS_BYTES);                             \
-                edge_value16t_kernel<L2V, true><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a); \
-            } while (0)
+#define TD_V16T_LAUNCH_VIA(L2V) TD_V16T_LAUNCH_ANY(L2V, true)
             if (!mlp.l2_f16) TD_V16T_LAUNCH_VIA(0);
             else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_V16T_LAUNCH_VIA(2);
             else TD_V16T_LAUNCH_VIA(1);
@@ -2509,29 +2609,21 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
         } else if (cptr) {
             TD_V16_LAUNCH_WALK();
         } else if (gate_m) {
-            TD_LDS_ONCE((edge_value16_kernel<true, false, true>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, false, true><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+            TD_V16_LAUNCH(false, true, 0);
         } else if (a.deal == 2) {          // (the default) rows through the LDS ticket: the 12-wave kernel
             int Gt = grid16(count, V16T_WAVES);
             if (Gt < 2 && a.lig_count > 0) Gt = 2;
-#define TD_V16T_LAUNCH(L2V)                                                                              \
-            do {                                                                                            \
-                TD_LDS_ONCE((edge_value16t_kernel<L2V>), V16T_LDS_BYTES);                                   \
-                edge_value16t_kernel<L2V><<<dim3(Gt), dim3(V16T_WAVES * 64), V16T_LDS_BYTES, s>>>(a);       \
-            } while (0)
+#define TD_V16T_LAUNCH(L2V) TD_V16T_LAUNCH_ANY(L2V, false)
             if (!mlp.l2_f16) TD_V16T_LAUNCH(0);
             else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_V16T_LAUNCH(2);
             else TD_V16T_LAUNCH(1);
 #undef TD_V16T_LAUNCH
         } else if (mlp.l2_f16 && mlp.z_plain && !TD_ZPLAIN_OFF) {
-            TD_LDS_ONCE((edge_value16_kernel<true, false, false, 2>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, false, false, 2><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+            TD_V16_LAUNCH(false, false, 2);
         } else if (mlp.l2_f16) {
-            TD_LDS_ONCE((edge_value16_kernel<true, false, false, 1>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, false, false, 1><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+            TD_V16_LAUNCH(false, false, 1);
         } else {
-            TD_LDS_ONCE((edge_value16_kernel<true, false>), V16S_LDS_BYTES);
-            edge_value16_kernel<true, false><<<dim3(G), block, V16S_LDS_BYTES, s>>>(a);
+            TD_V16_LAUNCH(false, false, 0);
         }
     } else if (cptr) {
         TD_LDS_ONCE((edge_value16_kernel<false, true>), V16_LDS_BYTES);
@@ -2543,6 +2635,10 @@ int td_launch_edge_value16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 
         TD_LDS_ONCE((edge_value16_kernel<false, false>), V16_LDS_BYTES);
         edge_value16_kernel<false, false><<<dim3(G), block, V16_LDS_BYTES, s>>>(a);
     }
+#undef TD_V16_LAUNCH_WALK
+#undef TD_V16_LAUNCH_WALK_L2
+#undef TD_V16T_LAUNCH_ANY
+#undef TD_V16_LAUNCH
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }

@@ -50,7 +50,14 @@ struct FoldedMlp {
     float ln_c1 = 1.f / 128.f, ln_c2 = 1e-5f;        // the kernels' variance constants (below)
     int dead_units = 0;
     bool overflow_risk = false;                      // M^2 * (pre-LayerNorm variance of 1e8) would leave the fp32 range
-    FoldedMlp(const MlpSrc &m, int in, int hid, int out)
+    // first_scale (round 6, late): the whole first Linear -- every column, the bias -- times 2^first_scale_exp, and ln_c2 times its
+    // square: the normalised activations do not change (a power of two goes through every product, sum and the rsqrt exactly: the kernels
+    // that do not care produce the same bits as without it), and the per-edge columns' largest weight sits in [2^13, 2^14) -- where the
+    // f16 piece-pair table of the key pass's first layer (pack_h2_table) needs it, since its products accumulate onto the gathered node
+    // projections, which therefore have to be in the same units
+    int first_scale_exp = 0;
+    bool first_scaled = false;
+    FoldedMlp(const MlpSrc &m, int in, int hid, int out, bool first_scale = false)
         : w0((size_t)hid * in), b0(hid), g(hid), b(hid), w3((size_t)out * hid), b3v(m.b3, m.b3 + out), b3(nullptr) {
         std::vector<float> sg(hid);
         std::vector<char> dead(hid, 0);
@@ -96,6 +103,20 @@ struct FoldedMlp {
         for (int o = 0; o < out; ++o)
             for (int n = 0; n < hid; ++n) w3[(size_t)o * hid + n] = m.w3[(size_t)o * hid + n] * g[n];
         b3 = b3v.data();
+        if (first_scale) {
+            const int edge_cols = in >= 2 * hid ? in - 2 * hid : in;          // [edge type | r_feat | h_i | h_j]
+            float wmax = 0.f;
+            for (int n = 0; n < hid; ++n)
+                for (int k = 0; k < edge_cols; ++k) wmax = std::max(wmax, fabsf(w0[(size_t)n * in + k]));
+            int e = (wmax > 0.f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+            e = e > 60 ? 60 : (e < -60 ? -60 : e);
+            while (e > -60 && !(M * M * 1e8 * ldexp(1.0, 2 * e) < 3.0e38)) --e;       // the LayerNorm's radicand stays in range
+            first_scale_exp = e;
+            first_scaled = true;
+            for (float &x : w0) x = ldexpf(x, e);
+            for (float &x : b0) x = ldexpf(x, e);
+            ln_c2 = ldexpf(ln_c2, 2 * e);
+        }
     }
     MlpSrc src() const { return MlpSrc{w0.data(), b0.data(), g.data(), b.data(), w3.data(), b3}; }
 };
@@ -191,13 +212,52 @@ void pack_pk4_table(uint32_t *dst, F w) {
         }
 }
 
+// The same 21-wide first layer on f16 piece PAIRS (round 6, late; the x2h key pass): w = a1 + a2 (a1 = f16 of w, a2 = f16 of the exact
+// residual: 22 bits), an input b = b1 + b2 likewise, and the three products a1 b1, a2 b1, a1 b2 of the lane group's five Gaussians are 15
+// K slots of the 16 the group has in TWO v_mfma_f32_16x16x32_f16; the sixteenth carries a piece of the type column's weight (piece 1 in
+// group 0, piece 2 in group 1; its input is exactly 1).  Per lane (hidden lo, group g) and hidden block, halves low first:
+//   I0 = (a1_0 a1_1 | a1_2 a1_3 | a2_0 a2_1 | a2_2 a2_3)   x   (b1_0 b1_1 | b1_2 b1_3 | b1_0 b1_1 | b1_2 b1_3)
+//   I1 = (a1_0 a1_1 | a1_2 a1_3 | a1_4 a1_4 | a2_4 T_g )   x   (b2_0 b2_1 | b2_2 b2_3 | b1_4 b2_4 | b1_4 1   )
+// One (dst class, source class) table: I0[hb 8][lane 64], I1[hb][lane], 16 bytes each = 16 KiB.  w(n, k): the folded, SCALED weight.
+constexpr size_t H2_WORDS = (size_t)2 * 8 * 64 * 4;
+template <class F>
+void pack_h2_table(uint32_t *dst, F w) {
+    auto half_bits = [](float x) -> uint32_t {
+        const _Float16 h = (_Float16)x;             // round to nearest even; subnormals kept
+        uint16_t u;
+        memcpy(&u, &h, 2);
+        return u;
+    };
+    auto half_value = [](uint32_t u) -> float {
+        const uint16_t v = (uint16_t)u;
+        _Float16 h;
+        memcpy(&h, &v, 2);
+        return (float)h;
+    };
+    for (int hb = 0; hb < 8; ++hb)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lo = lane & 15, g = lane >> 4, n = 16 * hb + lo;
+            uint32_t a1[6], a2[6];                     // pieces of k0 .. k4 and of the type column
+            for (int i = 0; i < 6; ++i) {
+                const float x = w(n, i < 5 ? 5 * g + i : TD_NG);
+                a1[i] = half_bits(x);
+                a2[i] = half_bits(x - half_value(a1[i]));
+            }
+            auto pair = [](uint32_t lo16, uint32_t hi16) { return lo16 | (hi16 << 16); };
+            uint32_t *I0 = dst + ((size_t)hb * 64 + lane) * 4, *I1 = dst + (size_t)8 * 64 * 4 + ((size_t)hb * 64 + lane) * 4;
+            I0[0] = pair(a1[0], a1[1]); I0[1] = pair(a1[2], a1[3]); I0[2] = pair(a2[0], a2[1]); I0[3] = pair(a2[2], a2[3]);
+            I1[0] = pair(a1[0], a1[1]); I1[1] = pair(a1[2], a1[3]); I1[2] = pair(a1[4], a1[4]);
+            I1[3] = pair(a2[4], g == 0 ? a1[5] : (g == 1 ? a2[5] : 0u));
+        }
+}
+
 size_t pack_vec(Packer &pk, const float *v, size_t n, size_t padded) {
     size_t off = pk.alloc(padded ? padded : n);
     if (v) memcpy(pk.data.data() + off, v, n * sizeof(float));
     return off;
 }
 
-struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q; float ln_c1, ln_c2, w2_bound; bool z_plain; };
+struct EdgeOff { size_t R, gamma, beta, W2, b2, Walt, R16, Walt16, R16q, R16h = 0; float ln_c1, ln_c2, w2_bound; bool z_plain; };
 
 EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, int alt) {
     const MlpSrc m = fm.src();
@@ -257,6 +317,17 @@ EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, 
                 return k < TD_NG ? m.w0[(size_t)n * in_dim + 4 + TD_NG * type + k] : m.w0[(size_t)n * in_dim + type];
             });
         }
+    // ... and, for the key MLP of an x2h stage, as f16 piece pairs (pack_h2_table): [dst class][source class] x 16 KiB
+    if ((alt == 1 || alt == 2) && fm.first_scaled) {
+        o.R16h = pk.alloc((size_t)2 * 2 * H2_WORDS);
+        for (int cls = 0; cls < 2; ++cls)
+            for (int sl = 0; sl < 2; ++sl) {
+                const int type = cls == 0 ? (sl == 0 ? 0 : 2) : (sl == 0 ? 1 : 3);
+                pack_h2_table(reinterpret_cast<uint32_t *>(pk.data.data() + o.R16h) + ((size_t)cls * 2 + sl) * H2_WORDS, [&](int n, int k) {
+                    return k < TD_NG ? m.w0[(size_t)n * in_dim + 4 + TD_NG * type + k] : m.w0[(size_t)n * in_dim + type];
+                });
+            }
+    }
     o.gamma = pack_vec(pk, m.g, TD_H);
     o.beta = pack_vec(pk, m.b, TD_H);
     if (out_dim == TD_H) {
@@ -484,7 +555,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             const float *ewm = c.ew_net_type == 3 ? cur.take(H + 1) : nullptr;
             if (!cur.ok) break;
             // the edge MLPs with their LayerNorm folded in (the query MLPs run node-side and keep theirs)
-            const FoldedMlp fhk(hk, KV, H, H), fhv(hv, KV, H, H);
+            const FoldedMlp fhk(hk, KV, H, H, true), fhv(hv, KV, H, H, true);
             hk = fhk.src(); hv = fhv.src();
             fold_overflow = fold_overflow || fhk.overflow_risk || fhv.overflow_risk;
             if (c.ew_net_type != 0) gate_rows(o.ew_x2h, ewx);
@@ -566,7 +637,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
     m->gate = TdGate{D + oGR, D + oGb0, D + oGg, D + oGb, D + oGw3, gate_b3, D + oGoff, gate_coeff, D + oGRp, fgate.ln_c1, fgate.ln_c2, m->opt.edge_key_split != 0};
     auto edge = [&](const EdgeOff &o, bool split = false) {
         return TdEdgeMlp{D + o.R, D + o.gamma, D + o.beta, D + o.W2, D + o.b2, D + o.R16, D + o.Walt16, D + o.Walt,
-                         D + o.R16q, o.ln_c1, o.ln_c2, o.w2_bound, m->opt.edge_second_layer_f16 != 0, o.z_plain, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
+                         D + o.R16q, o.R16h ? D + o.R16h : nullptr, o.ln_c1, o.ln_c2, o.w2_bound, m->opt.edge_second_layer_f16 != 0, m->opt.edge_first_layer_f16 != 0 && o.R16h != 0, o.z_plain, split && m->opt.edge_key_split != 0, m->opt.edge_row_dealing};
     };
     auto node = [&](const NodeOff &o) {
         return TdNodeStage{D + o.projB, D + o.projBias, D + o.qGamma, D + o.qBeta, D + o.q3B, D + o.q3Bias, D + o.projB3, D + o.q3B3,
@@ -629,6 +700,12 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
             m->layers[l].xk.use_split = m->layers[l].xk.R16q && value != 0;
             m->layers[l].xv.use_split = m->layers[l].xv.R16q && value != 0;
         }
+    } else if (strcmp(name, "edge_first_layer_f16") == 0) {
+        m->opt.edge_first_layer_f16 = value != 0;
+        for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) {
+            m->layers[l].hk.l1_f16 = m->layers[l].hk.R16h && value != 0;
+            m->layers[l].hv.l1_f16 = m->layers[l].hv.R16h && value != 0;
+        }
     } else if (strcmp(name, "edge_second_layer_f16") == 0) {
         m->opt.edge_second_layer_f16 = value != 0;
         for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l)
@@ -653,6 +730,7 @@ extern "C" int td_model_get_option(const td_model *m, const char *name, int32_t 
     else if (strcmp(name, "edge_row_dealing") == 0) *value = m->opt.edge_row_dealing;
     else if (strcmp(name, "edge_key_split") == 0) *value = m->opt.edge_key_split;
     else if (strcmp(name, "edge_second_layer_f16") == 0) *value = m->opt.edge_second_layer_f16;
+    else if (strcmp(name, "edge_first_layer_f16") == 0) *value = m->opt.edge_first_layer_f16;
     else if (strcmp(name, "session_hop_levels") == 0) *value = m->opt.session_hop_levels;
     else if (strcmp(name, "session_forward_reach") == 0) *value = m->opt.session_forward_reach;
     else if (strcmp(name, "session_step_lists") == 0) *value = m->opt.session_step_lists;

@@ -414,9 +414,11 @@ def test_sampling_with_fp32_edge_first_layer(state_dict):
     close(torch.stack(res[(1, True)]['pos_traj']), torch.stack(res[(0, True)]['pos_traj']), 5e-5)
 
 
+@pytest.mark.parametrize('opt', ['edge_second_layer_f16', 'edge_first_layer_f16'])
 @pytest.mark.parametrize('cfg', [dict(), dict(cutoff_mode='hybrid'), dict(knn=48)], ids=['knn32', 'hybrid', 'knn48'])
-def test_sampling_with_fp32_second_layer(state_dict, cfg):
-    """edge_second_layer_f16 = 0 (logits and alpha^T z on the fp32 matrix instruction instead of f16 piece pairs) stays a tested path: 5 reverse
+def test_sampling_with_fp32_second_layer(state_dict, cfg, opt):
+    """edge_second_layer_f16 = 0 (logits and alpha^T z on the fp32 matrix instruction instead of f16 piece pairs) and edge_first_layer_f16 = 0
+    (the radial / type first layer of the x2h passes on the exact bf16 piece triples instead of f16 piece pairs) stay tested paths: 5 reverse
     steps through the session and the stateless forward against the default -- same types, positions within the sampling tolerance, session ==
     stateless bit for bit under either setting.  On the default graph, on a `hybrid` graph (protein rows through the default graph's kernels,
     ligand rows through the chunk walk) and at k = 48 (chunk walk: the value pass follows the option, the key pass is fp32 either way).  (That
@@ -431,8 +433,8 @@ def test_sampling_with_fp32_second_layer(state_dict, cfg):
     for l2 in (1, 0):
         for use_session in (True, False):
             model = _model(state_dict, **cfg)
-            assert model._native(dev).get_option('edge_second_layer_f16') == 1            # shipped default
-            model._native(dev).set_option('edge_second_layer_f16', l2)
+            assert model._native(dev).get_option(opt) == 1            # shipped default
+            model._native(dev).set_option(opt, l2)
             res[(l2, use_session)] = model.sample_diffusion(
                 bd.protein_pos, bd.protein_atom_feature.float(), bd.protein_element_batch, lpos.to(dev), lv.to(dev),
                 bd.ligand_element_batch, num_steps=5, center_pos_mode='protein', noise_source=draws.Source(77, dev),

@@ -138,6 +138,17 @@ def test_node_stage_projections(model, state_dict):
                 want.append(fold(hd @ w0[:, 84:212].T + b0))
                 want.append(fold(hd @ w0[:, 212:340].T))
             want = torch.cat(want, dim=1)
+            if stage == 0:
+                # the whole first layer of an x2h edge MLP is packed in units of 2^e, the power of two that puts the largest folded per-edge
+                # weight (type + radial columns) into [2^13, 2^14): the f16 piece-pair tables of the x2h passes need it there, and their
+                # products accumulate onto these projections (FoldedMlp::first_scale_exp, csrc/pack.cpp); the activations are scale-free
+                P = P.clone()
+                for seg, nm in enumerate(names[:2]):
+                    w0 = state_dict[pre + nm + '.net.0.weight'].double()
+                    sg = torch.where(state_dict[pre + nm + '.net.1.weight'].double() < 0, -1.0, 1.0)
+                    edge = (sg[:, None] * (w0[:, :84] - w0[:, :84].mean(dim=0, keepdim=True))).float().abs().max().item()
+                    e = 13 - int(np.floor(np.log2(edge)))
+                    P[:, 256 * seg:256 * (seg + 1)] = torch.ldexp(P[:, 256 * seg:256 * (seg + 1)], torch.tensor(-e, device=P.device))
             close(P, want, 5e-5, (N, layer, stage))
             from oracle import restatement as R
             qw = R._mlp(state_dict, pre + names[2], hd, torch.float64)

@@ -44,29 +44,32 @@ def _args(g, dev):
 
 @pytest.mark.parametrize('name', ['forward_ln_dead.npz', 'forward_trained_g4.npz', 'forward_trained_g8.npz'])
 def test_forward_weight_regimes_vs_reference(name):
-    """One forward (return_all) per variant of the attention passes' arithmetic: first layer on bf16 piece triples (default) or fp32, second
-    layer on f16 piece pairs (default) or fp32 -- every combination is held to the same tolerance against the same golden."""
+    """One forward (return_all) per variant of the attention passes' arithmetic: first layer on f16 piece pairs (default), on the exact bf16
+    piece triples or on fp32, second layer on f16 piece pairs (default) or fp32 -- every combination is held to the same tolerance against
+    the same golden."""
     dev = _dev()
     g = load_golden(name)
     sd = regime_state_dict(name)
     seen = {}
-    for split, l2 in ((1, 1), (1, 0), (0, 0)):
+    for split, l1, l2 in ((1, 1, 1), (1, 0, 1), (1, 0, 0), (0, 0, 0)):
         model = _model(sd)
+        assert model._native(dev).get_option('edge_first_layer_f16') == 1 and model._native(dev).get_option('edge_second_layer_f16') == 1     # shipped defaults
         model._native(dev).set_option('edge_key_split', split)
+        model._native(dev).set_option('edge_first_layer_f16', l1)
         model._native(dev).set_option('edge_second_layer_f16', l2)
-        assert model._native(dev).get_option('edge_second_layer_f16') == l2
+        assert model._native(dev).get_option('edge_second_layer_f16') == l2 and model._native(dev).get_option('edge_first_layer_f16') == l1
         p = model(*_args(g, dev), return_all=True)
         for k in ('pred_ligand_pos', 'pred_ligand_v', 'final_h'):
-            close(p[k], g[k], regime_tolerance(g, k, TOL_FWD), (name, 'split', split, 'f16 second layer', l2, k))
+            close(p[k], g[k], regime_tolerance(g, k, TOL_FWD), (name, 'split', split, 'f16 first layer', l1, 'f16 second layer', l2, k))
             d64, r64 = _maxdiff(p[k], g[k + '_f64']), _maxdiff(g[k], g[k + '_f64'])
-            print(f'{name} first layer split {split}, second layer f16 {l2}, {k}: HIP vs float64 {d64:.3e}, fp32 reference vs float64 {r64:.3e}')
+            print(f'{name} first layer split {split} / f16 {l1}, second layer f16 {l2}, {k}: HIP vs float64 {d64:.3e}, fp32 reference vs float64 {r64:.3e}')
             assert d64 <= max(TOL_FWD, 2.0 * r64), (name, k, d64, r64)
-        seen[(split, l2)] = p['final_h'].clone()
+        seen[(split, l1, l2)] = p['final_h'].clone()
         tol_h = regime_tolerance(g, 'final_h', TOL_FWD)
         close(p['final_ligand_h'], g['final_ligand_h'], tol_h, (name, 'final_ligand_h'))
         close(p['layer_pred_ligand_v'][0], g['layer0_pred_ligand_v'], regime_tolerance(g, 'pred_ligand_v', TOL_FWD), (name, 'layer 0 v'))
         close(p['layer_pred_ligand_pos'][0], g['layer0_pred_ligand_pos'], regime_tolerance(g, 'pred_ligand_pos', TOL_FWD), (name, 'layer 0 pos'))
-    assert not torch.equal(seen[(1, 1)], seen[(1, 0)]) and not torch.equal(seen[(1, 0)], seen[(0, 0)])          # both options are live
+    assert not torch.equal(seen[(1, 1, 1)], seen[(1, 0, 1)]) and not torch.equal(seen[(1, 0, 1)], seen[(1, 0, 0)]) and not torch.equal(seen[(1, 0, 0)], seen[(0, 0, 0)])          # every option is live
 
 
 def test_dead_units_used_to_overflow_and_other_weights_differ():
