@@ -54,6 +54,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0         # same guide: ~2.5 PFLOP/s dense bf16 (24
 # first layer of an attention pass on bf16 piece triples: the six piece products of the 21 inputs K-packed into four 32-deep instructions
 # (csrc/edge16.hip td_pk4_tiles), all 32 slots of the row
 FIRST_LAYER_FLOP_BF16_EXECUTED = 4 * 2 * 32 * 128 * 32
+FIRST_LAYER_FLOP_F16_EXECUTED = 2 * 2 * 32 * 128 * 32     # f16 piece pairs: two 32-deep instructions per tile
 PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E ~ 8 TB/s
 # Dominant kernels: edge_value16t_kernel (x2h value pass, default graph) and its twin edge_key16_kernel (x2h key pass).  FLOPs per dst node,
 # identical for the two passes:
@@ -582,6 +583,8 @@ def main():
     slots_val = 32 * (cpn - 1) + (16 if (cpn > 1 and last <= 16 and args.cutoff_mode == 'knn') else 32)
     flop_val = 2 * (slots_val * 128 * 20 + slots_val * 128 * 16) + 2 * 128 * 128
     split = bool(model._native(dev).get_option('edge_key_split'))
+    l1_f16 = split and bool(model._native(dev).get_option('edge_first_layer_f16'))       # x2h passes: first layer on f16 piece pairs
+    first_exec = FIRST_LAYER_FLOP_F16_EXECUTED if l1_f16 else FIRST_LAYER_FLOP_BF16_EXECUTED
     # second layer on f16 piece pairs: the value pass on every graph, the key pass on rows of one chunk (the default graph; the protein rows of
     # `hybrid` / k < 32 / capped-radius graphs, which run the default graph's kernels through the chunk index); the chunk-walking key pass: fp32
     l2_f16 = bool(model._native(dev).get_option('edge_second_layer_f16')) and split
@@ -605,11 +608,11 @@ def main():
         if split_here and l2_here:
             # + the second layer (logits / alpha^T z: 2 * 32 * 128 * 16 algorithmic FLOPs per chunk) as three f16 piece products at the 16-bit peak
             second_alg = 2 * (min(fan_in, 32) if fan_in <= 32 else (32 * cpn if cls == 'x2h_k' else slots_val)) * 128 * 16
-            t_min = (chunks * (FIRST_LAYER_FLOP_BF16_EXECUTED + 3 * 2 * 32 * 128 * 16) / PEAK_BF16_MFMA_TFLOPS
+            t_min = (chunks * (first_exec + 3 * 2 * 32 * 128 * 16) / PEAK_BF16_MFMA_TFLOPS
                      + (per_row - first_alg - second_alg) / PEAK_FP32_MFMA_TFLOPS)
             bound = per_row / t_min
         elif split_here:
-            t_min = cpn * FIRST_LAYER_FLOP_BF16_EXECUTED / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
+            t_min = cpn * first_exec / PEAK_BF16_MFMA_TFLOPS + (per_row - first_alg) / PEAK_FP32_MFMA_TFLOPS
             bound = per_row / t_min
         else:
             bound = PEAK_FP32_MFMA_TFLOPS
@@ -634,7 +637,8 @@ def main():
         return {'bound': 'mfma', 'kernel': kernel, 'rows_per_launch': rows_per_launch, 'session_rows': session_rows, 'achieved': achieved,
                 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'matrix_bound_as_built': bound, 'frac_of_matrix_bound_as_built': achieved / bound,
-                'first_layer': 'bf16 x 3 piece triples, K-packed: 4 x v_mfma_f32_16x16x32_bf16 per tile' if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)',
+                'first_layer': (('f16 piece pairs (22 bits per operand), K-packed: 2 x v_mfma_f32_16x16x32_f16 per tile' if l1_f16
+                                 else 'bf16 x 3 piece triples, K-packed: 4 x v_mfma_f32_16x16x32_bf16 per tile') if split_here else 'fp32 (v_mfma_f32_16x16x4_f32)'),
                 'second_layer': ('f16 piece pairs (22 bits per operand), 3 x v_mfma_f32_16x16x32_f16 per tile; the per-row 128 x 128 product on the vector unit'
                                  if (split_here and l2_here) else 'fp32 (v_mfma_f32_16x16x4_f32); the per-row 128 x 128 product on the vector unit'),
                 'traffic': traffic, 'traffic_source': source, 'launch_ms': ms, 'launches': p['launches'],
@@ -683,13 +687,16 @@ def main():
           'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
         + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
            f'(fp32-equivalent: errors against the reference golden unchanged, {split_error_table()})')
-        + ('; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split' if split else '')
+        + (('; the 21-wide radial/type first layer of the x2h attention passes on f16 piece pairs: weights (scaled by a power of two per MLP) and '
+            'inputs carried to 22 bits (the exact bf16 x 3 form stays selectable: edge_first_layer_f16 = 0; the h2x stage and the edge gate use it)'
+            if l1_f16 else '; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split') if split else '')
         + ('; their per-edge second-layer products (logits, alpha^T z) on f16 piece pairs: operands carried to 22 bits, within one to two fp32 '
-           'roundings of the fp32 products (tests/test_gpu_weight_regimes.py holds both forms to the same goldens)' if l2_f16 else '') + ')',
+           'roundings of the fp32 products (tests/test_gpu_weight_regimes.py holds every form to the same goldens)' if l2_f16 else '') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
-                   'edge_first_layer': 'exact bf16 x 3 operand split, fp32 accumulate' if split else 'fp32 MFMA',
+                   'edge_first_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate (x2h passes; h2x stage and edge gate: exact bf16 x 3 split)'
+                                         if l1_f16 else 'exact bf16 x 3 operand split, fp32 accumulate') if split else 'fp32 MFMA'),
                    'edge_second_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate'
                                           + ('' if l2_key else '; the chunk-walking key pass: fp32 MFMA')) if l2_f16 else 'fp32 MFMA'),
                    'step_launch': step_launch, 'build_tag': capi.build_tag(),

@@ -297,7 +297,7 @@ class NativeModel:
     # ------------------------------------------------------------------------------------------
     @_device_bound
     def set_option(self, name: str, value: int):
-        """Per-model switch (td_model_set_option): 'node_proj_split', 'edge_key_split', 'edge_second_layer_f16', 'h2x_fused', 'session_share_pockets', 'session_hop_levels',
+        """Per-model switch (td_model_set_option): 'node_proj_split', 'edge_key_split', 'edge_first_layer_f16', 'edge_second_layer_f16', 'h2x_fused', 'session_share_pockets', 'session_hop_levels',
         'session_forward_reach', 'session_step_lists'.  Stored in the native handle; nothing is read from the environment."""
         _check(self.lib.td_model_set_option(self.handle, name.encode(), int(value)), 'td_model_set_option')
 
