@@ -586,9 +586,10 @@ def main():
     l1_f16 = split and bool(model._native(dev).get_option('edge_first_layer_f16'))       # x2h passes: first layer on f16 piece pairs
     first_exec = FIRST_LAYER_FLOP_F16_EXECUTED if l1_f16 else FIRST_LAYER_FLOP_BF16_EXECUTED
     # second layer on f16 piece pairs: the value pass on every graph, the key pass on rows of one chunk (the default graph; the protein rows of
-    # `hybrid` / k < 32 / capped-radius graphs, which run the default graph's kernels through the chunk index); the chunk-walking key pass: fp32
+    # `hybrid` / k < 32 / capped-radius graphs, which run the default graph's kernels through the chunk index) and, beside the f16 first layer,
+    # on the chunk walk
     l2_f16 = bool(model._native(dev).get_option('edge_second_layer_f16')) and split
-    l2_key = l2_f16 and (default_graph or cpn == 1)
+    l2_key = l2_f16 and (default_graph or cpn == 1 or l1_f16)      # (the chunk-walking key pass: f16 logits only beside the f16 first layer)
 
     def pass_roofline(cls, kernel, traffic_file):
         p = prof[cls]
@@ -650,14 +651,14 @@ def main():
                 'share_of_step': (p['ms'] / prof_steps) / (sec_per_step * 1e3), 'profiled_steps': prof_steps}
 
     if default_graph:
-        vk, kk = (('edge_value16t_kernel<L2> (12 waves)', 'edge_key16_kernel<false, 12, 0, 0, true, L2>') if split
+        vk, kk = (('edge_value16t_kernel<L2, false, FL> (12 waves)', 'edge_key16_kernel<false, 12, 0, 0, true, L2, FL>') if split
                   else ('edge_value16_kernel<false>', 'edge_key16_kernel<false, 16, 0, 0, false>'))
     elif split and cpn == 1:      # one chunk per protein row: the default graph's kernels through the chunk index, the ligand rows in a second launch
-        vk = 'edge_value16t_kernel<L2, true> (12 waves; protein rows) + edge_value16_kernel<true, true, false, L2> (chunk-walking; ligand rows)'
-        kk = 'edge_key16_kernel<false, 12, 0, 2, true, L2> (protein rows) + edge_key16_kernel<false, 12, 0, 1, true, 0> (chunk-walking; ligand rows)'
+        vk = 'edge_value16t_kernel<L2, true, FL> (12 waves; protein rows) + edge_value16_kernel<true, true, false, L2, FL> (chunk-walking; ligand rows)'
+        kk = 'edge_key16_kernel<false, 12, 0, 2, true, L2, FL> (protein rows) + edge_key16_kernel<false, 12, 0, 1, true, L2, FL> (chunk-walking; ligand rows)'
     else:
-        vk = 'edge_value16_kernel<true, true, false, L2> (chunk-walking)' if split else 'edge_value16_kernel<false, true> (chunk-walking)'
-        kk = 'edge_key16_kernel<false, 12, 0, 1, true, 0>' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
+        vk = 'edge_value16_kernel<true, true, false, L2, FL> (chunk-walking)' if split else 'edge_value16_kernel<false, true> (chunk-walking)'
+        kk = 'edge_key16_kernel<false, 12, 0, 1, true, L2, FL> (chunk-walking)' if split else 'edge_key16_kernel<false, 16, 0, 1, false>'
     roofline = pass_roofline('x2h_v', vk + ' (x2h value pass)', 'traffic_x2h_value.json')
     if roofline is not None:
         roofline['key_pass'] = pass_roofline('x2h_k', kk + ' (x2h key pass)', 'traffic_x2h_key.json')

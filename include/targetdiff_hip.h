@@ -132,7 +132,7 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *                            products; 0 = v_mfma_f32_16x16x4_f32 on the fp32 values.  Applies to the value pass
  *                            on every graph and to the key pass on rows of one 32-slot chunk (the default k = 32 graph; the protein rows
  *                            of `hybrid`, k < 32 and capped-radius graphs); the key pass of rows that span several chunks (k > 32, the
- *                            ligand rows of `hybrid`) computes fp32 logits under either setting
+ *                            ligand rows of `hybrid`) follows it only while "edge_first_layer_f16" is on (fp32 logits otherwise)
  *   "h2x_fused"              1 (default): key + value halves of the h2x stage in one launch; 0 = two launches
  *   "session_hop_levels"     1 .. 4 (default 4): receptive-field levels a sampling session prunes the last layers with
  *   "session_forward_reach"  1 (default): layer 1 of a session runs on the ligand's one-hop forward reach only

@@ -869,7 +869,7 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 
 #define TD_KEY_WAVES 12
 #endif
 #ifndef TD_KEY_WALK_F16
-#define TD_KEY_WALK_F16 0          // f16 logits in the chunk-walking key pass: measured slower (td_launch_edge_key16)
+#define TD_KEY_WALK_F16 1          // f16 logits in the chunk-walking key pass, where its first layer runs on f16 pairs too (td_launch_edge_key16)
 #endif
 constexpr int K16S_WAVES = TD_KEY_WAVES;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
 #ifndef TD_KEY_PK
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     constexpr bool CHUNKED = GRAPH == 1;       // walks the chunks of a row
     constexpr bool VIA = GRAPH == 2;           // one chunk per row, found through cptr; ligand rows are somebody else's
     // logits on v_mfma_f32_16x16x32_f16 (f16 piece pairs): the x2h key pass on rows of one chunk (the default graph, the protein rows of a
-    // `hybrid` graph); the chunk walk can (TD_KEY_WALK_F16) and does not: measured slower.  (The unfused h2x key pass keeps the fp32
+    // `hybrid` graph) and, with the first layer on f16 pairs, the chunk walk (TD_KEY_WALK_F16).  (The unfused h2x key pass keeps the fp32
     // product: the fused and the unfused form of that stage run different kernels on the same rows and are held bit-identical.)
     constexpr bool L2H = L2 != 0;
     static_assert(L2 == 0 || (SPLIT && !XV && STAGE == 0), "f16 logits: x2h key pass, bf16 first layer");
@@ -2474,14 +2474,20 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
         }                                                                                                                 \
     } while (0)
 #define TD_KEY_LAUNCH_WALK_L2(L2V) TD_KEY_LAUNCH_X2H(1, L2V)
-    // the chunk walk's key pass keeps the fp32 logits: on f16 piece pairs (TD_KEY_WALK_F16 = 1: 9 spilled registers at the 168 budget, the
-    // row's query and U_i rebuilt per chunk as before) C5 k = 48 / k = 64 key pass 11.16 -> 11.40 / 12.78 -> 12.89 ms per step, one call
+    // the chunk walk's key pass takes f16 logits only together with the f16 first layer: with the bf16 piece triples the kernel spilled 9
+    // registers at its 168 budget and lost (C5 k = 48 / k = 64 key pass 11.16 -> 11.40 / 12.78 -> 12.89 ms per step); with the f16 tables it
+    // needs 158 and wins (10.54 -> 10.15 / 12.28 -> 11.65, one call each)
 #if TD_KEY_WALK_F16
+#define TD_KEY_LAUNCH_WALK_F16(L2V)                                                                                           \
+    do {                                                                                                                  \
+        TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V, 1>), K16S_LDS_BYTES);                          \
+        edge_key16_kernel<false, K16S_WAVES, 0, 1, true, L2V, 1><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+    } while (0)
 #define TD_KEY_LAUNCH_WALK()                                                        \
     do {                                                                            \
-        if (!mlp.l2_f16) TD_KEY_LAUNCH_WALK_L2(0);                                  \
-        else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_WALK_L2(2);           \
-        else TD_KEY_LAUNCH_WALK_L2(1);                                              \
+        if (!mlp.l2_f16 || !mlp.l1_f16) TD_KEY_LAUNCH_WALK_L2(0);                   \
+        else if (mlp.z_plain && !TD_ZPLAIN_OFF) TD_KEY_LAUNCH_WALK_F16(2);          \
+        else TD_KEY_LAUNCH_WALK_F16(1);                                             \
     } while (0)
 #else
 #define TD_KEY_LAUNCH_WALK() TD_KEY_LAUNCH_WALK_L2(0)

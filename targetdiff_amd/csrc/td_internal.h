@@ -154,7 +154,7 @@ struct TdOptions {
     int node_proj_split = 1;       // node-side GEMMs on exact bf16 x 3 operand pieces with fp32 accumulation (0: fp32 MFMA)
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
     int edge_first_layer_f16 = 1;  // x2h passes: the 21-wide radial / type first layer on f16 piece pairs (two products per tile; 0: the exact bf16 piece triples, four)
-    int edge_second_layer_f16 = 1; // x2h passes: logits / alpha^T z on f16 piece pairs (0: fp32 MFMA products; the chunk-walking key pass is fp32 either way)
+    int edge_second_layer_f16 = 1; // x2h passes: logits / alpha^T z on f16 piece pairs (0: fp32 MFMA products; the chunk-walking key pass takes the f16 logits only beside the f16 first layer)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only
     int edge_row_dealing = 2;      // x2h key / value passes: units of rows dealt round-robin to an XCD's workgroups (0: one
