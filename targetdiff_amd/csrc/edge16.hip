@@ -871,7 +871,7 @@ constexpr size_t K16_LDS_BYTES = (size_t)(E16_R_FLOATS + E16_WQ_FLOATS + TD_H + 
 #ifndef TD_KEY_WALK_F16
 #define TD_KEY_WALK_F16 1          // f16 logits in the chunk-walking key pass, where its first layer runs on f16 pairs too (td_launch_edge_key16)
 #endif
-constexpr int K16S_WAVES = TD_KEY_WAVES;     // bf16 first layer: 168 VGPRs -> 3 waves per SIMD, the 72 KiB piece table + Wq in LDS
+constexpr int K16S_WAVES = TD_KEY_WAVES;     // 16-bit first layer: <= 168 VGPRs -> 3 waves per SIMD, the piece tables (88 KiB bf16 triples / 64 KiB f16 pairs) + Wq in LDS
 #ifndef TD_KEY_PK
 #define TD_KEY_PK 3
 #endif
@@ -894,7 +894,8 @@ static_assert(K16S_LDS_BYTES <= 160 * 1024, "key pass: LDS");        // + the ro
 //             one chunk: in registers as on the default graph; several: the scaled logits go to alpha[c] with a running
 //             (max, sum) per head, then every lane re-reads its own entries and writes exp(x - max) / sum * gate.
 //             XV: delta_x accumulates over the chunks (scatter_sum, :139).
-// SPLIT = true: the first layer on bf16 piece triples (td_first_layer_split16; the whole piece table in LDS).
+// SPLIT = true: the first layer on 16-bit pieces (td_first_layer_split16; the whole piece table in LDS) -- exact bf16 triples, or (FL = 1,
+// x2h key pass) f16 pairs.
 // L2 (x2h key pass of the default graph, bf16 first layer): the logits product -- 0: fp32 (v_mfma_f32_16x16x4_f32), 1: f16 piece pairs
 // with z'' scaled by 2^15, 2: f16 piece pairs of z'' itself (the launcher's reading of TdEdgeMlp::l2_f16 / z_plain).
 // FL (x2h key pass, bf16-class first layer): 1 = the first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h; model option
@@ -1781,7 +1782,8 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
         h1 = a.h[(size_t)ix * TD_H + nout + 4];
     };
     // General graphs: the protein workgroups of a graph whose protein rows are one chunk wide (`hybrid`: plain k-NN rows, k <= 32)
-    // take the software-pipelined single-chunk loop below (chunk index through cptr); everything else walks chunks here.
+    // take the software-pipelined single-chunk loop below (chunk index through cptr); everything else walks chunks here.  (With the 16-bit
+    // first layer td_launch_edge_value16 sends such protein rows to edge_value16t_kernel<.., VIA> and only the ligand rows here.)
     if (CHUNKED && !(SPLIT && my_cls == 1 && a.cpn_p == 1)) {
         for (int64_t i = next_row(); i >= 0; i = next_row()) {
             if (SPLIT && dyn && !of_class(a.x4[i])) continue;
@@ -2113,6 +2115,7 @@ __global__ __launch_bounds__(V16_WAVES * 64) void edge_value16_kernel(Args16 a) 
 // product without the Zbar exchange (td_value_out16) 1.508 -> 1.440 -> with the 16.5 KiB of scratch that freed, both source-class tables
 // of the workgroup's destination class in the 48-byte form (PK = 1: three 16-byte reads per hidden block) 1.397.  156 registers,
 // 48 + 64 KiB of tables + 12 x 2.75 KiB of scratch = 146.4 KiB.  (Table quads a pair ahead -- 164 registers -- changes nothing: 1.395.)
+// Round 6: second layer on f16 piece pairs (L2), then the first layer too (FL = 1: 32 instead of 48 KiB of tables, 150 registers): 1.34 -> 1.27.
 constexpr int V16T_WAVES = 12;
 #ifndef TD_VALUET_PK
 #define TD_VALUET_PK 1
