@@ -688,15 +688,15 @@ def main():
           'parity-unpinned upstream; arithmetic fp32 throughout, the node-side 128 x 128 GEMMs '
         + ('on fp32 MFMA' if args.fp32_node_gemms else 'on an exact 3-way bf16 split of both fp32 operands with fp32 accumulation '
            f'(fp32-equivalent: errors against the reference golden unchanged, {split_error_table()})')
-        + (('; the 21-wide radial/type first layer of the x2h attention passes on f16 piece pairs: weights (scaled by a power of two per MLP) and '
-            'inputs carried to 22 bits (the exact bf16 x 3 form stays selectable: edge_first_layer_f16 = 0; the h2x stage and the edge gate use it)'
+        + (('; the 21-wide radial/type first layer of the attention kernels (x2h passes, h2x stage) on f16 piece pairs: weights (scaled by a power of two per MLP) and '
+            'inputs carried to 22 bits (the exact bf16 x 3 form stays selectable: edge_first_layer_f16 = 0; the edge gate uses it)'
             if l1_f16 else '; the 21-wide radial/type first layer of the x2h attention passes on the same kind of split') if split else '')
         + ('; their per-edge second-layer products (logits, alpha^T z) on f16 piece pairs: operands carried to 22 bits, within one to two fp32 '
            'roundings of the fp32 products (tests/test_gpu_weight_regimes.py holds every form to the same goldens)' if l2_f16 else '') + ')',
         'config': {'workload': desc, 'graph': graph_desc(args), 'ligand_spread': args.ligand_spread, 'nodes_per_gpu': n_nodes,
                    'edges_per_gpu': (32 if default_graph else fan_in) * n_nodes, 'graphs_per_gpu': graphs,
                    'node_gemms': 'fp32 MFMA' if args.fp32_node_gemms else 'exact bf16 x 3 operand split, fp32 accumulate',
-                   'edge_first_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate (x2h passes; h2x stage and edge gate: exact bf16 x 3 split)'
+                   'edge_first_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate (x2h passes and h2x stage; edge gate: exact bf16 x 3 split)'
                                          if l1_f16 else 'exact bf16 x 3 operand split, fp32 accumulate') if split else 'fp32 MFMA'),
                    'edge_second_layer': (('f16 piece pairs of both operands (22 significant bits each), fp32 accumulate'
                                           + ('' if l2_key else '; the chunk-walking key pass: fp32 MFMA')) if l2_f16 else 'fp32 MFMA'),

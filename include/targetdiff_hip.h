@@ -121,11 +121,11 @@ size_t td_model_num_weights(const td_config *cfg);      /* expected length of th
  *   "edge_key_split"         1 (default): the 21-wide radial / edge-type first layer of the attention passes on 32-slot rows
  *                            (x2h key and value passes, the h2x stage), of the chunked key pass and of the edge gate on v_mfma_f32_16x16x32_bf16
  *                            with the same exact three-piece split of both operands; 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32)
- *   "edge_first_layer_f16"   1 (default): the 21-wide radial / type first layer of the x2h key / value passes on v_mfma_f32_16x16x32_f16, weights
+ *   "edge_first_layer_f16"   1 (default): the 21-wide radial / type first layer of the attention kernels (x2h key / value passes, h2x stage) on v_mfma_f32_16x16x32_f16, weights
  *                            and inputs as pairs of f16 pieces (22 significant bits each; the MLP's first layer -- node projections included --
  *                            is packed in units of a power of two so that no piece meets the f16 subnormal floor): two products and two
  *                            16-byte table reads per tile; 0 = the exact bf16 x 3 piece triples (four products, three reads).  Needs
- *                            "edge_key_split"; the h2x stage and the edge gate use the bf16 form under either setting
+ *                            "edge_key_split"; the edge gate uses the bf16 form under either setting
  *   "edge_second_layer_f16"  1 (default): the per-edge 128-deep products of the x2h key / value passes (logits = z . U_i, alpha^T z) on
  *                            v_mfma_f32_16x16x32_f16, both operands as pairs of f16 pieces (22 significant bits each, scaled by exact
  *                            powers of two; three piece products, fp32 accumulation): within one to two fp32 roundings of the fp32

@@ -910,9 +910,9 @@ __global__ __launch_bounds__(WAVES * 64) void edge_key16_kernel(Args16 a) {
     // product: the fused and the unfused form of that stage run different kernels on the same rows and are held bit-identical.)
     constexpr bool L2H = L2 != 0;
     static_assert(L2 == 0 || (SPLIT && !XV && STAGE == 0), "f16 logits: x2h key pass, bf16 first layer");
-    // the x2h key pass's first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h); the h2x key / value halves keep the bf16 piece triples
-    // (they are held bit-identical to the fused h2x kernel)
-    static_assert(FL == 0 || (SPLIT && !XV && STAGE == 0), "f16 first layer: x2h key pass, bf16-class instantiations");
+    // first layer on f16 piece pairs (PK = 5, TdEdgeMlp::R16h): the x2h key pass, and the unfused h2x key / value halves whenever the fused
+    // h2x kernel takes them too (they are held bit-identical to it)
+    static_assert(FL == 0 || SPLIT, "f16 first layer: the 16-bit instantiations");
     constexpr int KPK = FL ? 5 : TD_KEY_PK;
     constexpr int RF = SPLIT ? e16q_u4<KPK>() * 4 : E16_R_FLOATS;       // floats of the radial/type table (SPLIT: K-packed)
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
@@ -1266,10 +1266,13 @@ struct ArgsH2x {
     TdEdgeMlp mlp_v;       // xv MLP
 };
 
-template <bool SPLIT>
+// FL = 1: both halves' first layers on f16 piece pairs (PK = 5, TdEdgeMlp::R16h; model option "edge_first_layer_f16")
+template <bool SPLIT, int FL = 0>
 __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar) {
     constexpr int WAVES = H2X16_WAVES;
-    constexpr int RH = h2x16_table_floats<SPLIT>();
+    static_assert(FL == 0 || SPLIT, "f16 first layer: the 16-bit instantiation");
+    constexpr int HPK = FL ? 5 : 2;
+    constexpr int RH = FL ? e16q_half_u4<5>() * 4 : h2x16_table_floats<SPLIT>();
     constexpr int NOFF = SPLIT ? 8 : E16_STEPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Args16 &a = ar.a;
@@ -1282,10 +1285,12 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
     if (a.trace && threadIdx.x == 0) a.trace[8 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();      // kernel entry: slot 0 - slot 4 = table staging
     {
         // destination class 0 (ligand) is the first half of either table
-        if (SPLIT) td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
+        if constexpr (FL) td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16h), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        else if (SPLIT) td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
         else td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
-        if (SPLIT) td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
+        if constexpr (FL) td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16h), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        else if (SPLIT) td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
         else td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
         if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
@@ -1314,7 +1319,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         Edge2 ed;
         td_row_index16(a, i, i, lane, rin);
         td_row_gather16<true>(a, i, i, lane, rin, acc);
-        if constexpr (SPLIT) td_first_layer_split16<true, true, false, 2, false, 2, 1>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+        if constexpr (SPLIT) td_first_layer_split16<true, true, false, 2, false, HPK, 1>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
         else td_first_layer_compute16<true>(a, reinterpret_cast<const float4 *>(Rk), KBk, offk, rin, lane, acc, ed);
         // the value half's gathers (its own accumulators) fly while the logits and the softmax run.  The query is fetched BEFORE they are
         // issued: vmcnt counts in order, so a load issued after the gathers could only be waited for together with them -- and the
@@ -1349,7 +1354,7 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
         td_softmax16x4(lg, ed.valid, ed.ew, al);
         // ---- value half: xv MLP on the same edges, delta x = mean_heads sum_e alpha xv (x_i - x_j) ----------------------
         Edge2 ev;
-        if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, 2, 1>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
+        if constexpr (SPLIT) td_first_layer_split16<false, true, false, 2, false, HPK, 1>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rv, i, lane, accv, ev);
         else td_first_layer_compute16<false>(av, reinterpret_cast<const float4 *>(Rv), KBv, offk, rv, lane, accv, ev);
         floatx4_t xv[2];
 #pragma unroll
@@ -1395,9 +1400,11 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_kernel(ArgsH2x ar
 // alpha[c] and keeps a running (max, sum) per head; sweep 2 runs the xv MLP on each chunk and weights it with exp(x - max) / sum * gate
 // computed on the fly from the stored logits (same lane layout), accumulating delta x.  Arithmetic as in edge_key16_kernel<false, .., 1> +
 // edge_key16_kernel<true, .., 1>; tables as in edge_h2x16_kernel (both MLPs' ligand-destination halves resident).
+template <int FL = 0>
 __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(ArgsH2x ar) {
     constexpr int WAVES = H2X16_WAVES;
-    constexpr int RH = h2x16_table_floats<true>();
+    constexpr int HPK = FL ? 5 : 2;
+    constexpr int RH = FL ? e16q_half_u4<5>() * 4 : h2x16_table_floats<true>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Args16 &a = ar.a;
     float *Rk = lds, *WqF = Rk + RH, *Rv = WqF + E16_WQ_FLOATS, *WxF = Rv + RH, *GB = WxF + H2X16_WX_FLOATS;
@@ -1407,9 +1414,11 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lo = lane & 15, g = lane >> 4;
     {
-        td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
+        if constexpr (FL) td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.R16h), reinterpret_cast<float4 *>(Rk), RH / 4, tid, WAVES * 64);
+        else td_stage_pk4<2>(a.mlp.R16q, Rk, 2, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(a.mlp.Walt16), reinterpret_cast<float4 *>(WqF), E16_WQ_FLOATS / 4, tid, WAVES * 64);
-        td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
+        if constexpr (FL) td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.R16h), reinterpret_cast<float4 *>(Rv), RH / 4, tid, WAVES * 64);
+        else td_stage_pk4<2>(ar.mlp_v.R16q, Rv, 2, tid, WAVES * 64);
         td_stage_lds16(reinterpret_cast<const float4 *>(ar.mlp_v.Walt16), reinterpret_cast<float4 *>(WxF), H2X16_WX_FLOATS / 4, tid, WAVES * 64);
         if (tid < TD_H) GB[tid] = a.mlp.beta[tid];
         else if (tid < 2 * TD_H) GB[tid] = ar.mlp_v.beta[tid - TD_H];
@@ -1438,9 +1447,9 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
             td_row_index16(a, i, c, lane, rin);
             td_row_gather16<false>(a, i, c, lane, rin, acc);
             if (__ballot(rin.j[1] >= 0) == 0ull)              // wave-uniform: the chunk's second block is all padding
-                td_first_layer_split16<false, true, false, 1, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 1, false, HPK>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
             else
-                td_first_layer_split16<false, true, false, 2, false, 2>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 2, false, HPK>(a, reinterpret_cast<const uint4 *>(Rk), KBk, offk, rin, i, lane, acc, ed);
             floatx4_t lg[2];
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) lg[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -1503,9 +1512,9 @@ __global__ __launch_bounds__(H2X16_WAVES * 64) void edge_h2x16_chunked_kernel(Ar
             td_row_gather16<false>(av, i, c, lane, rin, acc);
             const float ew0 = a.ew[(size_t)c * TD_K + lo], ew1 = a.ew[(size_t)c * TD_K + 16 + lo];       // 0 on pads
             if (__ballot(rin.j[1] >= 0) == 0ull)
-                td_first_layer_split16<false, true, false, 1, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 1, false, HPK>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
             else
-                td_first_layer_split16<false, true, false, 2, false, 2>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
+                td_first_layer_split16<false, true, false, 2, false, HPK>(av, reinterpret_cast<const uint4 *>(Rv), KBv, offk, rin, i, lane, acc, ed);
             floatx4_t xv[2];
 #pragma unroll
             for (int eb = 0; eb < 2; ++eb) xv[eb] = floatx4_t{0.f, 0.f, 0.f, 0.f};
@@ -2495,7 +2504,15 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 #else
 #define TD_KEY_LAUNCH_WALK() TD_KEY_LAUNCH_WALK_L2(0)
 #endif
-    if (mlp.use_split) {                      // first layer on bf16 piece triples
+    // (the unfused h2x key pass: STAGE tag 1, fp32 logits; its first layer follows TdEdgeMlp::l1_f16 like the fused kernel's)
+#define TD_KEY_LAUNCH_H2X(GR)                                                                                                 \
+    do {                                                                                                                  \
+        if (mlp.l1_f16) {                                                                                                 \
+            TD_LDS_ONCE((edge_key16_kernel<false, K16S_WAVES, 1, GR, true, 0, 1>), K16S_LDS_BYTES);                        \
+            edge_key16_kernel<false, K16S_WAVES, 1, GR, true, 0, 1><<<dim3(grid16(a.count, K16S_WAVES)), dim3(K16S_WAVES * 64), K16S_LDS_BYTES, s>>>(a); \
+        } else TD_KEY_LAUNCH(K16S_WAVES, 1, GR, true, K16S_LDS_BYTES);                                                     \
+    } while (0)
+    if (mlp.use_split) {                      // first layer on 16-bit pieces
         if (cptr && !h2x && cpn_p == 1) {
 #define TD_KEY_LAUNCH_VIA(L2V) TD_KEY_LAUNCH_X2H(2, L2V)
             if (!mlp.l2_f16) TD_KEY_LAUNCH_VIA(0);
@@ -2506,8 +2523,8 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
                 a.rows = lig_rows; a.count_ptr = nullptr; a.count = lig_count; a.trace = nullptr;
                 TD_KEY_LAUNCH_WALK();
             }
-        } else if (cptr) { if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 1, true, K16S_LDS_BYTES); else TD_KEY_LAUNCH_WALK(); }
-        else if (h2x) TD_KEY_LAUNCH(K16S_WAVES, 1, 0, true, K16S_LDS_BYTES);
+        } else if (cptr) { if (h2x) TD_KEY_LAUNCH_H2X(1); else TD_KEY_LAUNCH_WALK(); }
+        else if (h2x) TD_KEY_LAUNCH_H2X(0);
         else {
 #define TD_KEY_LAUNCH_L2(L2V) TD_KEY_LAUNCH_X2H(0, L2V)
             if (!mlp.l2_f16) TD_KEY_LAUNCH_L2(0);
@@ -2523,6 +2540,7 @@ int td_launch_edge_key16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x
 #undef TD_KEY_LAUNCH_WALK
 #undef TD_KEY_LAUNCH_WALK_L2
 #undef TD_KEY_LAUNCH_X2H
+#undef TD_KEY_LAUNCH_H2X
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -2542,9 +2560,16 @@ int td_launch_edge_xv16(const TdEdgeMlp &mlp, const TdLayer &L, const float4 *x4
         TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, CH, SP>), BYTES);                  \
         edge_key16_kernel<true, XV16_WAVES, 1, CH, SP><<<grid, block, BYTES, s>>>(a);          \
     } while (0)
-    if (mlp.use_split) { if (cptr) TD_XV_LAUNCH(1, true, K16S_LDS_BYTES); else TD_XV_LAUNCH(0, true, K16S_LDS_BYTES); }
+#define TD_XV_LAUNCH_F16(CH)                                                                   \
+    do {                                                                                       \
+        TD_LDS_ONCE((edge_key16_kernel<true, XV16_WAVES, 1, CH, true, 0, 1>), K16S_LDS_BYTES); \
+        edge_key16_kernel<true, XV16_WAVES, 1, CH, true, 0, 1><<<grid, block, K16S_LDS_BYTES, s>>>(a); \
+    } while (0)
+    if (mlp.use_split && mlp.l1_f16) { if (cptr) TD_XV_LAUNCH_F16(1); else TD_XV_LAUNCH_F16(0); }
+    else if (mlp.use_split) { if (cptr) TD_XV_LAUNCH(1, true, K16S_LDS_BYTES); else TD_XV_LAUNCH(0, true, K16S_LDS_BYTES); }
     else { if (cptr) TD_XV_LAUNCH(1, false, K16_LDS_BYTES); else TD_XV_LAUNCH(0, false, K16_LDS_BYTES); }
 #undef TD_XV_LAUNCH
+#undef TD_XV_LAUNCH_F16
     TD_CHECK_HIP(hipGetLastError());
     return TD_OK;
 }
@@ -2665,9 +2690,16 @@ int td_launch_edge_h2x16(const TdEdgeMlp &mlp_k, const TdEdgeMlp &mlp_v, const T
     ar.mlp_v = mlp_v;
     a.trace = cptr ? nullptr : wg_trace_slot(2);
     const dim3 grid(grid16(count, H2X16_WAVES)), block(H2X16_WAVES * 64);
-    if (cptr) {           // general graphs: the chunk-walking form (bf16 first layer; the caller checks use_split)
-        TD_LDS_ONCE((edge_h2x16_chunked_kernel), h2x16_lds_bytes<true>());
-        edge_h2x16_chunked_kernel<<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
+    const bool f16_first = mlp_k.l1_f16 && mlp_v.l1_f16;          // both halves' first layers on f16 piece pairs
+    if (cptr && f16_first) {           // general graphs: the chunk-walking form (16-bit first layer; the caller checks use_split)
+        TD_LDS_ONCE((edge_h2x16_chunked_kernel<1>), h2x16_lds_bytes<true>());
+        edge_h2x16_chunked_kernel<1><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
+    } else if (cptr) {
+        TD_LDS_ONCE((edge_h2x16_chunked_kernel<0>), h2x16_lds_bytes<true>());
+        edge_h2x16_chunked_kernel<0><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
+    } else if (mlp_k.use_split && mlp_v.use_split && f16_first) {
+        TD_LDS_ONCE((edge_h2x16_kernel<true, 1>), h2x16_lds_bytes<true>());
+        edge_h2x16_kernel<true, 1><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);
     } else if (mlp_k.use_split && mlp_v.use_split) {
         TD_LDS_ONCE((edge_h2x16_kernel<true>), h2x16_lds_bytes<true>());
         edge_h2x16_kernel<true><<<grid, block, h2x16_lds_bytes<true>(), s>>>(ar);

@@ -318,7 +318,7 @@ EdgeOff pack_edge_mlp(Packer &pk, const FoldedMlp &fm, int in_dim, int out_dim, 
             });
         }
     // ... and, for the key MLP of an x2h stage, as f16 piece pairs (pack_h2_table): [dst class][source class] x 16 KiB
-    if ((alt == 1 || alt == 2) && fm.first_scaled) {
+    if (fm.first_scaled) {
         o.R16h = pk.alloc((size_t)2 * 2 * H2_WORDS);
         for (int cls = 0; cls < 2; ++cls)
             for (int sl = 0; sl < 2; ++sl) {
@@ -589,7 +589,7 @@ extern "C" int td_model_create(const td_config *cfg, const float *host_weights, 
             MlpSrc xk = cur.mlp(KV, H, H), xv = cur.mlp(KV, H, c.n_heads), xq = cur.mlp(H, H, H);
             const float *ewh = c.ew_net_type == 1 ? cur.take(4 * TD_NG + 1) : nullptr;
             if (!cur.ok) break;
-            const FoldedMlp fxk(xk, KV, H, H), fxv(xv, KV, H, c.n_heads);
+            const FoldedMlp fxk(xk, KV, H, H, true), fxv(xv, KV, H, c.n_heads, true);
             xk = fxk.src(); xv = fxv.src();
             fold_overflow = fold_overflow || fxk.overflow_risk || fxv.overflow_risk;
             if (c.ew_net_type != 0) gate_rows(o.ew_h2x, ewh);
@@ -705,6 +705,8 @@ extern "C" int td_model_set_option(td_model *m, const char *name, int32_t value)
         for (int l = 0; l < m->cfg.num_layers * stage_rows(m->cfg); ++l) {
             m->layers[l].hk.l1_f16 = m->layers[l].hk.R16h && value != 0;
             m->layers[l].hv.l1_f16 = m->layers[l].hv.R16h && value != 0;
+            m->layers[l].xk.l1_f16 = m->layers[l].xk.R16h && value != 0;
+            m->layers[l].xv.l1_f16 = m->layers[l].xv.R16h && value != 0;
         }
     } else if (strcmp(name, "edge_second_layer_f16") == 0) {
         m->opt.edge_second_layer_f16 = value != 0;

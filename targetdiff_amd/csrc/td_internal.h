@@ -62,13 +62,13 @@ struct TdEdgeMlp {
     const float *Walt;     // key MLPs: Wq[t][r][jq][hi][c<16][4] = W2[8c+4jq+jj][32t+erow(r,hi)];  hv: Wt[d][k/4][head][4] = W2v[8 head + d][k]
     const float *R16q;     // the radial/type table as exact bf16 piece triples, K-packed for four v_mfma_f32_16x16x32_bf16 per tile
                            // (pack_pk4_table, pack.cpp): [2 dst class][2 slot] x {QA, QB, H7, QC}[8 hidden block][64 lanes]
-    const float *R16h;     // x2h key MLP: the same table as f16 piece pairs for two v_mfma_f32_16x16x32_f16 per tile (pack_h2_table); the MLP's whole
+    const float *R16h;     // attention MLPs (hk, hv, xk, xv): the same table as f16 piece pairs for two v_mfma_f32_16x16x32_f16 per tile (pack_h2_table); the MLP's whole
                            // first layer, node projections included, is in units of 2^FoldedMlp::first_scale_exp
     float ln_c1, ln_c2;    // folded LayerNorm (FoldedMlp, pack.cpp): 1 / (sigma M) = rsqrt(sum_n c_n^2 * ln_c1 + ln_c2); z'' = clamp_[0,1](c_n / (sigma M) + beta_n)
     float w2_bound;        // key MLPs: 8 max |W2'| (folded second Linear): |U_i[n][head]| = |sum_d W2'[8 head + d][n] q_i[8 head + d]| <= w2_bound max |q_i|
                            // (the f16 logits product scales the query by a power of two from this bound, edge16.hip)
     bool l2_f16;           // x2h passes: logits (rows of one chunk) / alpha^T z (every graph) on v_mfma_f32_16x16x32_f16 with f16 piece pairs (model option "edge_second_layer_f16")
-    bool l1_f16;           // x2h passes: the radial / type first layer on f16 piece pairs (R16h; model option "edge_first_layer_f16"); false: exact bf16 piece triples
+    bool l1_f16;           // attention kernels (x2h passes, h2x stage): the radial / type first layer on f16 piece pairs (R16h; model option "edge_first_layer_f16"); false: exact bf16 piece triples
     bool z_plain;          // f16 second layer: the folded scale M is at most TD_Z_PLAIN_MAX_M, take the f16 pieces of z'' itself (edge16.hip, td_ln_relu16_pairs_*)
     bool use_split;        // run the first layer on the piece triples where a kernel has that variant (model option "edge_key_split")
     int deal_rows;         // x2h passes: rows dealt round-robin inside an XCD's range (model option "edge_row_dealing": 0 contiguous
@@ -153,7 +153,7 @@ struct TdOptions {
     int h2x_fused = 1;             // one launch for the h2x stage's key + value halves (0: two launches, alpha through memory)
     int node_proj_split = 1;       // node-side GEMMs on exact bf16 x 3 operand pieces with fp32 accumulation (0: fp32 MFMA)
     int edge_key_split = 1;        // attention passes: radial/type first layer on exact bf16 x 3 pieces (0: fp32 MFMA)
-    int edge_first_layer_f16 = 1;  // x2h passes: the 21-wide radial / type first layer on f16 piece pairs (two products per tile; 0: the exact bf16 piece triples, four)
+    int edge_first_layer_f16 = 1;  // x2h passes and h2x stage: the 21-wide radial / type first layer on f16 piece pairs (two products per tile; 0: the exact bf16 piece triples, four)
     int edge_second_layer_f16 = 1; // x2h passes: logits / alpha^T z on f16 piece pairs (0: fp32 MFMA products; the chunk-walking key pass takes the f16 logits only beside the f16 first layer)
     int session_hop_levels = 4;    // receptive-field levels a sampling session tracks (1 .. 4)
     int session_forward_reach = 1; // layer 1 of a session runs on the ligand's one-hop forward reach only

@@ -138,9 +138,9 @@ def test_node_stage_projections(model, state_dict):
                 want.append(fold(hd @ w0[:, 84:212].T + b0))
                 want.append(fold(hd @ w0[:, 212:340].T))
             want = torch.cat(want, dim=1)
-            if stage == 0:
-                # the whole first layer of an x2h edge MLP is packed in units of 2^e, the power of two that puts the largest folded per-edge
-                # weight (type + radial columns) into [2^13, 2^14): the f16 piece-pair tables of the x2h passes need it there, and their
+            if True:
+                # the whole first layer of an edge MLP is packed in units of 2^e, the power of two that puts the largest folded per-edge
+                # weight (type + radial columns) into [2^13, 2^14): the f16 piece-pair tables of the attention kernels need it there, and their
                 # products accumulate onto these projections (FoldedMlp::first_scale_exp, csrc/pack.cpp); the activations are scale-free
                 P = P.clone()
                 for seg, nm in enumerate(names[:2]):
